@@ -1,0 +1,287 @@
+"""CPU oracle for the DM-NeRF ray-rendering hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, float32) restatement of the reference algorithm
+for the path SURVEY.md section 8 scopes.  It is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+Nothing under ``dm_nerf_amd/`` imports it, and the product path raises when the HIP
+library is missing instead of falling back to this code.
+
+Parity pinning: every function below is checked bit-for-bit against the *imported*
+reference (``/root/reference``) in the build container by
+``tests/golden/make_golden.py`` (which also writes the committed fixtures under
+``tests/golden/*.npz``); ``tests/test_oracle_golden.py`` re-checks the oracle against
+those fixtures everywhere (CPU, no reference needed).
+
+Each function cites the reference lines it follows (paths relative to
+/root/reference).  Unlike the reference, every tensor is created on the device of
+its inputs -- no ``torch.set_default_tensor_type`` side effect (config.py:149-153).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# positional encoding  (networks/dm_nerf.py:8-55)
+# --------------------------------------------------------------------------------------
+
+def freq_bands(multires):
+    """``2.**linspace(0, L-1, L)`` -- exactly 1,2,4,...  (networks/dm_nerf.py:25)."""
+    return 2. ** torch.linspace(0., multires - 1, steps=multires)
+
+
+def embed(x, multires):
+    """``Embedder.embed`` (networks/dm_nerf.py:37-38) for include_input=True, log sampling.
+
+    Layout: ``[x | sin(x f0) | cos(x f0) | sin(x f1) | ...]`` in blocks of ``x.shape[-1]``.
+    """
+    outs = [x]
+    for freq in freq_bands(multires):
+        f = freq.to(x.device)
+        outs.append(torch.sin(x * f))
+        outs.append(torch.cos(x * f))
+    return torch.cat(outs, -1)
+
+
+def embed_out_dim(multires, d=3):
+    return d + 2 * multires * d
+
+
+# --------------------------------------------------------------------------------------
+# the DM-NeRF MLP  (networks/dm_nerf.py:58-106)
+# --------------------------------------------------------------------------------------
+
+PARAM_ORDER = (
+    [f"mlps.{i}" for i in range(8)]
+    + ["rgb_feature_linear", "ins_feature_linear", "rgb_feature_linears.0",
+       "ins_feature_linears.0", "density_linear", "ins_linear", "rgb_linear"]
+)
+
+
+def param_shapes(ins_num, W=256, input_ch_pts=63, input_ch_views=27, D=8, skips=(4,)):
+    """Layer shapes of ``DM_NeRF.__init__`` (networks/dm_nerf.py:59-78), state_dict order."""
+    shapes = {}
+    shapes["mlps.0"] = (W, input_ch_pts)
+    for i in range(D - 1):
+        shapes[f"mlps.{i + 1}"] = (W, W + input_ch_pts) if i in skips else (W, W)
+    shapes["rgb_feature_linear"] = (W, W)
+    shapes["ins_feature_linear"] = (W, W)
+    shapes["rgb_feature_linears.0"] = (W // 2, W + input_ch_views)
+    shapes["ins_feature_linears.0"] = (W // 2, W)
+    shapes["density_linear"] = (1, W)
+    shapes["ins_linear"] = (ins_num + 1, W // 2)
+    shapes["rgb_linear"] = (3, W // 2)
+    return shapes
+
+
+def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0):
+    """Deterministic synthetic weights from a numpy seed (no 2.8 MB blobs in the repo).
+
+    ``nn.Linear``-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)) scaled by ``gain``;
+    ``sigma_bias`` shifts the density head so rays see surfaces ("trained-like").
+    Returns ``{name.weight / name.bias: float32 torch tensor}`` keyed as the
+    reference state_dict.
+    """
+    rng = np.random.RandomState(seed)
+    sd = {}
+    for name, (o, i) in param_shapes(ins_num, W).items():
+        bound = gain / np.sqrt(i)
+        sd[name + ".weight"] = torch.from_numpy(rng.uniform(-bound, bound, size=(o, i)).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy(rng.uniform(-bound, bound, size=(o,)).astype(np.float32))
+    sd["density_linear.bias"] = sd["density_linear.bias"] + np.float32(sigma_bias)
+    return sd
+
+
+def mlp_forward(sd, x, input_ch_pts=63, input_ch_views=27, skips=(4,), D=8, return_acts=False):
+    """``DM_NeRF.forward`` (networks/dm_nerf.py:80-106).
+
+    ``sd`` is a state_dict-like mapping; ``x`` is ``[M, 63+27]``.  Output ``[M, 4+C]`` =
+    ``cat[rgb(3), density(1), ins(C)]`` -- raw, no output activations (:105).
+    """
+    input_pts, input_dirs = torch.split(x, [input_ch_pts, input_ch_views], dim=-1)
+    h = input_pts
+    acts = []
+    for i in range(D):
+        h = F.linear(h, sd[f"mlps.{i}.weight"], sd[f"mlps.{i}.bias"])
+        h = F.relu(h)
+        if i in skips:
+            h = torch.cat([h, input_pts], -1)          # order [h, pts]  (:87)
+        acts.append(h)
+    rgb_feature = F.linear(h, sd["rgb_feature_linear.weight"], sd["rgb_feature_linear.bias"])   # no act (:89)
+    rgb_feature = torch.cat([rgb_feature, input_dirs], -1)
+    rgb_feature = F.relu(F.linear(rgb_feature, sd["rgb_feature_linears.0.weight"], sd["rgb_feature_linears.0.bias"]))
+    ins_feature = h.detach()                                                                    # (:95)
+    ins_feature = F.linear(ins_feature, sd["ins_feature_linear.weight"], sd["ins_feature_linear.bias"])
+    ins_feature = F.relu(F.linear(ins_feature, sd["ins_feature_linears.0.weight"], sd["ins_feature_linears.0.bias"]))
+    density = F.linear(h, sd["density_linear.weight"], sd["density_linear.bias"])
+    rgb = F.linear(rgb_feature, sd["rgb_linear.weight"], sd["rgb_linear.bias"])
+    ins = F.linear(ins_feature, sd["ins_linear.weight"], sd["ins_linear.bias"])
+    out = torch.cat([rgb, density, ins], -1)
+    if return_acts:
+        return out, acts
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# samplers / ray generation  (networks/helpers.py)
+# --------------------------------------------------------------------------------------
+
+def get_rays_k(H, W, K, c2w):
+    """``get_rays_k`` (networks/helpers.py:50-61).  K: numpy 3x3 / 4x4; c2w: f32 tensor [3or4,4]."""
+    dev = c2w.device
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=dev),
+                          torch.linspace(0, H - 1, H, device=dev), indexing='ij')
+    i = i.t()
+    j = j.t()
+    dirs = torch.stack([(i - K[0, 2]) / K[0, 0], (j - K[1, 2]) / K[1, 1], K[2, 2] * torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def z_val_sample(N_rays, near, far, N_samples, device="cpu"):
+    """``z_val_sample`` (networks/helpers.py:114-119): ``near + linspace(0,1,S)*(far-near)``."""
+    near_t = near * torch.ones(size=(N_rays, 1), device=device)
+    far_t = far * torch.ones(size=(N_rays, 1), device=device)
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=device)
+    z = near_t + t_vals * (far_t - near_t)
+    return z.expand([N_rays, N_samples])
+
+
+def stratify(z_vals, t_rand):
+    """Stratified jitter (networks/render.py:42-47) with the random draw passed in."""
+    mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    upper = torch.cat([mids, z_vals[..., -1:]], -1)
+    lower = torch.cat([z_vals[..., :1], mids], -1)
+    return lower + (upper - lower) * t_rand
+
+
+def sample_pdf(bins, weights, N_samples, det=False, u=None, return_aux=False):
+    """``sample_pdf`` (networks/helpers.py:123-155).  ``u`` overrides the draw (same shape/order)."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if u is None:
+        if det:
+            u = torch.linspace(0., 1., steps=N_samples, device=bins.device)
+            u = u.expand(list(cdf.shape[:-1]) + [N_samples])
+        else:
+            u = torch.rand(list(cdf.shape[:-1]) + [N_samples], device=bins.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    inds_g = torch.stack([below, above], -1)
+    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    denom = (cdf_g[..., 1] - cdf_g[..., 0])
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    samples = bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+    if return_aux:
+        return samples, cdf, inds
+    return samples
+
+
+def sample_from_cdf(bins, cdf, u):
+    """Stage-isolated tail of ``sample_pdf`` (helpers.py:139-153): identical (cdf,u) -> inds, samples."""
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_lo = torch.gather(cdf, 1, below)
+    cdf_hi = torch.gather(cdf, 1, above)
+    b_lo = torch.gather(bins, 1, below)
+    b_hi = torch.gather(bins, 1, above)
+    denom = cdf_hi - cdf_lo
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_lo) / denom
+    return b_lo + t * (b_hi - b_lo), inds
+
+
+# --------------------------------------------------------------------------------------
+# volume rendering  (networks/render.py)
+# --------------------------------------------------------------------------------------
+
+def render_train(raw, z_vals, rays_d):
+    """``render_train`` (networks/render.py:6-28)."""
+    dev = raw.device
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.tensor([1e10], device=dev).expand(dists[..., :1].shape)], -1)
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+    rgb = torch.sigmoid(raw[..., :3])
+    ins_labels = raw[..., 4:]
+    alpha = 1. - torch.exp(-F.relu(raw[..., 3]) * dists)
+    weights = alpha * torch.cumprod(
+        torch.cat([torch.ones((alpha.shape[0], 1), device=dev), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)
+    depth_map = torch.sum(weights * z_vals, -1)
+    weights_ins = weights.clone().detach()
+    ins_map = torch.sum(weights_ins[..., None] * ins_labels, -2)
+    ins_map = torch.sigmoid(ins_map)
+    ins_map = ins_map[..., :-1]
+    return rgb_map, weights, depth_map, ins_map
+
+
+def dm_nerf(rays, sd_coarse, sd_fine, z_vals_coarse, perturb=0., N_importance=128,
+            is_train=False, N_ins=None, t_rand=None, u=None, multires=10, multires_views=4):
+    """``dm_nerf`` (networks/render.py:31-96) with weights as state_dicts.
+
+    RNG: when ``perturb > 0`` the reference draws ``torch.rand([N,64])`` (:46) then
+    ``torch.rand([N,N_importance])`` (helpers.py:135); pass ``t_rand`` / ``u`` to pin them,
+    otherwise they are drawn here in that order.
+    """
+    rays_o, rays_d = rays
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    if perturb > 0.:
+        if t_rand is None:
+            t_rand = torch.rand(z_vals_coarse.shape, device=z_vals_coarse.device)
+        z_vals_coarse = stratify(z_vals_coarse, t_rand)
+
+    def run(sd, z):
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+        pts_flat = torch.reshape(pts, [-1, 3])
+        e_pos = embed(pts_flat, multires)
+        dirs = torch.reshape(viewdirs[:, None].expand(pts.shape), [-1, 3])
+        e_dir = embed(dirs, multires_views)
+        raw = mlp_forward(sd, torch.cat([e_pos, e_dir], -1))
+        return torch.reshape(raw, list(pts.shape[:-1]) + [raw.shape[-1]])
+
+    raw_coarse = run(sd_coarse, z_vals_coarse)
+    rgb_coarse, weights_coarse, depth_coarse, ins_coarse = render_train(raw_coarse, z_vals_coarse, rays_d)
+    z_vals_mid = .5 * (z_vals_coarse[..., 1:] + z_vals_coarse[..., :-1])
+    z_samples = sample_pdf(z_vals_mid, weights_coarse[..., 1:-1], N_importance, det=(perturb == 0.), u=u)
+    z_samples = z_samples.detach()
+    z_vals_fine, _ = torch.sort(torch.cat([z_vals_coarse, z_samples], -1), -1)
+    raw_fine = run(sd_fine, z_vals_fine)
+    rgb_fine, weights_fine, depth_fine, ins_fine = render_train(raw_fine, z_vals_fine, rays_d)
+    if is_train and N_ins is not None:
+        ins_fine = ins_fine[-N_ins:]
+        ins_coarse = ins_coarse[-N_ins:]
+    return {'rgb_fine': rgb_fine, 'ins_fine': ins_fine, 'z_vals_fine': z_vals_fine, 'raw_fine': raw_fine,
+            'raw_coarse': raw_coarse, 'rgb_coarse': rgb_coarse, 'ins_coarse': ins_coarse,
+            'z_vals_coarse': z_vals_coarse, 'depth_fine': depth_fine, 'depth_coarse': depth_coarse}
+
+
+# --------------------------------------------------------------------------------------
+# synthetic scene; used by tests and bench
+# --------------------------------------------------------------------------------------
+
+def dmsr_intrinsics(H=480, W=640, camera_angle_x=0.69):
+    """DM-SR K convention ``[[f,0,W/2],[0,-f,H/2],[0,0,-1]]`` (datasets/loader_dmsr.py:136-137)."""
+    focal = .5 * W / np.tan(.5 * camera_angle_x)
+    return np.array([[focal, 0, 0.5 * W], [0, -focal, 0.5 * H], [0, 0, -1]])
+
+
+def pose_spherical(theta, phi, radius):
+    """Restated ``pose_spherical`` (tools/pose_generator.py:29-34) -> 4x4 float32 c2w."""
+    t = np.eye(4); t[2, 3] = radius
+    ph = phi / 180. * np.pi
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]])
+    th = theta / 180. * np.pi
+    ry = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])
+    c2w = ry @ rx @ t
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
+    return torch.from_numpy(c2w.astype(np.float32))

@@ -1,0 +1,253 @@
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py          # needs /root/reference; writes tests/golden/*.npz
+
+What it does
+  1. imports the reference hot path from /root/reference (networks.render / dm_nerf / helpers),
+  2. runs each stage on small seeded inputs with synthetic weights (oracle.ref_cpu.make_weights:
+     numpy-seeded, so no weight blobs are committed),
+  3. asserts that oracle/ref_cpu.py reproduces every reference output BIT-FOR-BIT on CPU,
+  4. writes inputs + reference outputs as small float32/int64 ``.npz`` fixtures.
+
+The fixtures are data only (inputs and expected outputs); no reference source travels.
+``/root/reference`` does not exist on the GPU box: tests read only the ``.npz`` files.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("DMNERF_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+from oracle import ref_cpu as O  # noqa: E402
+
+import networks.dm_nerf as R_model  # noqa: E402  (reference)
+import networks.render as R_render  # noqa: E402
+import networks.helpers as R_helpers  # noqa: E402
+
+torch.autograd.set_detect_anomaly(False)  # the reference switches it on at import (dm_nerf.py:5)
+torch.set_num_threads(1)                  # fixtures must not depend on the thread count
+
+
+def beq(a, b, what):
+    a = a.detach() if torch.is_tensor(a) else torch.as_tensor(a)
+    b = b.detach() if torch.is_tensor(b) else torch.as_tensor(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.equal(a, b), f"oracle != reference for {what}: max|d|={float((a.double() - b.double()).abs().max())}"
+
+
+def ref_model(sd, ins_num):
+    m = R_model.DM_NeRF(8, 256, 63, 27, [4], ins_num)
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def npy(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **npy(arrays))
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def gen_embed():
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(96, 3, generator=g) * 2 - 1) * 15.0       # |x| up to 15 -> args up to 7680 rad
+    x[0] = torch.tensor([0., 1e-6, -15.])
+    x[1] = torch.tensor([15., -7.5, 3.14159274])
+    d = torch.nn.functional.normalize(torch.randn(96, 3, generator=g), dim=-1)
+    e10, _ = R_model.get_embedder(10, 0)
+    e4, _ = R_model.get_embedder(4, 0)
+    y10, y4 = e10.embed(x), e4.embed(d)
+    beq(O.embed(x, 10), y10, "embed L=10")
+    beq(O.embed(d, 4), y4, "embed L=4")
+    save("embed", x=x, d=d, y10=y10, y4=y4)
+
+
+def gen_mlp():
+    out = {}
+    for ins_num, seed in ((13, 101), (59, 102), (93, 103)):
+        sd = O.make_weights(seed, ins_num, gain=1.7)
+        g = torch.Generator().manual_seed(seed)
+        pts = (torch.rand(80, 3, generator=g) * 2 - 1) * 6.0
+        dirs = torch.nn.functional.normalize(torch.randn(80, 3, generator=g), dim=-1)
+        x = torch.cat([O.embed(pts, 10), O.embed(dirs, 4)], -1)
+        with torch.no_grad():
+            y = ref_model(sd, ins_num)(x)
+            beq(O.mlp_forward(sd, x), y, f"mlp ins_num={ins_num}")
+        out[f"x_{ins_num}"] = x
+        out[f"y_{ins_num}"] = y
+        out[f"seed_{ins_num}"] = np.int64(seed)
+    out["gain"] = np.float64(1.7)
+    save("mlp", **out)
+
+
+def gen_render_train():
+    out = {}
+    for S, C, seed in ((64, 14, 201), (192, 14, 202), (320, 60, 203), (192, 94, 204), (5, 3, 205)):
+        g = torch.Generator().manual_seed(seed)
+        N = 6
+        raw = torch.randn(N, S, 4 + C, generator=g) * 2.0
+        raw[..., 3] = raw[..., 3] * 3.0            # sigma: mix of negative (relu->0) and large values
+        raw[1, :, 3] = -1.0                        # empty ray: all alpha = 0
+        raw[2, S // 3, 3] = 1e4                    # opaque wall
+        z = torch.sort(torch.rand(N, S, generator=g) * 11 + 4, -1)[0]
+        z[3] = O.z_val_sample(1, 4.0, 15.0, S)[0]
+        if S > 8:
+            z[4, 5] = z[4, 4]                      # duplicated depth -> dist 0
+        d = torch.randn(N, 3, generator=g)
+        rgb, w, dep, ins = R_render.render_train(raw, z, d)
+        o = O.render_train(raw, z, d)
+        for a, b, n in zip(o, (rgb, w, dep, ins), ("rgb", "w", "depth", "ins")):
+            beq(a, b, f"render_train S={S} {n}")
+        k = f"S{S}_C{C}"
+        out.update({f"{k}_raw": raw, f"{k}_z": z, f"{k}_d": d, f"{k}_rgb": rgb, f"{k}_w": w,
+                    f"{k}_depth": dep, f"{k}_ins": ins})
+    # the KAT of SURVEY 8(a-8)
+    S, C = 64, 4
+    raw = torch.zeros(1, S, 4 + C); raw[..., 3] = 1.0; raw[..., 4 + 2] = 3.0
+    z = O.z_val_sample(1, 4.0, 15.0, S).contiguous()
+    d = torch.tensor([[0., 0., -1.]])
+    rgb, w, dep, ins = R_render.render_train(raw, z, d)
+    out.update(kat_raw=raw, kat_z=z, kat_d=d, kat_rgb=rgb, kat_w=w, kat_depth=dep, kat_ins=ins)
+    save("render_train", **out)
+
+
+def gen_sample_pdf():
+    out = {}
+    g = torch.Generator().manual_seed(301)
+    N = 12
+    z = torch.sort(torch.rand(N, 64, generator=g) * 11 + 4, -1)[0]
+    z[0] = O.z_val_sample(1, 4.0, 15.0, 64)[0]
+    bins = .5 * (z[..., 1:] + z[..., :-1])
+    w = torch.rand(N, 62, generator=g) ** 4
+    w[0] = 1.0                                   # uniform: the SURVEY a-9 KAT
+    w[1] = 0.0                                   # zero-weight ray
+    w[2] = 0.0; w[2, 30] = 1.0                   # one spike
+    w[3, :40] = 0.0                              # long flat cdf prefix (denom < 1e-5 branch)
+    w[4] = 1e-7
+    # deterministic
+    torch.manual_seed(0)
+    s_det = R_helpers.sample_pdf(bins, w, 128, det=True)
+    o_det, cdf, inds_det = O.sample_pdf(bins, w, 128, det=True, return_aux=True)
+    beq(o_det, s_det, "sample_pdf det")
+    # random u: reproduce the reference's own torch.rand draw
+    torch.manual_seed(302)
+    s_rnd = R_helpers.sample_pdf(bins, w, 128, det=False)
+    torch.manual_seed(302)
+    u = torch.rand(N, 128)
+    u[5, 0] = 0.0; u[5, 1] = 1.0 - 2 ** -24      # edge values of torch.rand's range
+    torch.manual_seed(302)
+    o_rnd, _, inds_rnd = O.sample_pdf(bins, w, 128, det=False, return_aux=True)
+    beq(o_rnd, s_rnd, "sample_pdf rand")
+    o_rnd_u, _, inds_rnd_u = O.sample_pdf(bins, w, 128, u=u, return_aux=True)   # with edge-valued u
+    s2, i2 = O.sample_from_cdf(bins, cdf, u)
+    beq(s2, o_rnd_u, "sample_from_cdf")
+    beq(i2, inds_rnd_u, "sample_from_cdf inds")
+    u_det = torch.linspace(0., 1., steps=128)
+    # merged + sorted fine depths (render.py:70)
+    zf_det = torch.sort(torch.cat([z, s_det], -1), -1)[0]
+    zf_rnd = torch.sort(torch.cat([z, o_rnd_u], -1), -1)[0]
+    out.update(z=z, bins=bins, w=w, cdf=cdf, u_det=u_det, s_det=s_det, inds_det=inds_det,
+               u_rnd=u, s_rnd=o_rnd_u, inds_rnd=inds_rnd_u, zf_det=zf_det, zf_rnd=zf_rnd)
+    save("sample_pdf", **out)
+
+
+def gen_rays():
+    out = {}
+    H, W = 6, 8
+    c2w = O.pose_spherical(37.0, -65.0, 7.0)
+    Ks = {
+        "dmsr": O.dmsr_intrinsics(H, W),
+        "replica": np.array([[W / 2, 0, (W - 1) / 2], [0, W / 2, (H - 1) / 2], [0, 0, 1]], dtype=np.float64),
+        "scannet": np.array([[577.590698, 0, 318.905426, 0], [0, 578.729797, 242.683609, 0],
+                             [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64) * np.array([[W / 640.], [H / 480.], [1], [1]]),
+    }
+    for name, K in Ks.items():
+        ro, rd = R_helpers.get_rays_k(H, W, K, c2w)
+        oo, od = O.get_rays_k(H, W, K, c2w)
+        beq(oo, ro, f"rays_o {name}"); beq(od, rd, f"rays_d {name}")
+        out[f"K_{name}"] = K
+        out[f"o_{name}"] = ro.contiguous()
+        out[f"d_{name}"] = rd
+    # full-size spot rows of the 640x480 DM-SR camera (first/last row) to pin large pixel indices
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = R_helpers.get_rays_k(480, 640, K, c2w)
+    beq(O.get_rays_k(480, 640, K, c2w)[1], rd, "rays_d 640x480")
+    out.update(K_full=K, d_full_row0=rd[0], d_full_row479=rd[479], c2w=c2w, HW=np.array([H, W]))
+    z = R_helpers.z_val_sample(3, 4.0, 15.0, 64)
+    beq(O.z_val_sample(3, 4.0, 15.0, 64), z, "z_val_sample")
+    z2 = R_helpers.z_val_sample(2, 0.0, 4.7, 64)
+    out.update(z_4_15=z.contiguous(), z_0_47=z2.contiguous())
+    # stratified jitter with the reference's own draw (render.py:42-47)
+    torch.manual_seed(77)
+    t_rand = torch.rand(3, 64)
+    zc = z.contiguous()
+    mids = .5 * (zc[..., 1:] + zc[..., :-1])
+    upper = torch.cat([mids, zc[..., -1:]], -1); lower = torch.cat([zc[..., :1], mids], -1)
+    zj = lower + (upper - lower) * t_rand
+    beq(O.stratify(zc, t_rand), zj, "stratify")
+    out.update(t_rand=t_rand, z_jit=zj)
+    save("rays", **out)
+
+
+def gen_dm_nerf():
+    """Full ``dm_nerf`` dict (render.py:31-96): det and perturb=1, is_train/N_ins slice."""
+    out = {}
+    ins_num = 13
+    sd_c = O.make_weights(401, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(402, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = ref_model(sd_c, ins_num), ref_model(sd_f, ins_num)
+    pe, _ = R_model.get_embedder(10, 0)
+    ve, _ = R_model.get_embedder(4, 0)
+    K = O.dmsr_intrinsics(480, 640)
+    c2w = O.pose_spherical(37.0, -65.0, 7.0)
+    ro, rd = R_helpers.get_rays_k(480, 640, K, c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    sel = torch.from_numpy(np.random.RandomState(5).choice(480 * 640, 24, replace=False))
+    rays = torch.stack([ro[sel], rd[sel]], 0)
+    z = R_helpers.z_val_sample(24, 4.0, 15.0, 64)
+    out.update(rays=rays, z_in=z.contiguous(), seed_c=np.int64(401), seed_f=np.int64(402),
+               gain=np.float64(1.7), sigma_bias=np.float64(0.3), ins_num=np.int64(ins_num))
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        ref = R_render.dm_nerf(rays, pe, ve, mc, mf, z, args)
+        ora = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0., N_importance=128)
+    for k in ref:
+        beq(ora[k], ref[k], f"dm_nerf det {k}")
+        out[f"det_{k}"] = ref[k]
+    # perturb = 1, training-mode slice of the last N_ins rays
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=7)
+    with torch.no_grad():
+        torch.manual_seed(403)
+        ref = R_render.dm_nerf(rays, pe, ve, mc, mf, z, args)
+        torch.manual_seed(403)
+        t_rand = torch.rand(24, 64); u = torch.rand(24, 128)
+        ora = O.dm_nerf(rays, sd_c, sd_f, z, perturb=1.0, N_importance=128, is_train=True, N_ins=7,
+                        t_rand=t_rand, u=u)
+    for k in ref:
+        beq(ora[k], ref[k], f"dm_nerf perturb {k}")
+        out[f"prt_{k}"] = ref[k]
+    out.update(t_rand=t_rand, u=u)
+    save("dm_nerf", **out)
+
+
+if __name__ == "__main__":
+    print("reference:", REF, "| torch", torch.__version__)
+    gen_embed()
+    gen_mlp()
+    gen_render_train()
+    gen_sample_pdf()
+    gen_rays()
+    gen_dm_nerf()
+    print("all oracle == reference checks passed (bit-exact)")
