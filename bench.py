@@ -1,0 +1,171 @@
+"""bench.py -- rays/s of the DM-NeRF render hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (``dm_nerf``: coarse MLP -> composite -> resample -> fine MLP ->
+composite) over one 4096-ray chunk of a synthetic 640x480 DM-SR 'study' frame, 64 + 128 samples,
+deterministic sampling -- the chunk loop of the reference's render_test (networks/tester.py:63-72).
+Inputs (rays, depth grid, packed weights) are resident in HBM before the timed region.  With N GPUs
+every rank renders its own chunks (weak scaling) and the rendered tiles are all-gathered (RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+INS_NUM = 13                 # DM-SR 'study' (data/color_dict.json: 13 labels)
+N_RAYS = 4096                # N_test of every shipped config (configs/dmsr/train/study.txt)
+S_COARSE, N_IMP = 64, 128
+H_IMG, W_IMG = 480, 640
+NEAR, FAR = 4.0, 15.0
+MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)          # 693 504
+F32_MFMA_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
+    return p.parse_args()
+
+
+def build_models(device):
+    from dm_nerf_amd import config as Cfg
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256,
+                                 ins_num=INS_NUM, device=device)
+    pe, ve, mc, mf, _ = Cfg.create_nerf(args)
+    with torch.no_grad():                       # "trained-like": give the density head surfaces
+        mc.density_linear.bias.add_(0.3)
+        mf.density_linear.bias.add_(0.3)
+    return pe, ve, mc.eval(), mf.eval()
+
+
+def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
+    """The oracle (CPU port of the reference path) timed on this host's cores, bounded sample."""
+    from oracle import ref_cpu as O
+    sd_c = {k: v.detach().cpu() for k, v in mc.state_dict().items()}
+    sd_f = {k: v.detach().cpu() for k, v in mf.state_dict().items()}
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        n0 = 256
+        t0 = time.perf_counter()
+        O.dm_nerf(rays_cpu[:, :n0], sd_c, sd_f, z_cpu[:n0], perturb=0.)
+        t1 = time.perf_counter() - t0                                   # calibration (also the warm-up)
+        n = int(min(N_RAYS, max(256, (seconds / max(t1, 1e-3)) * n0 // 256 * 256)))
+        t0 = time.perf_counter()
+        want = O.dm_nerf(rays_cpu[:, :n], sd_c, sd_f, z_cpu[:n], perturb=0.)
+        dt = time.perf_counter() - t0
+    mse = float(((got_rgb[:n] - want['rgb_fine']) ** 2).mean())
+    psnr = float(-10 * np.log10(max(mse, 1e-20)))
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} rays of the same 4096-ray chunk (64+128 samples, det), oracle/ref_cpu.dm_nerf, {dt:.1f} s"}, psnr, n
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from dm_nerf_amd import _lib
+    from dm_nerf_amd.networks import helpers as H, render as R
+    from oracle.ref_cpu import dmsr_intrinsics, pose_spherical   # synthetic camera definition only (host numpy)
+
+    pe, ve, mc, mf = build_models(dev)
+    K = dmsr_intrinsics(H_IMG, W_IMG)
+    c2w = pose_spherical(30.0, -65.0, 7.0)
+    # rank r owns a contiguous band of rows of the frame and generates its own rays (no scatter)
+    rows = H_IMG // world
+    ro, rd = H.get_rays_k(H_IMG, W_IMG, K, c2w.to(dev), row0=rank * rows, nrows=rows)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    n_chunks = ro.shape[0] // N_RAYS
+    z = H.z_val_sample(N_RAYS, NEAR, FAR, S_COARSE, device=dev)
+    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None)
+    mc.blob(); mf.blob()                                        # packed weights resident
+    tile = torch.empty(N_RAYS, 3 + INS_NUM + 1, device=dev)
+    gathered = torch.empty(world * N_RAYS, 3 + INS_NUM + 1, device=dev) if world > 1 else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i, events=None):
+        c = i % n_chunks
+        rays = torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]])
+        out = R.dm_nerf(rays, pe, ve, mc, mf, z, args, _events=events)
+        if world > 1:                                           # all-gather of the rendered tile (rgb | ins | depth)
+            tile[:, :3] = out['rgb_fine']; tile[:, 3:3 + INS_NUM] = out['ins_fine']; tile[:, -1] = out['depth_fine']
+            dist.all_gather_into_tensor(gathered, tile)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            out = step(i, ev[i])
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
+        k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * N_RAYS
+        achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+        rays_per_s = world * N_RAYS * a.steps / dt
+        res = {
+            "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DM-SR 'study' 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
+                                   "4096-ray chunk per step per GPU, det sampling, ins_num=13, random-init weights",
+                       "rays_per_step_per_gpu": N_RAYS, "parallelism": f"ray-sharded x{world}" + (" + RCCL all-gather of tiles" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "mlp_fwd_kernel<1,false> (fine network, 4096x192 samples)", "kernel_ms": k_ms,
+                         "flop_per_launch": flop_per_launch},
+            "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            c = 0 if a.steps == 0 else (a.steps - 1) % n_chunks
+            rays_cpu = torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]]).cpu()
+            base, psnr, n = cpu_baseline(mc, mf, rays_cpu, z.cpu(), out['rgb_fine'].cpu(), a.cpu_seconds)
+            res["cpu_baseline"] = base
+            res["psnr_vs_oracle_db"] = psnr
+            res["speedup_vs_cpu"] = rays_per_s / base["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+// layout.h -- weight "blob" layout shared by the packer (host) and the fused MLP kernels (device).
+//
+// The fused kernel keeps activations in MFMA accumulator layout and feeds them straight back
+// as the B operand of the next layer.  For v_mfma_f32_32x32x2_f32:
+//   A[i][k]: lane l supplies row i = l&31,  k = l>>5          (one f32 VGPR)
+//   B[k][j]: lane l supplies col j = l&31,  k = l>>5          (one f32 VGPR)
+//   C[i][j]: lane l holds   col j = l&31,  rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
+// With W (out x in) as A and X^T (in x samples) as B, a lane's 16 accumulator registers of
+// out-block b are 16 features of ITS sample; register r of block b pairs feature
+// f0 = 32b + (r&3) + 8*(r>>2) (lanes 0-31) with f0+4 (lanes 32-63) -- exactly a k-pair of the
+// next layer.  So "k-pair p = 16b + r"  <->  input features cfeat(p, half).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DMN_HD __host__ __device__
+#else
+#define DMN_HD
+#endif
+
+namespace dmn {
+
+// accumulator-layout k order: k-pair p (0..), half (lane>>5) -> feature index
+DMN_HD constexpr int cfeat(int p, int half) {
+    return 32 * (p >> 4) + ((p & 15) & 3) + 8 * ((p & 15) >> 2) + 4 * half;
+}
+
+// positional-encoding k order for L frequencies: pairs 0,1 = (x,y),(z,pad); pair 2+3k+c =
+// (sin(2^k x_c), cos(2^k x_c)).  Returns the column in Embedder.embed's output
+// (networks/dm_nerf.py:37: [x | sin f0 | cos f0 | sin f1 | ...], blocks of 3) or -1 (zero pad).
+DMN_HD constexpr int pefeat(int p, int half, int L) {
+    if (p == 0) return half;                 // x, y
+    if (p == 1) return half ? -1 : 2;        // z, pad
+    int q = p - 2;
+    if (q >= 3 * L) return -1;
+    int k = q / 3, c = q % 3;
+    return 3 + 6 * k + 3 * half + c;
+}
+
+constexpr int W = 256;        // trunk width
+constexpr int HW = 128;       // head hidden width (W/2)
+constexpr int POS_CH = 63, DIR_CH = 27, POS_L = 10, DIR_L = 4;
+constexpr int POS_KP = 32;    // k-pairs of the padded position encoding (64 slots)
+constexpr int DIR_KP = 16;    // k-pairs of the padded direction encoding (32 slots)
+constexpr int NSTAGE = 9;     // 256->256 GEMMs sharing one code body: L1..L4, L5(h part), L6, L7, rgb_feature, ins_feature
+
+// A gemm segment of NKG k-groups (4 k-pairs each) x OB out-blocks (32 rows each):
+//   seg[((g*OB + ob)*64 + lane)*4 + kk] = Wmat[ob*32 + (lane&31)][kmap(4g+kk, lane>>5)]
+constexpr int64_t seg_floats(int nkg, int ob) { return (int64_t)nkg * ob * 256; }
+// bias segment: seg[(ob*2 + half)*16 + r] = bias[32ob + (r&3) + 8(r>>2) + 4half]
+constexpr int64_t bias_floats(int ob) { return (int64_t)ob * 32; }
+
+struct BlobLayout {
+    int C, OBI;                   // logits, out-blocks of the ins_linear head
+    int64_t w0, b0;               // mlps.0: PE k-order, NKG=8, OB=8
+    int64_t w_stage, b_stage;     // NSTAGE x (NKG=32, OB=8) + NSTAGE x bias(8)
+    int64_t w5pe;                 // mlps.5 columns 256..318: PE k-order, NKG=8, OB=8
+    int64_t w_rgbh, w_rgbh_dir, b_rgbh;   // rgb_feature_linears.0: (NKG=32,OB=4) + dir (NKG=4,OB=4)
+    int64_t w_insh, b_insh;       // ins_feature_linears.0: NKG=32, OB=4
+    int64_t w_inso, b_inso;       // ins_linear: NKG=16, OB=OBI
+    int64_t w_den, b_den;         // density_linear on VALU: [half][128] + bias (padded to 4)
+    int64_t w_rgbo, b_rgbo;       // rgb_linear on VALU: [c][half][64] + bias[3] (padded to 4)
+    int64_t total;
+};
+
+DMN_HD inline BlobLayout make_layout(int ins_num) {
+    BlobLayout L;
+    L.C = ins_num + 1;
+    L.OBI = (L.C + 31) / 32;
+    int64_t o = 0;
+    L.w0 = o; o += seg_floats(8, 8);
+    L.b0 = o; o += bias_floats(8);
+    L.w_stage = o; o += NSTAGE * seg_floats(32, 8);
+    L.b_stage = o; o += NSTAGE * bias_floats(8);
+    L.w5pe = o; o += seg_floats(8, 8);
+    L.w_rgbh = o; o += seg_floats(32, 4);
+    L.w_rgbh_dir = o; o += seg_floats(4, 4);
+    L.b_rgbh = o; o += bias_floats(4);
+    L.w_insh = o; o += seg_floats(32, 4);
+    L.b_insh = o; o += bias_floats(4);
+    L.w_inso = o; o += seg_floats(16, L.OBI);
+    L.b_inso = o; o += bias_floats(L.OBI);
+    L.w_den = o; o += 256;
+    L.b_den = o; o += 4;
+    L.w_rgbo = o; o += 3 * 2 * 64;
+    L.b_rgbo = o; o += 4;
+    L.total = o;
+    return L;
+}
+
+}  // namespace dmn

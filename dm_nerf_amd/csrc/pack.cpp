@@ -1,0 +1,123 @@
+// pack.cpp -- host-side: reference state_dict order -> kernel blob gather index.  No GPU needed.
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/dmnerf_hip.h"
+#include "common.h"
+#include "layout.h"
+
+using namespace dmn;
+
+namespace {
+
+// One reference nn.Linear in the flat parameter vector (weight [out,in] row-major, then bias).
+struct Lin {
+    int64_t w_off, b_off;
+    int out, in;
+    int64_t w(int o, int i) const { return (o < out && i >= 0 && i < in) ? w_off + (int64_t)o * in + i : -1; }
+    int64_t b(int o) const { return o < out ? b_off + o : -1; }
+};
+
+struct Params {
+    Lin mlps[8], rgb_feature, ins_feature, rgb_hidden, ins_hidden, density, ins_out, rgb_out;
+    int64_t total;
+};
+
+// DM_NeRF.__init__ order (networks/dm_nerf.py:59-78)
+Params make_params(int ins_num) {
+    Params P;
+    int64_t o = 0;
+    auto add = [&](Lin& l, int out, int in) {
+        l.out = out; l.in = in; l.w_off = o; o += (int64_t)out * in; l.b_off = o; o += out;
+    };
+    add(P.mlps[0], W, POS_CH);
+    for (int i = 1; i < 8; ++i) add(P.mlps[i], W, i == 5 ? W + POS_CH : W);
+    add(P.rgb_feature, W, W);
+    add(P.ins_feature, W, W);
+    add(P.rgb_hidden, HW, W + DIR_CH);
+    add(P.ins_hidden, HW, W);
+    add(P.density, 1, W);
+    add(P.ins_out, ins_num + 1, HW);
+    add(P.rgb_out, 3, HW);
+    P.total = o;
+    return P;
+}
+
+enum KMap { K_ACC, K_POS, K_DIR };
+
+int kcol(KMap km, int p, int half) {
+    switch (km) {
+        case K_ACC: return cfeat(p, half);
+        case K_POS: return pefeat(p, half, POS_L);
+        case K_DIR: return pefeat(p, half, DIR_L);
+    }
+    return -1;
+}
+
+void fill_seg(int32_t* idx, int64_t off, const Lin& l, int nkg, int ob_n, KMap km, int col_off) {
+    for (int g = 0; g < nkg; ++g)
+        for (int ob = 0; ob < ob_n; ++ob)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int kk = 0; kk < 4; ++kk) {
+                    int col = kcol(km, 4 * g + kk, lane >> 5);
+                    int64_t src = col < 0 ? -1 : l.w(ob * 32 + (lane & 31), col + col_off);
+                    idx[off + (((int64_t)g * ob_n + ob) * 64 + lane) * 4 + kk] = (int32_t)src;
+                }
+}
+
+void fill_bias(int32_t* idx, int64_t off, const Lin& l, int ob_n) {
+    for (int ob = 0; ob < ob_n; ++ob)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r)
+                idx[off + (ob * 2 + half) * 16 + r] = (int32_t)l.b(32 * ob + (r & 3) + 8 * (r >> 2) + 4 * half);
+}
+
+}  // namespace
+
+extern "C" int64_t dmnerf_param_count(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_params(ins_num).total;
+}
+
+extern "C" int64_t dmnerf_blob_floats(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_layout(ins_num).total;
+}
+
+extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS)
+        return dmn_fail(DMNERF_E_ARG, "build_pack_index: ins_num %d outside [1,%d]", ins_num, DMNERF_MAX_LOGITS - 1);
+    const BlobLayout L = make_layout(ins_num);
+    if (!idx || n_idx != L.total)
+        return dmn_fail(DMNERF_E_ARG, "build_pack_index: need %lld index slots, got %lld", (long long)L.total, (long long)n_idx);
+    const Params P = make_params(ins_num);
+    for (int64_t i = 0; i < L.total; ++i) idx[i] = -1;
+
+    fill_seg(idx, L.w0, P.mlps[0], 8, 8, K_POS, 0);
+    fill_bias(idx, L.b0, P.mlps[0], 8);
+    // the nine 256->256 stages: L1..L4, L5 (h columns 0..255), L6, L7, rgb_feature, ins_feature
+    const Lin* stage[NSTAGE] = {&P.mlps[1], &P.mlps[2], &P.mlps[3], &P.mlps[4], &P.mlps[5],
+                                &P.mlps[6], &P.mlps[7], &P.rgb_feature, &P.ins_feature};
+    for (int s = 0; s < NSTAGE; ++s) {
+        fill_seg(idx, L.w_stage + s * seg_floats(32, 8), *stage[s], 32, 8, K_ACC, 0);
+        fill_bias(idx, L.b_stage + s * bias_floats(8), *stage[s], 8);
+    }
+    fill_seg(idx, L.w5pe, P.mlps[5], 8, 8, K_POS, W);            // skip concat [h, pts] (dm_nerf.py:87)
+    fill_seg(idx, L.w_rgbh, P.rgb_hidden, 32, 4, K_ACC, 0);
+    fill_seg(idx, L.w_rgbh_dir, P.rgb_hidden, 4, 4, K_DIR, W);   // cat[rgb_feature, dirs] (dm_nerf.py:90)
+    fill_bias(idx, L.b_rgbh, P.rgb_hidden, 4);
+    fill_seg(idx, L.w_insh, P.ins_hidden, 32, 4, K_ACC, 0);
+    fill_bias(idx, L.b_insh, P.ins_hidden, 4);
+    fill_seg(idx, L.w_inso, P.ins_out, 16, L.OBI, K_ACC, 0);
+    fill_bias(idx, L.b_inso, P.ins_out, L.OBI);
+    for (int half = 0; half < 2; ++half)
+        for (int p = 0; p < 128; ++p) idx[L.w_den + half * 128 + p] = (int32_t)P.density.w(0, cfeat(p, half));
+    idx[L.b_den] = (int32_t)P.density.b(0);
+    for (int c = 0; c < 3; ++c)
+        for (int half = 0; half < 2; ++half)
+            for (int p = 0; p < 64; ++p)
+                idx[L.w_rgbo + (c * 2 + half) * 64 + p] = (int32_t)P.rgb_out.w(c, cfeat(p, half));
+    for (int c = 0; c < 3; ++c) idx[L.b_rgbo + c] = (int32_t)P.rgb_out.b(c);
+    return DMNERF_OK;
+}

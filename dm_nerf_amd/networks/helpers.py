@@ -1,0 +1,113 @@
+"""Drop-in for the hot-path functions of the reference's ``networks/helpers.py``."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+_const_cache = {}
+
+
+def _device(device):
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def linspace01(steps, device):
+    """``torch.linspace(0, 1, steps)`` evaluated on the CPU (the reference's values, bit for bit)
+    and cached on ``device``; ROCm's own linspace kernel may round differently."""
+    key = (int(steps), str(device))
+    if key not in _const_cache:
+        _const_cache[key] = torch.linspace(0., 1., steps=int(steps)).to(device)
+    return _const_cache[key]
+
+
+def get_rays_k(H, W, K, c2w, row0=0, nrows=None):
+    """``get_rays_k`` (networks/helpers.py:50-61) -> ``rays_o, rays_d`` of shape [H, W, 3].
+
+    ``K``: numpy 3x3 / 4x4 intrinsics, ``c2w``: [3or4, 4] tensor (any device; 12 floats are read on
+    the host).  ``row0/nrows`` (extension) generate only a band of rows -> [nrows, W, 3]: this is
+    how ranks shard a frame without a scatter.
+    """
+    H, W = int(H), int(W)
+    nrows = H - row0 if nrows is None else int(nrows)
+    dev = c2w.device if torch.is_tensor(c2w) and c2w.is_cuda else _device(None)
+    K = np.asarray(K)
+    intr = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[2, 2]], dtype=np.float64).astype(np.float32)
+    c = (c2w.detach().cpu().numpy() if torch.is_tensor(c2w) else np.asarray(c2w)).astype(np.float32)[:3, :4]
+    c = np.ascontiguousarray(c)
+    rays_o = torch.empty(nrows, W, 3, dtype=torch.float32, device=dev)
+    rays_d = torch.empty(nrows, W, 3, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().dmnerf_raygen(H, W, intr.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p),
+                                         int(row0), nrows, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.stream()), "dmnerf_raygen")
+    return rays_o, rays_d
+
+
+def z_val_sample(N_rays, near, far, N_samples, device=None):
+    """``z_val_sample`` (networks/helpers.py:114-119): ``near + linspace(0,1,S) * (far - near)`` -> [N, S]."""
+    dev = _device(device)
+    t = linspace01(N_samples, dev)
+    z = torch.empty(int(N_rays), int(N_samples), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().dmnerf_z_val_sample(_lib.ptr(t), float(near), float(far), int(N_rays), int(N_samples),
+                                               _lib.ptr(z), _lib.stream()), "dmnerf_z_val_sample")
+    return z
+
+
+def sample_pdf(bins, weights, N_samples, det=False, u=None, return_aux=False):
+    """``sample_pdf`` (networks/helpers.py:123-155).  ``u`` (extension) pins the random draw."""
+    bins, weights = _lib.f32(bins), _lib.f32(weights)
+    _lib.require_gpu(bins, weights)
+    N, nb = bins.shape
+    if weights.shape != (N, nb - 1):
+        raise ValueError("sample_pdf: weights must be [N, bins-1]")
+    if u is None:
+        u = linspace01(N_samples, bins.device) if det else torch.rand([N, N_samples], device=bins.device)
+    u = _lib.f32(u)
+    stride = 0 if u.dim() == 1 else N_samples
+    samples = torch.empty(N, N_samples, dtype=torch.float32, device=bins.device)
+    cdf = torch.empty(N, nb, dtype=torch.float32, device=bins.device) if return_aux else None
+    inds = torch.empty(N, N_samples, dtype=torch.int64, device=bins.device) if return_aux else None
+    _lib.check(_lib.load().dmnerf_sample_pdf(_lib.ptr(bins), _lib.ptr(weights), _lib.ptr(u), stride, N, nb, int(N_samples),
+                                             _lib.ptr(samples), _lib.ptr(cdf), _lib.ptr(inds), _lib.stream()), "dmnerf_sample_pdf")
+    if return_aux:
+        return samples, cdf, inds
+    return samples
+
+
+def sample_from_cdf(bins, cdf, u):
+    """Stage-isolated inverse-CDF step (helpers.py:139-153) -> (samples, inds int64)."""
+    bins, cdf, u = _lib.f32(bins), _lib.f32(cdf), _lib.f32(u)
+    _lib.require_gpu(bins, cdf, u)
+    N, nb = bins.shape
+    ns = u.shape[-1]
+    stride = 0 if u.dim() == 1 else ns
+    samples = torch.empty(N, ns, dtype=torch.float32, device=bins.device)
+    inds = torch.empty(N, ns, dtype=torch.int64, device=bins.device)
+    _lib.check(_lib.load().dmnerf_sample_from_cdf(_lib.ptr(bins), _lib.ptr(cdf), _lib.ptr(u), stride, N, nb, ns,
+                                                  _lib.ptr(samples), _lib.ptr(inds), _lib.stream()), "dmnerf_sample_from_cdf")
+    return samples, inds
+
+
+def stratify(z_vals, t_rand):
+    """Stratified jitter of render.py:42-47 with the draw passed in."""
+    z, t = _lib.f32(z_vals), _lib.f32(t_rand)
+    _lib.require_gpu(z, t)
+    out = torch.empty_like(z)
+    _lib.check(_lib.load().dmnerf_stratify(_lib.ptr(z), _lib.ptr(t), z.shape[0], z.shape[1], _lib.ptr(out), _lib.stream()), "dmnerf_stratify")
+    return out
+
+
+def importance_resample(z_coarse, weights_coarse, N_importance, det=True, u=None, return_samples=False):
+    """render.py:66-70 fused: z_mid, sample_pdf(z_mid, w[...,1:-1]), sort(cat(z_coarse, z_samples))."""
+    z, w = _lib.f32(z_coarse), _lib.f32(weights_coarse)
+    _lib.require_gpu(z, w)
+    N, S = z.shape
+    if u is None:
+        u = linspace01(N_importance, z.device) if det else torch.rand([N, N_importance], device=z.device)
+    u = _lib.f32(u)
+    stride = 0 if u.dim() == 1 else N_importance
+    z_fine = torch.empty(N, S + N_importance, dtype=torch.float32, device=z.device)
+    zs = torch.empty(N, N_importance, dtype=torch.float32, device=z.device) if return_samples else None
+    _lib.check(_lib.load().dmnerf_importance_resample(_lib.ptr(z), _lib.ptr(w), _lib.ptr(u), stride, N, S, int(N_importance),
+                                                      _lib.ptr(z_fine), _lib.ptr(zs), _lib.stream()), "dmnerf_importance_resample")
+    return (z_fine, zs) if return_samples else z_fine

@@ -1,0 +1,105 @@
+"""Drop-in for the reference's ``networks/render.py``: render_train, dm_nerf."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from . import helpers
+
+
+def render_train(raw, z_vals, rays_d):
+    """``render_train`` (networks/render.py:6-28) -> (rgb_map, weights, depth_map, ins_map)."""
+    if torch.is_grad_enabled() and raw.requires_grad:
+        from .. import autograd
+        return autograd.render_train_train(raw, z_vals, rays_d)
+    raw, z, d = _lib.f32(raw), _lib.f32(z_vals), _lib.f32(rays_d)
+    _lib.require_gpu(raw, z, d)
+    N, S, ch = raw.shape
+    C = ch - 4
+    dev = raw.device
+    rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    w = torch.empty(N, S, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    ins = torch.empty(N, C - 1, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().dmnerf_composite_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(d), N, S, C, _lib.ptr(rgb), _lib.ptr(w),
+                                                _lib.ptr(depth), _lib.ptr(ins), _lib.stream()), "dmnerf_composite_fwd")
+    return rgb, w, depth, ins
+
+
+def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args,
+            t_rand=None, u=None, _events=None):
+    """``dm_nerf`` (networks/render.py:31-96) -> the reference's 10-key dict.
+
+    ``position_embedder`` / ``view_embedder`` are accepted for signature compatibility; the
+    encoding (multires 10 / 4, the only values create_nerf's configs use) is computed inside the
+    fused kernel.  RNG parity: with ``args.perturb > 0`` the reference draws ``torch.rand([N,S])``
+    (render.py:46) and then ``torch.rand([N,N_importance])`` (helpers.py:135); the same two draws
+    are made here, in that order, on the rays' device -- or pass ``t_rand`` / ``u`` (extension).
+    ``_events``: optional (begin, end) ``torch.cuda.Event`` pair recorded around the fine MLP kernel.
+    """
+    training = torch.is_grad_enabled() and any(p.requires_grad for p in model_fine.parameters())
+    if training:
+        from .. import autograd
+        return autograd.dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=t_rand, u=u)
+    for emb, want in ((position_embedder, 63), (view_embedder, 27)):
+        if getattr(emb, "out_dim", want) != want:
+            raise NotImplementedError("dm_nerf: only multires=10 / multires_views=4 encoders are implemented")
+    rays_o, rays_d = rays
+    rays_o, rays_d = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3))
+    z_in = _lib.f32(z_vals_coarse)
+    _lib.require_gpu(rays_o, rays_d, z_in)
+    dev = rays_o.device
+    N, S = z_in.shape
+    n_imp = int(args.N_importance)
+    if n_imp < 1:
+        raise NotImplementedError("dm_nerf: N_importance must be >= 1 (every shipped config uses 128)")
+    ins_num = model_fine.ins_num
+    C = ins_num + 1
+    perturb = float(args.perturb)
+    if perturb > 0.:
+        if t_rand is None:
+            t_rand = torch.rand(z_in.shape, device=dev)
+        if u is None:
+            u = torch.rand([N, n_imp], device=dev)
+        t_rand, u = _lib.f32(t_rand), _lib.f32(u)
+        u_stride = n_imp
+    else:
+        t_rand = None
+        if u is None:
+            u = helpers.linspace01(n_imp, dev)      # det = (perturb == 0.)  (render.py:67)
+        u = _lib.f32(u)
+        u_stride = 0 if u.dim() == 1 else n_imp
+    SF = S + n_imp
+    f = dict(dtype=torch.float32, device=dev)
+    out = {
+        'rgb_fine': torch.empty(N, 3, **f), 'ins_fine': torch.empty(N, C - 1, **f),
+        'z_vals_fine': torch.empty(N, SF, **f), 'raw_fine': torch.empty(N, SF, 4 + C, **f),
+        'raw_coarse': torch.empty(N, S, 4 + C, **f), 'rgb_coarse': torch.empty(N, 3, **f),
+        'ins_coarse': torch.empty(N, C - 1, **f), 'z_vals_coarse': torch.empty(N, S, **f),
+        'depth_fine': torch.empty(N, **f), 'depth_coarse': torch.empty(N, **f),
+    }
+    ws = torch.empty(N, SF, **f)
+    a = _lib.RenderArgs()
+    a.d_blob_coarse = model_coarse.blob().data_ptr()
+    a.d_blob_fine = model_fine.blob().data_ptr()
+    a.ins_num = ins_num
+    a.d_rays_o, a.d_rays_d, a.d_z_in = rays_o.data_ptr(), rays_d.data_ptr(), z_in.data_ptr()
+    a.d_t_rand = t_rand.data_ptr() if t_rand is not None else None
+    a.d_u, a.u_row_stride = u.data_ptr(), u_stride
+    a.N, a.S, a.n_imp = N, S, n_imp
+    a.d_z_coarse, a.d_raw_coarse = out['z_vals_coarse'].data_ptr(), out['raw_coarse'].data_ptr()
+    a.d_rgb_coarse, a.d_depth_coarse = out['rgb_coarse'].data_ptr(), out['depth_coarse'].data_ptr()
+    a.d_ins_coarse = out['ins_coarse'].data_ptr()
+    a.d_z_fine, a.d_raw_fine = out['z_vals_fine'].data_ptr(), out['raw_fine'].data_ptr()
+    a.d_rgb_fine, a.d_depth_fine = out['rgb_fine'].data_ptr(), out['depth_fine'].data_ptr()
+    a.d_ins_fine = out['ins_fine'].data_ptr()
+    a.d_weights_ws = ws.data_ptr()
+    if _events is not None:          # (begin, end) torch.cuda.Event pair around the fine-network MLP kernel
+        for e in _events:
+            e.record()               # torch creates the hipEvent_t lazily; the library re-records it in place
+        a.ev_fine_mlp_begin, a.ev_fine_mlp_end = _events[0].cuda_event, _events[1].cuda_event
+    _lib.check(_lib.load().dmnerf_render_rays_fwd(ctypes.byref(a), _lib.stream()), "dmnerf_render_rays_fwd")
+    if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
+        out['ins_fine'] = out['ins_fine'][-args.N_ins:]          # render.py:88-90
+        out['ins_coarse'] = out['ins_coarse'][-args.N_ins:]
+    return out

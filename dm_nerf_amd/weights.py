@@ -1,0 +1,54 @@
+"""Reference state_dict -> kernel weight blob (MFMA A-operand order)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# DM_NeRF.__init__ / state_dict order (networks/dm_nerf.py:59-78 of the reference)
+PARAM_MODULES = [f"mlps.{i}" for i in range(8)] + [
+    "rgb_feature_linear", "ins_feature_linear", "rgb_feature_linears.0", "ins_feature_linears.0",
+    "density_linear", "ins_linear", "rgb_linear"]
+PARAM_KEYS = [f"{m}.{p}" for m in PARAM_MODULES for p in ("weight", "bias")]
+
+_index_cache = {}
+
+
+def pack_index_host(ins_num):
+    """int32 numpy gather index (host only; works without a GPU)."""
+    lib = _lib.load()
+    n = lib.dmnerf_blob_floats(ins_num)
+    if n <= 0:
+        raise ValueError(f"unsupported ins_num={ins_num}")
+    idx = np.empty(n, dtype=np.int32)
+    _lib.check(lib.dmnerf_build_pack_index(ins_num, idx.ctypes.data_as(ctypes.c_void_p), n), "dmnerf_build_pack_index")
+    return idx
+
+
+def pack_index(ins_num, device):
+    key = (ins_num, str(device))
+    if key not in _index_cache:
+        _index_cache[key] = torch.from_numpy(pack_index_host(ins_num)).to(device)
+    return _index_cache[key]
+
+
+def flat_params(state):
+    """Concatenate parameters in reference order.  ``state``: mapping key -> tensor (all on one GPU)."""
+    return torch.cat([state[k].detach().reshape(-1).float() for k in PARAM_KEYS])
+
+
+def pack_blob(state, ins_num, out=None):
+    """Build (or refresh in place) the kernel blob for one DM_NeRF model."""
+    lib = _lib.load()
+    flat = flat_params(state)
+    if flat.numel() != lib.dmnerf_param_count(ins_num):
+        raise ValueError(f"parameter count {flat.numel()} != {lib.dmnerf_param_count(ins_num)} "
+                         f"(only D=8, W=256, skips=[4], 63+27 input channels are supported)")
+    _lib.require_gpu(flat)
+    idx = pack_index(ins_num, flat.device)
+    n = idx.numel()
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=flat.device)
+    _lib.check(lib.dmnerf_pack_weights(_lib.ptr(flat), _lib.ptr(idx), _lib.ptr(out), n, _lib.stream()), "dmnerf_pack_weights")
+    return out

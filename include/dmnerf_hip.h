@@ -1,0 +1,158 @@
+/*
+ * dmnerf_hip.h -- C ABI of libdmnerf_hip.so: the MI355X (gfx950) implementation of the
+ * DM-NeRF ray-rendering hot path.
+ *
+ * The reference (vLAR-group/DM-NeRF) has no FFI/plugin layer: its boundary is a set of Python
+ * callables.  Each entry point below replaces the ATen op sequence of
+ * one of them and cites it (paths relative to the reference checkout).  The Python mirror of
+ * those callables (dm_nerf_amd/networks/) binds these symbols with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer marked d_ is a DEVICE pointer to contiguous row-major float32 (int64 where
+ *     stated); h_ pointers are HOST pointers.  No torch / ATen types cross this boundary.
+ *   - the caller owns all memory; the library never allocates, frees or synchronises on the hot
+ *     path, and launches only on the `stream` it is given (hipStream_t passed as void*),
+ *     so every call is graph-capturable.
+ *   - return 0 on success; negative on error (DMNERF_E_*), message via dmnerf_last_error().
+ *   - N rays, S samples per ray, C = ins_num + 1 object logits, raw row = [r g b sigma | C logits].
+ */
+#ifndef DMNERF_HIP_H
+#define DMNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMNERF_ABI_VERSION 1
+
+#define DMNERF_OK 0
+#define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
+#define DMNERF_E_LAUNCH (-2)  /* hipGetLastError() after launch */
+#define DMNERF_E_NODEV (-3)   /* no HIP device visible */
+
+#define DMNERF_POS_CH 63   /* 3 + 2*10*3, get_embedder(multires=10)  networks/dm_nerf.py:41-55 */
+#define DMNERF_DIR_CH 27   /* 3 + 2*4*3,  get_embedder(multires_views=4) */
+#define DMNERF_W 256       /* netwidth  (config.py:33 default; every shipped config) */
+#define DMNERF_D 8         /* netdepth  (config.py:31 default), skips=[4] (config.py:133) */
+#define DMNERF_MAX_LOGITS 128 /* C = ins_num+1 <= 128 (Replica room_0: 94) */
+
+int dmnerf_abi_version(void);
+const char* dmnerf_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int dmnerf_device_count(void);
+
+/* ---- weights: reference state_dict -> kernel layout -------------------------------------
+ * Flat parameter order = DM_NeRF.__init__ / state_dict order (networks/dm_nerf.py:59-78):
+ *   mlps.0..7, rgb_feature_linear, ins_feature_linear, rgb_feature_linears.0,
+ *   ins_feature_linears.0, density_linear, ins_linear, rgb_linear; each as weight[out,in]
+ *   row-major followed by bias[out].
+ * The kernel "blob" holds the same numbers permuted into MFMA A-operand order (DESIGN.md
+ * section 3), zero padded.  blob[i] = idx[i] >= 0 ? flat[idx[i]] : 0.
+ */
+int64_t dmnerf_param_count(int ins_num);                    /* 696338 for ins_num=13 */
+int64_t dmnerf_blob_floats(int ins_num);
+int dmnerf_build_pack_index(int ins_num, int32_t* h_idx, int64_t n_idx);   /* host only, no GPU */
+int dmnerf_pack_weights(const float* d_flat, const int32_t* d_idx, float* d_blob,
+                        int64_t n_blob, void* stream);
+
+/* ---- helpers.py --------------------------------------------------------------------------
+ * get_rays_k (networks/helpers.py:50-61) for image rows [row0, row0+nrows):
+ *   dirs = [(i-K02)/K00, (j-K12)/K11, K22]; rays_d = R dirs; rays_o = c2w[:3,3].
+ *   h_intr = {K00, K11, K02, K12, K22} already rounded to float32 (what ATen does with the
+ *   numpy float64 scalars); h_c2w = first 3 rows of c2w, row-major [3][4].
+ *   d_rays_o / d_rays_d: [nrows*W, 3].                                                     */
+int dmnerf_raygen(int H, int W, const float* h_intr, const float* h_c2w, int row0, int nrows,
+                  float* d_rays_o, float* d_rays_d, void* stream);
+
+/* z_val_sample (networks/helpers.py:114-119): z[n,s] = near + t[s]*(far-near); d_t = linspace(0,1,S). */
+int dmnerf_z_val_sample(const float* d_t, float near_, float far_, int64_t N, int S, float* d_z,
+                        void* stream);
+
+/* stratified jitter (networks/render.py:42-47): mids/upper/lower, lower + (upper-lower)*t_rand. */
+int dmnerf_stratify(const float* d_z_in, const float* d_t_rand, int64_t N, int S, float* d_z_out,
+                    void* stream);
+
+/* sample_pdf (networks/helpers.py:123-155).  bins [N,nb], weights [N,nb-1], u [N,n_samples]
+ * (u_row_stride = n_samples) or one shared row (u_row_stride = 0, the det=True linspace).
+ * Optional outputs (may be NULL): d_cdf [N,nb] float32, d_inds [N,n_samples] int64.          */
+int dmnerf_sample_pdf(const float* d_bins, const float* d_weights, const float* d_u,
+                      int64_t u_row_stride, int64_t N, int nb, int n_samples, float* d_samples,
+                      float* d_cdf, int64_t* d_inds, void* stream);
+
+/* stage-isolated inverse-CDF step (helpers.py:139-153): same (cdf,u) => same inds, samples. */
+int dmnerf_sample_from_cdf(const float* d_bins, const float* d_cdf, const float* d_u,
+                           int64_t u_row_stride, int64_t N, int nb, int n_samples,
+                           float* d_samples, int64_t* d_inds, void* stream);
+
+/* hierarchical resample + merge (networks/render.py:66-70):
+ *   z_mid, sample_pdf(z_mid, weights[...,1:-1], n_imp, u), sort(cat(z_coarse, z_samples)).
+ * d_z_samples may be NULL.  d_z_fine [N, S + n_imp].                                         */
+int dmnerf_importance_resample(const float* d_z_coarse, const float* d_weights_coarse,
+                               const float* d_u, int64_t u_row_stride, int64_t N, int S, int n_imp,
+                               float* d_z_fine, float* d_z_samples, void* stream);
+
+/* ---- dm_nerf.py ---------------------------------------------------------------------------
+ * Embedder.embed (networks/dm_nerf.py:37-38): x [M,3] -> [M, 3+6L], L frequencies 2^0..2^(L-1). */
+int dmnerf_embed(const float* d_x, int64_t M, int L, float* d_out, void* stream);
+
+/* DM_NeRF.forward (networks/dm_nerf.py:80-106) on pre-embedded rows x [M, 63+27] -> raw [M, 4+C]. */
+int dmnerf_mlp_fwd_embedded(const float* d_blob, int ins_num, const float* d_x, int64_t M,
+                            float* d_raw, void* stream);
+
+/* Fused points + positional encoding + DM_NeRF.forward (networks/render.py:49-61 / :71-83):
+ *   pts = o + d*z; embed(pts) | embed(d/|d|); MLP.  rays_o/rays_d [N,3], z [N,S] -> raw [N,S,4+C]. */
+int dmnerf_mlp_fwd_rays(const float* d_blob, int ins_num, const float* d_rays_o,
+                        const float* d_rays_d, const float* d_z, int64_t N, int S, float* d_raw,
+                        void* stream);
+
+/* ---- render.py ----------------------------------------------------------------------------
+ * render_train (networks/render.py:6-28): raw [N,S,4+C], z [N,S], rays_d [N,3] ->
+ *   rgb_map [N,3], weights [N,S], depth_map [N], ins_map [N,C-1] (sigmoid after the sum, last
+ *   channel dropped).                                                                       */
+int dmnerf_composite_fwd(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N,
+                         int S, int C, float* d_rgb_map, float* d_weights, float* d_depth_map,
+                         float* d_ins_map, void* stream);
+
+/* dm_nerf inference (networks/render.py:31-96, perturb handled by the caller passing t_rand/u):
+ * all stages on `stream`, outputs = the 10 tensors of the reference dict (ins_* are [N, C-1]).
+ *   d_t_rand: [N,S] or NULL (no jitter); d_u / u_row_stride as in dmnerf_sample_pdf.
+ * Scratch: d_weights_ws [N, S+n_imp] floats.                                                  */
+typedef struct {
+    const float* d_blob_coarse;
+    const float* d_blob_fine;
+    int ins_num;
+    const float* d_rays_o;
+    const float* d_rays_d;
+    const float* d_z_in;        /* [N,S] coarse depths before jitter */
+    const float* d_t_rand;      /* nullable */
+    const float* d_u;
+    int64_t u_row_stride;
+    int64_t N;
+    int S;
+    int n_imp;
+    /* outputs */
+    float* d_z_coarse;          /* [N,S]        'z_vals_coarse' (jittered) */
+    float* d_raw_coarse;        /* [N,S,4+C]    'raw_coarse'   */
+    float* d_rgb_coarse;        /* [N,3]        'rgb_coarse'   */
+    float* d_depth_coarse;      /* [N]          'depth_coarse' */
+    float* d_ins_coarse;        /* [N,C-1]      'ins_coarse'   */
+    float* d_z_fine;            /* [N,S+n_imp]  'z_vals_fine'  */
+    float* d_raw_fine;          /* [N,S+n_imp,4+C] 'raw_fine'  */
+    float* d_rgb_fine;          /* [N,3]        'rgb_fine'     */
+    float* d_depth_fine;        /* [N]          'depth_fine'   */
+    float* d_ins_fine;          /* [N,C-1]      'ins_fine'     */
+    float* d_weights_ws;        /* scratch [N, S+n_imp] */
+    /* optional hipEvent_t pair recorded on `stream` around the fine-network MLP launch (the dominant
+     * kernel), so a caller can time it live without splitting the call; NULL = not recorded */
+    void* ev_fine_mlp_begin;
+    void* ev_fine_mlp_end;
+} dmnerf_render_args;
+int dmnerf_render_rays_fwd(const dmnerf_render_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMNERF_HIP_H */

@@ -1,0 +1,296 @@
+"""GPU parity tests (-m gpu): every HIP stage, called through the C ABI via the Python mirror of
+the reference API, against (a) the committed golden vectors produced by the reference itself and
+(b) the CPU oracle on fresh seeded inputs.  Tolerances are the per-stage contract of SURVEY.md 8(a):
+integer / permutation outputs exact; raygen / z grids <= 1 ulp-class; PE abs 2.4e-7 (x2 margin);
+MLP |d raw| <= 1e-5 (1 + |raw|); compositing rel 2e-6 (+abs); argmax mismatch <= 1e-3 of rays.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from dm_nerf_amd import _lib
+    from dm_nerf_amd.networks import dm_nerf as M, helpers as H, render as R
+    from dm_nerf_amd import config as Cfg
+    _lib.load()
+    return types.SimpleNamespace(M=M, H=H, R=R, Cfg=Cfg, lib=_lib)
+
+
+def dev(t):
+    return t.cuda()
+
+
+def cpu(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu()
+
+
+def maxrel(a, b):
+    return float(((a - b).abs() / (1 + b.abs())).max())
+
+
+def model_from(A, sd, ins_num):
+    m = A.M.DM_NeRF(8, 256, 63, 27, [4], ins_num)
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+# ------------------------------------------------------------------------------------------
+def test_embed_golden(A, golden):
+    g = golden("embed")
+    e10, d10 = A.M.get_embedder(10, 0)
+    e4, d4 = A.M.get_embedder(4, 0)
+    assert (d10, d4) == (63, 27)
+    y10, y4 = cpu(e10.embed(dev(g["x"]))), cpu(e4.embed(dev(g["d"])))
+    assert y10.shape == g["y10"].shape
+    assert torch.equal(y10[:, :3], g["x"])
+    assert float((y10 - g["y10"]).abs().max()) <= 4.8e-7      # args reach 7680 rad
+    assert float((y4 - g["y4"]).abs().max()) <= 2.4e-7
+
+
+def test_mlp_embedded_golden(A, golden):
+    g = golden("mlp")
+    for ins_num in (13, 59, 93):
+        sd = O.make_weights(int(g[f"seed_{ins_num}"]), ins_num, gain=float(g["gain"]))
+        m = model_from(A, sd, ins_num)
+        with torch.no_grad():
+            y = cpu(m(dev(g[f"x_{ins_num}"])))
+        want = g[f"y_{ins_num}"]
+        assert y.shape == want.shape
+        assert maxrel(y, want) <= 1e-5, (ins_num, maxrel(y, want))
+
+
+def test_mlp_embedded_vs_oracle_ragged_sizes(A):
+    sd = O.make_weights(3, 13, gain=1.7)
+    m = model_from(A, sd, 13)
+    g = torch.Generator().manual_seed(3)
+    for M_rows in (1, 31, 32, 33, 127, 1000):
+        pts = (torch.rand(M_rows, 3, generator=g) * 2 - 1) * 8
+        dirs = torch.nn.functional.normalize(torch.randn(M_rows, 3, generator=g), dim=-1)
+        x = torch.cat([O.embed(pts, 10), O.embed(dirs, 4)], -1)
+        with torch.no_grad():
+            y = cpu(m(dev(x)))
+        want = O.mlp_forward(sd, x)
+        assert y.shape == want.shape and maxrel(y, want) <= 1e-5, (M_rows, maxrel(y, want))
+    # leading dims are preserved and an empty batch is fine
+    with torch.no_grad():
+        assert m(dev(x).reshape(10, 100, 90)).shape == (10, 100, 18)
+        assert m(torch.empty(0, 90, device="cuda")).shape == (0, 18)
+
+
+def test_blob_refreshes_after_inplace_update(A):
+    sd = O.make_weights(4, 13, gain=1.7)
+    m = model_from(A, sd, 13)
+    x = torch.randn(64, 90)
+    with torch.no_grad():
+        y0 = cpu(m(dev(x)))
+        m.density_linear.bias.add_(1.0)             # what optimizer.step() does: in-place, bumps _version
+        y1 = cpu(m(dev(x)))
+    assert torch.allclose(y1[:, 3], y0[:, 3] + 1.0, atol=1e-5) and torch.equal(y1[:, :3], y0[:, :3])
+
+
+def test_render_train_golden(A, golden):
+    g = golden("render_train")
+    for k in ("S64_C14", "S192_C14", "S320_C60", "S192_C94", "S5_C3", "kat"):
+        raw, z, d = g[f"{k}_raw"], g[f"{k}_z"], g[f"{k}_d"]
+        with torch.no_grad():
+            rgb, w, dep, ins = [cpu(t) for t in A.R.render_train(dev(raw), dev(z), dev(d))]
+        for got, name in ((rgb, "rgb"), (w, "w"), (dep, "depth"), (ins, "ins")):
+            want = g[f"{k}_{name}"]
+            assert got.shape == want.shape, (k, name)
+            assert torch.allclose(got, want, rtol=2e-6, atol=2e-6 * max(1.0, float(want.abs().max()))), \
+                (k, name, float((got - want).abs().max()))
+        # argmax given (nearly) identical ins_map
+        assert (ins.argmax(-1) == g[f"{k}_ins"].argmax(-1)).float().mean() >= 0.99 or ins.shape[-1] < 2
+
+
+def test_sample_pdf_golden(A, golden):
+    g = golden("sample_pdf")
+    bins, w = dev(g["bins"]), dev(g["w"])
+    # stage-isolated: identical (cdf, u) -> identical indices (exact) and samples
+    s, inds = A.H.sample_from_cdf(bins, dev(g["cdf"]), dev(g["u_rnd"]))
+    assert torch.equal(cpu(inds), g["inds_rnd"])
+    assert torch.allclose(cpu(s), g["s_rnd"], rtol=1e-6, atol=1e-6)
+    s, inds = A.H.sample_from_cdf(bins, dev(g["cdf"]), dev(g["u_det"]))
+    assert torch.equal(cpu(inds), g["inds_det"])
+    assert torch.allclose(cpu(s), g["s_det"], rtol=1e-6, atol=1e-6)
+    # full sample_pdf: cdf within 1-2 ulp, indices >= 99.9 % equal, samples close where indices agree
+    for u_key, s_key, i_key in (("u_det", "s_det", "inds_det"), ("u_rnd", "s_rnd", "inds_rnd")):
+        s, cdf, inds = A.H.sample_pdf(bins, w, 128, u=dev(g[u_key]), return_aux=True)
+        s, cdf, inds = cpu(s), cpu(cdf), cpu(inds)
+        assert float((cdf - g["cdf"]).abs().max()) <= 2.4e-7
+        same = inds == g[i_key]
+        assert same.float().mean() >= 0.999
+        assert torch.allclose(s[same], g[s_key][same], rtol=1e-5, atol=1e-5)
+    # det=True path builds its own linspace
+    s = cpu(A.H.sample_pdf(bins, w, 128, det=True))
+    assert torch.allclose(s, g["s_det"], rtol=1e-5, atol=2e-4)
+
+
+def test_importance_resample_golden(A, golden):
+    g = golden("sample_pdf")
+    N = g["z"].shape[0]
+    # weights_coarse[..., 1:-1] are the pdf weights (render.py:67)
+    wc = torch.zeros(N, 64); wc[:, 1:-1] = g["w"]
+    zf, zs = A.H.importance_resample(dev(g["z"]), dev(wc), 128, u=dev(g["u_det"]), return_samples=True)
+    zf, zs = cpu(zf), cpu(zs)
+    assert zf.shape == (N, 192)
+    assert torch.allclose(zs, g["s_det"], rtol=1e-5, atol=2e-4)
+    # exact permutation property: z_fine is the sorted multiset of coarse + the kernel's own samples
+    assert torch.equal(zf, torch.sort(torch.cat([g["z"], zs], -1), -1)[0])
+    assert torch.allclose(zf, g["zf_det"], rtol=1e-5, atol=2e-4)
+    zf2, zs2 = A.H.importance_resample(dev(g["z"]), dev(wc), 128, u=dev(g["u_rnd"]), return_samples=True)
+    assert torch.equal(cpu(zf2), torch.sort(torch.cat([g["z"], cpu(zs2)], -1), -1)[0])
+
+
+def test_rays_and_zvals_golden(A, golden):
+    g = golden("rays")
+    H_, W_ = [int(v) for v in g["HW"]]
+    c2w = g["c2w"]
+    for name in ("dmsr", "replica", "scannet"):
+        o, d = A.H.get_rays_k(H_, W_, g[f"K_{name}"].numpy(), dev(c2w))
+        assert o.shape == (H_, W_, 3)
+        assert torch.equal(cpu(o), g[f"o_{name}"])
+        assert torch.allclose(cpu(d), g[f"d_{name}"], rtol=3e-7, atol=1e-7)
+    o, d = A.H.get_rays_k(480, 640, g["K_full"].numpy(), dev(c2w))
+    d = cpu(d)
+    assert torch.allclose(d[0], g["d_full_row0"], rtol=3e-7, atol=1e-7)
+    assert torch.allclose(d[479], g["d_full_row479"], rtol=3e-7, atol=1e-7)
+    # a row band equals the same rows of the full frame (how ranks shard a frame)
+    ob, db = A.H.get_rays_k(480, 640, g["K_full"].numpy(), dev(c2w), row0=120, nrows=60)
+    assert torch.equal(cpu(db), d[120:180])
+    z = cpu(A.H.z_val_sample(3, 4.0, 15.0, 64))
+    assert torch.equal(z, g["z_4_15"])
+    assert torch.equal(cpu(A.H.z_val_sample(2, 0.0, 4.7, 64)), g["z_0_47"])
+    assert torch.equal(cpu(A.H.stratify(dev(g["z_4_15"]), dev(g["t_rand"]))), g["z_jit"])
+
+
+def _check_dict(out, g, prefix, N_ins=None):
+    worst = {}
+    for k in ('rgb_fine', 'ins_fine', 'z_vals_fine', 'raw_fine', 'raw_coarse', 'rgb_coarse', 'ins_coarse',
+              'z_vals_coarse', 'depth_fine', 'depth_coarse'):
+        got, want = cpu(out[k]), g[f"{prefix}_{k}"]
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        worst[k] = maxrel(got, want)
+    return worst
+
+
+def test_dm_nerf_dict_golden(A, golden):
+    g = golden("dm_nerf")
+    ins_num = int(g["ins_num"])
+    kw = dict(gain=float(g["gain"]), sigma_bias=float(g["sigma_bias"]))
+    mc = model_from(A, O.make_weights(int(g["seed_c"]), ins_num, **kw), ins_num)
+    mf = model_from(A, O.make_weights(int(g["seed_f"]), ins_num, **kw), ins_num)
+    pe, _ = A.M.get_embedder(10, 0); ve, _ = A.M.get_embedder(4, 0)
+    rays = dev(g["rays"])
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        out = A.R.dm_nerf(rays, pe, ve, mc, mf, dev(g["z_in"]), args)
+    worst = _check_dict(out, g, "det")
+    assert worst['z_vals_coarse'] == 0.0
+    assert max(worst.values()) <= 2e-4, worst          # end-to-end: sample positions feed back through the MLP
+    assert worst['rgb_fine'] <= 2e-5 and worst['raw_coarse'] <= 1e-5, worst
+    lab = cpu(out['ins_fine']).argmax(-1)
+    assert (lab == g["det_ins_fine"].argmax(-1)).float().mean() >= 0.95   # 24 rays: allow one flip
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=7)
+    with torch.no_grad():
+        out = A.R.dm_nerf(rays, pe, ve, mc, mf, dev(g["z_in"]), args, t_rand=dev(g["t_rand"]), u=dev(g["u"]))
+    worst = _check_dict(out, g, "prt")
+    assert out['ins_fine'].shape == (7, 13)
+    assert max(worst.values()) <= 2e-4, worst
+
+
+def test_dm_nerf_vs_oracle_1024_rays(A):
+    """BASELINE config 0 shape (1024 rays, 64+128) on the synthetic 640x480 DM-SR camera."""
+    ins_num = 13
+    sd_c = O.make_weights(11, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(12, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+    K = O.dmsr_intrinsics(480, 640)
+    c2w = O.pose_spherical(20.0, -65.0, 7.0)
+    ro, rd = O.get_rays_k(480, 640, K, c2w)
+    sel = torch.from_numpy(np.random.RandomState(0).choice(480 * 640, 1024, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    z = O.z_val_sample(1024, 4.0, 15.0, 64).contiguous()
+    with torch.no_grad():
+        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0.)
+        args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+        got = A.R.dm_nerf(dev(rays), None, None, mc, mf, dev(z), args)
+    got = {k: cpu(v) for k, v in got.items()}
+    assert maxrel(got['raw_coarse'], want['raw_coarse']) <= 1e-5
+    assert torch.allclose(got['rgb_coarse'], want['rgb_coarse'], rtol=2e-6, atol=2e-6)
+    # fine level: sampled depths agree to float noise on >= 99.9 % of the samples
+    dz = (got['z_vals_fine'] - want['z_vals_fine']).abs()
+    assert float((dz <= 1e-4).float().mean()) >= 0.999
+    mse = float(((got['rgb_fine'] - want['rgb_fine']) ** 2).mean())
+    psnr = -10 * np.log10(max(mse, 1e-20))
+    assert psnr >= 80.0, psnr                                  # north_star: within 0.05 dB of the reference
+    flips = float((got['ins_fine'].argmax(-1) != want['ins_fine'].argmax(-1)).float().mean())
+    assert flips <= 1e-3 + 1.0 / 1024, flips
+
+
+def test_full_size_properties(A):
+    """BASELINE config 1 size (4096 rays x 64+128) without the oracle: structural invariants."""
+    ins_num = 13
+    mc = model_from(A, O.make_weights(21, ins_num, gain=1.7, sigma_bias=0.3), ins_num)
+    mf = model_from(A, O.make_weights(22, ins_num, gain=1.7, sigma_bias=0.3), ins_num)
+    K = O.dmsr_intrinsics(480, 640)
+    c2w = O.pose_spherical(20.0, -65.0, 7.0)
+    ro, rd = A.H.get_rays_k(480, 640, K, dev(c2w))
+    ro, rd = ro.reshape(-1, 3)[:4096], rd.reshape(-1, 3)[:4096]
+    z = A.H.z_val_sample(4096, 4.0, 15.0, 64)
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        out = A.R.dm_nerf(torch.stack([ro, rd]), None, None, mc, mf, z, args)
+        out2 = A.R.dm_nerf(torch.stack([ro, rd]), None, None, mc, mf, z, args)
+        # chunk independence: rays 1000..1999 alone give the same answer (rays are independent units)
+        sub = A.R.dm_nerf(torch.stack([ro[1000:2000], rd[1000:2000]]), None, None, mc, mf, z[1000:2000].contiguous(), args)
+    zf = out['z_vals_fine']
+    assert bool((zf[:, 1:] >= zf[:, :-1]).all())                               # sortedness
+    assert bool(torch.isfinite(out['raw_fine']).all())
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k                                 # run-to-run determinism
+        assert torch.equal(out[k][1000:2000], sub[k]), k
+    w_sum = A.R.render_train(out['raw_fine'], zf, rd)[1].sum(-1)
+    assert float(w_sum.max()) <= 1.0 + 1e-5 and float(w_sum.min()) >= 0.0      # weights are a sub-probability
+    assert float(out['rgb_fine'].min()) >= 0.0 and float(out['rgb_fine'].max()) <= 1.0 + 1e-6
+    # compositing is linear in the logits' weights: render_train(raw) reproduces the dict entries
+    rgb, w, dep, ins = A.R.render_train(out['raw_fine'], zf, rd)
+    assert torch.equal(rgb, out['rgb_fine']) and torch.equal(dep, out['depth_fine']) and torch.equal(ins, out['ins_fine'])
+
+
+def test_create_nerf_and_state_dict_roundtrip(A):
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256,
+                                 ins_num=13, device=torch.device("cuda:0"))
+    pe, ve, mc, mf, args2 = A.Cfg.create_nerf(args)
+    assert args2 is args and pe.out_dim == 63 and ve.out_dim == 27
+    keys = list(mc.state_dict())
+    assert keys[:2] == ["mlps.0.weight", "mlps.0.bias"] and len(keys) == 30
+    assert "rgb_feature_linears.0.weight" in keys and "ins_linear.bias" in keys
+    assert sum(p.numel() for p in mc.parameters()) == 696338
+    sd = O.make_weights(5, 13)
+    mc.load_state_dict(sd)                                  # reference checkpoints load unchanged
+    x = torch.randn(40, 90)
+    with torch.no_grad():
+        assert maxrel(cpu(mc(dev(x))), O.mlp_forward(sd, x)) <= 1e-5
+
+
+def test_errors_are_loud(A):
+    m = model_from(A, O.make_weights(1, 13), 13)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(torch.randn(4, 90))                           # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        A.M.DM_NeRF(4, 128, 63, 27, [2], 13).cuda().blob()
+    with pytest.raises(RuntimeError):
+        A.R.render_train(torch.zeros(2, 2000, 8, device="cuda"), torch.zeros(2, 2000, device="cuda"),
+                         torch.ones(2, 3, device="cuda"))    # S beyond the kernel's per-ray staging
