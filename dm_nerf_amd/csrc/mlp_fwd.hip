@@ -281,10 +281,10 @@ int launch(const MlpArgs& a, hipStream_t stream) {
 
 extern "C" int dmnerf_mlp_fwd_embedded(const float* d_blob, int ins_num, const float* d_x, int64_t M,
                                        float* d_raw, void* stream) {
-    if (!d_blob || !d_x || !d_raw) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_embedded: null pointer");
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_embedded: ins_num %d unsupported", ins_num);
     if (M < 0) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_embedded: M < 0");
-    if (M == 0) return DMNERF_OK;
+    if (M == 0) return DMNERF_OK;      // an empty batch is legal (and has null data pointers)
+    if (!d_blob || !d_x || !d_raw) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_embedded: null pointer");
     MlpArgs a{};
     a.blob = d_blob; a.L = make_layout(ins_num); a.x = d_x; a.raw = d_raw; a.M = M; a.S = 1;
     return launch<true>(a, (hipStream_t)stream);
@@ -293,10 +293,10 @@ extern "C" int dmnerf_mlp_fwd_embedded(const float* d_blob, int ins_num, const f
 extern "C" int dmnerf_mlp_fwd_rays(const float* d_blob, int ins_num, const float* d_rays_o,
                                    const float* d_rays_d, const float* d_z, int64_t N, int S,
                                    float* d_raw, void* stream) {
-    if (!d_blob || !d_rays_o || !d_rays_d || !d_z || !d_raw) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays: null pointer");
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays: ins_num %d unsupported", ins_num);
     if (N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays: bad N=%lld S=%d", (long long)N, S);
     if (N == 0) return DMNERF_OK;
+    if (!d_blob || !d_rays_o || !d_rays_d || !d_z || !d_raw) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays: null pointer");
     MlpArgs a{};
     a.blob = d_blob; a.L = make_layout(ins_num); a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z;
     a.raw = d_raw; a.M = N * S; a.S = S;

@@ -26,6 +26,18 @@ def render_train(raw, z_vals, rays_d):
     return rgb, w, depth, ins
 
 
+def run_network(model, rays_o, rays_d, z_vals):
+    """pts = o + d z -> embed(pts) | embed(d/|d|) -> ``model`` (networks/render.py:49-61 / :71-83)
+    as one fused kernel: ``[N,3], [N,3], [N,S] -> raw [N,S,4+C]`` (inference only)."""
+    rays_o, rays_d, z = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3)), _lib.f32(z_vals)
+    _lib.require_gpu(rays_o, rays_d, z)
+    N, S = z.shape
+    raw = torch.empty(N, S, 4 + model.ins_num + 1, dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().dmnerf_mlp_fwd_rays(_lib.ptr(model.blob()), model.ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d),
+                                               _lib.ptr(z), N, S, _lib.ptr(raw), _lib.stream()), "dmnerf_mlp_fwd_rays")
+    return raw
+
+
 def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args,
             t_rand=None, u=None, _events=None):
     """``dm_nerf`` (networks/render.py:31-96) -> the reference's 10-key dict.

@@ -174,13 +174,41 @@ def test_rays_and_zvals_golden(A, golden):
     assert torch.equal(cpu(A.H.stratify(dev(g["z_4_15"]), dev(g["t_rand"]))), g["z_jit"])
 
 
-def _check_dict(out, g, prefix, N_ins=None):
+def _check_dict(out, g, prefix):
     worst = {}
     for k in ('rgb_fine', 'ins_fine', 'z_vals_fine', 'raw_fine', 'raw_coarse', 'rgb_coarse', 'ins_coarse',
               'z_vals_coarse', 'depth_fine', 'depth_coarse'):
         got, want = cpu(out[k]), g[f"{prefix}_{k}"]
         assert got.shape == want.shape, (k, got.shape, want.shape)
         worst[k] = maxrel(got, want)
+    return worst
+
+
+def _check_levels(A, out, g, prefix, mf, rays):
+    """Coarse level strictly; the fine level stage by stage.  The inverse-CDF step divides by the
+    local cdf slope (as small as 1e-5, helpers.py:151), so float noise in the coarse weights moves a
+    few fine depths by ~1e-3, and 2^9-frequency encodings amplify that in raw_fine: end-to-end the
+    fine tensors are compared loosely, and each fine stage is pinned on the GOLDEN inputs instead."""
+    worst = _check_dict(out, g, prefix)
+    assert worst['z_vals_coarse'] == 0.0
+    assert worst['raw_coarse'] <= 1e-5 and worst['rgb_coarse'] <= 2e-6 and worst['ins_coarse'] <= 2e-6, worst
+    assert worst['depth_coarse'] <= 2e-6, worst
+    dz = (cpu(out['z_vals_fine']) - g[f"{prefix}_z_vals_fine"]).abs()
+    assert float((dz <= 1e-4).float().mean()) >= 0.99 and float(dz.max()) <= 2e-2, (float(dz.max()),)
+    assert worst['rgb_fine'] <= 1e-3 and worst['depth_fine'] <= 1e-3 and worst['ins_fine'] <= 1e-3, worst
+    # fine network on the golden depths: f32-roundoff class
+    zf = dev(g[f"{prefix}_z_vals_fine"])
+    with torch.no_grad():
+        raw_f = A.R.run_network(mf, rays[0], rays[1], zf)
+    assert maxrel(cpu(raw_f), g[f"{prefix}_raw_fine"]) <= 1e-5
+    # fine compositing on the golden raw
+    with torch.no_grad():
+        rgb, w, dep, ins = A.R.render_train(dev(g[f"{prefix}_raw_fine"]), zf, rays[1])
+    assert torch.allclose(cpu(rgb), g[f"{prefix}_rgb_fine"], rtol=2e-6, atol=2e-6)
+    assert torch.allclose(cpu(dep), g[f"{prefix}_depth_fine"], rtol=2e-6, atol=2e-5)
+    n_ins = g[f"{prefix}_ins_fine"].shape[0]
+    assert torch.allclose(cpu(ins)[-n_ins:], g[f"{prefix}_ins_fine"], rtol=2e-6, atol=2e-6)
+    assert torch.equal(cpu(ins)[-n_ins:].argmax(-1), g[f"{prefix}_ins_fine"].argmax(-1))      # argmax exact given identical inputs
     return worst
 
 
@@ -195,18 +223,12 @@ def test_dm_nerf_dict_golden(A, golden):
     args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
     with torch.no_grad():
         out = A.R.dm_nerf(rays, pe, ve, mc, mf, dev(g["z_in"]), args)
-    worst = _check_dict(out, g, "det")
-    assert worst['z_vals_coarse'] == 0.0
-    assert max(worst.values()) <= 2e-4, worst          # end-to-end: sample positions feed back through the MLP
-    assert worst['rgb_fine'] <= 2e-5 and worst['raw_coarse'] <= 1e-5, worst
-    lab = cpu(out['ins_fine']).argmax(-1)
-    assert (lab == g["det_ins_fine"].argmax(-1)).float().mean() >= 0.95   # 24 rays: allow one flip
+    _check_levels(A, out, g, "det", mf, rays)
     args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=7)
     with torch.no_grad():
         out = A.R.dm_nerf(rays, pe, ve, mc, mf, dev(g["z_in"]), args, t_rand=dev(g["t_rand"]), u=dev(g["u"]))
-    worst = _check_dict(out, g, "prt")
-    assert out['ins_fine'].shape == (7, 13)
-    assert max(worst.values()) <= 2e-4, worst
+    assert out['ins_fine'].shape == (7, 13) and out['ins_coarse'].shape == (7, 13)
+    _check_levels(A, out, g, "prt", mf, rays)
 
 
 def test_dm_nerf_vs_oracle_1024_rays(A):
