@@ -43,6 +43,16 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def build_models(device):
     from dm_nerf_amd import config as Cfg
     torch.manual_seed(0)
@@ -150,7 +160,7 @@ def main():
                                    "4096-ray chunk per step per GPU, det sampling, ins_num=13, random-init weights",
                        "rays_per_step_per_gpu": N_RAYS, "parallelism": f"ray-sharded x{world}" + (" + RCCL all-gather of tiles" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "kernel": "mlp_fwd_kernel<1,false> (fine network, 4096x192 samples)", "kernel_ms": k_ms,
                          "flop_per_launch": flop_per_launch},
             "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
