@@ -51,6 +51,12 @@ SIGNATURES = {
     "dmnerf_mlp_fwd_rays": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_composite_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_render_rays_fwd": (c_int, [ctypes.POINTER(RenderArgs), c_vp]),
+    "dmnerf_composite_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    "dmnerf_train_save_floats": (c_i64, [c_i64]),
+    "dmnerf_mlp_fwd_rays_train": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_blob_t_floats": (c_i64, [c_int]),
+    "dmnerf_build_pack_index_t": (c_int, [c_int, c_vp, c_i64]),
+    "dmnerf_mlp_bwd_data": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 _lib = None

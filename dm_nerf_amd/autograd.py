@@ -1,20 +1,176 @@
-"""Training-mode (autograd) entry points.  Backward kernels are not built yet: fail loudly."""
+"""Training-mode entry points: ``torch.autograd.Function`` wrappers around the HIP forward /
+backward kernels, so ``total_loss.backward()`` + ``torch.optim.Adam`` of the reference training
+loop (train_dmsr.py:56-64) work unchanged.
+
+Gradient barriers of the reference are reproduced structurally:
+  * ``weights_ins.detach()`` (render.py:22-23)  -- composite_bwd gives the ins logits no path into sigma;
+  * ``h.detach()`` on the ins branch (dm_nerf.py:95) -- mlp_bwd_data does not add d(ins_feature) to dh_7;
+  * ``z_samples.detach()`` (render.py:68) -- the resampled depths are computed outside autograd.
+
+Weight gradients dW = dy . x^T (a plain GEMM over the M samples of the batch, both operands
+stored feature-major by the kernels) currently go through torch.mm (rocBLAS f32) -- see
+DESIGN.md section 6; bias gradients are row sums of dy.
+"""
+import torch
+
+from . import _lib
+from .networks import helpers
+
+W = 256
+HW = 128
 
 
-def _todo(what):
-    raise NotImplementedError(
-        f"dm_nerf_amd: {what} under autograd is not implemented yet (the HIP backward kernels "
-        "composite_bwd / mlp_bwd are the next rows of SURVEY.md section 8); run under torch.no_grad() "
-        "for inference.  There is deliberately no eager-PyTorch fallback.")
+def _views(buf, M):
+    """Named [rows, M] views of a SaveLayout workspace (csrc/layout.h)."""
+    o = 0
+    out = {}
+    for name, rows in (("pe", 63), ("de", 27), ("h", 8 * W), ("f", W), ("q", W), ("g1", HW), ("g2", HW)):
+        out[name] = buf[o:o + rows * M].view(rows, M)
+        o += rows * M
+    out["h"] = out["h"].view(8, W, M)
+    return out
 
 
-def mlp_forward_train(model, x):
-    _todo("DM_NeRF.forward")
+class MLPRaysFunction(torch.autograd.Function):
+    """raw[N,S,4+C] = DM_NeRF(embed(o + d z) | embed(d/|d|)); parameters are inputs 3.. in state_dict order."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, z, *params):
+        lib = _lib.load()
+        N, S = z.shape
+        M = N * S
+        ins_num = model.ins_num
+        raw = torch.empty(N, S, 4 + ins_num + 1, dtype=torch.float32, device=z.device)
+        save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
+        _lib.check(lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(model.blob()), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
+                                                 N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
+        ctx.model, ctx.M, ctx.save = model, M, save
+        ctx.blob, ctx.blob_t = model.blob(), model.blob_t()      # the weights this forward used
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib = _lib.load()
+        model, M = ctx.model, ctx.M
+        ins_num = model.ins_num
+        C = ins_num + 1
+        g = _lib.f32(g_raw).reshape(M, 4 + C)
+        dsave = torch.empty_like(ctx.save)
+        _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                                           _lib.ptr(dsave), _lib.stream()), "dmnerf_mlp_bwd_data")
+        x, d = _views(ctx.save, M), _views(dsave, M)
+        grads = {}
+        # trunk: dW_l = dy_l . x_l^T, x_0 = embed(pts), x_l = h_{l-1}, x_5 = [h_4, embed(pts)]
+        for l in range(8):
+            dy = d["h"][l]
+            if l == 0:
+                gw = dy @ x["pe"].t()
+            elif l == 5:
+                gw = torch.cat([dy @ x["h"][4].t(), dy @ x["pe"].t()], 1)
+            else:
+                gw = dy @ x["h"][l - 1].t()
+            grads[f"mlps.{l}.weight"], grads[f"mlps.{l}.bias"] = gw, dy.sum(1)
+        h7 = x["h"][7]
+        grads["rgb_feature_linear.weight"], grads["rgb_feature_linear.bias"] = d["f"] @ h7.t(), d["f"].sum(1)
+        grads["ins_feature_linear.weight"], grads["ins_feature_linear.bias"] = d["q"] @ h7.t(), d["q"].sum(1)
+        grads["rgb_feature_linears.0.weight"] = torch.cat([d["g1"] @ x["f"].t(), d["g1"] @ x["de"].t()], 1)
+        grads["rgb_feature_linears.0.bias"] = d["g1"].sum(1)
+        grads["ins_feature_linears.0.weight"], grads["ins_feature_linears.0.bias"] = d["g2"] @ x["q"].t(), d["g2"].sum(1)
+        gt = g.t()                                                  # [4+C, M]
+        grads["density_linear.weight"], grads["density_linear.bias"] = gt[3:4] @ h7.t(), gt[3:4].sum(1)
+        grads["ins_linear.weight"], grads["ins_linear.bias"] = gt[4:] @ x["g2"].t(), gt[4:].sum(1)
+        grads["rgb_linear.weight"], grads["rgb_linear.bias"] = gt[:3] @ x["g1"].t(), gt[:3].sum(1)
+        ctx.save = None
+        names = [n for n, _ in model.named_parameters()]
+        return (None, None, None, None) + tuple(grads[n] for n in names)
+
+
+class CompositeFunction(torch.autograd.Function):
+    """render_train (networks/render.py:6-28) with its analytic backward."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rays_d):
+        lib = _lib.load()
+        N, S, ch = raw.shape
+        C = ch - 4
+        f = dict(dtype=torch.float32, device=raw.device)
+        rgb, w = torch.empty(N, 3, **f), torch.empty(N, S, **f)
+        depth, ins = torch.empty(N, **f), torch.empty(N, C - 1, **f)
+        _lib.check(lib.dmnerf_composite_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays_d), N, S, C, _lib.ptr(rgb), _lib.ptr(w),
+                                            _lib.ptr(depth), _lib.ptr(ins), _lib.stream()), "dmnerf_composite_fwd")
+        ctx.save_for_backward(raw, z, rays_d, ins)
+        return rgb, w, depth, ins
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_w, g_depth, g_ins):
+        lib = _lib.load()
+        raw, z, rays_d, ins = ctx.saved_tensors
+        N, S, ch = raw.shape
+        C = ch - 4
+
+        def prep(g, shape):
+            if g is None:
+                return None
+            return _lib.f32(g.expand(shape) if g.shape != torch.Size(shape) else g)
+        g_rgb = prep(g_rgb, (N, 3)) if g_rgb is not None else torch.zeros(N, 3, device=raw.device)
+        g_ins = prep(g_ins, (N, C - 1)) if g_ins is not None else torch.zeros(N, C - 1, device=raw.device)
+        g_w, g_depth = prep(g_w, (N, S)), prep(g_depth, (N,))
+        d_raw = torch.empty_like(raw)
+        _lib.check(lib.dmnerf_composite_bwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays_d), _lib.ptr(ins), _lib.ptr(g_rgb), _lib.ptr(g_ins),
+                                            _lib.ptr(g_depth), _lib.ptr(g_w), N, S, C, _lib.ptr(d_raw), _lib.stream()), "dmnerf_composite_bwd")
+        return d_raw, None, None
+
+
+def _params(model):
+    return [p for _, p in model.named_parameters()]
+
+
+def run_network_train(model, rays_o, rays_d, z):
+    """Differentiable (w.r.t. the parameters) fused points + encoding + MLP."""
+    rays_o, rays_d, z = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3)), _lib.f32(z)
+    _lib.require_gpu(rays_o, rays_d, z)
+    model._check_supported()
+    return MLPRaysFunction.apply(model, rays_o, rays_d, z, *_params(model))
 
 
 def render_train_train(raw, z_vals, rays_d):
-    _todo("render_train")
+    raw, z, d = _lib.f32(raw), _lib.f32(z_vals.detach()), _lib.f32(rays_d.detach())
+    _lib.require_gpu(raw, z, d)
+    return CompositeFunction.apply(raw, z, d)
+
+
+def mlp_forward_train(model, x):
+    raise NotImplementedError(
+        "dm_nerf_amd: DM_NeRF.forward on pre-embedded rows is inference-only; training goes through dm_nerf() / "
+        "run_network_train (the reference's train loops only ever call the model through dm_nerf, train_dmsr.py:32)")
 
 
 def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=None, u=None):
-    _todo("dm_nerf")
+    """Training-mode ``dm_nerf`` (networks/render.py:31-96): same dict, differentiable w.r.t. both models."""
+    rays_o, rays_d = rays
+    rays_o, rays_d = _lib.f32(rays_o.reshape(-1, 3)).detach(), _lib.f32(rays_d.reshape(-1, 3)).detach()
+    z_in = _lib.f32(z_vals_coarse).detach()
+    _lib.require_gpu(rays_o, rays_d, z_in)
+    N, S = z_in.shape
+    n_imp = int(args.N_importance)
+    perturb = float(args.perturb)
+    if perturb > 0.:                                   # RNG order of the reference: [N,S] then [N,n_imp]
+        if t_rand is None:
+            t_rand = torch.rand(z_in.shape, device=z_in.device)
+        if u is None:
+            u = torch.rand([N, n_imp], device=z_in.device)
+        z_coarse = helpers.stratify(z_in, t_rand)
+    else:
+        z_coarse = z_in
+    raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse)
+    rgb_coarse, weights_coarse, depth_coarse, ins_coarse = CompositeFunction.apply(raw_coarse, z_coarse, rays_d)
+    with torch.no_grad():                              # z_samples.detach()  (render.py:68)
+        z_fine = helpers.importance_resample(z_coarse, weights_coarse.detach(), n_imp, det=(perturb == 0.), u=u)
+    raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine)
+    rgb_fine, weights_fine, depth_fine, ins_fine = CompositeFunction.apply(raw_fine, z_fine, rays_d)
+    if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
+        ins_fine = ins_fine[-args.N_ins:]
+        ins_coarse = ins_coarse[-args.N_ins:]
+    return {'rgb_fine': rgb_fine, 'ins_fine': ins_fine, 'z_vals_fine': z_fine, 'raw_fine': raw_fine,
+            'raw_coarse': raw_coarse, 'rgb_coarse': rgb_coarse, 'ins_coarse': ins_coarse,
+            'z_vals_coarse': z_coarse, 'depth_fine': depth_fine, 'depth_coarse': depth_coarse}

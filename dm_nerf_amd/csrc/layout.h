@@ -88,4 +88,52 @@ DMN_HD inline BlobLayout make_layout(int ins_num) {
     return L;
 }
 
+// Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
+//   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
+constexpr int NSTAGE_T = 8;   // rgb_feature^T, mlps.7^T .. mlps.1^T (mlps.5: its 256 h-columns)
+struct BlobTLayout {
+    int C, OBI;
+    int64_t t_inso;     // ins_linear^T:            K = 32*OBI logits (NKG = 4*OBI), rows 128 (OB = 4)
+    int64_t t_insh;     // ins_feature_linears.0^T: K = 128 (NKG = 16), rows 256 (OB = 8)
+    int64_t t_rgbh;     // rgb_feature_linears.0^T: K = 128 (NKG = 16), rows 256 = the rgb_feature columns (OB = 8)
+    int64_t t_stage;    // NSTAGE_T x (NKG = 32, OB = 8)
+    int64_t total;
+};
+DMN_HD inline BlobTLayout make_layout_t(int ins_num) {
+    BlobTLayout L;
+    L.C = ins_num + 1;
+    L.OBI = (L.C + 31) / 32;
+    int64_t o = 0;
+    L.t_inso = o; o += seg_floats(4 * L.OBI, 4);
+    L.t_insh = o; o += seg_floats(16, 8);
+    L.t_rgbh = o; o += seg_floats(16, 8);
+    L.t_stage = o; o += NSTAGE_T * seg_floats(32, 8);
+    L.total = o;
+    return L;
+}
+
+// Training workspace: activations saved by the forward for the backward, every tensor stored
+// feature-major [rows][M] (row = feature in reference order, column = sample).
+constexpr int SAVE_ROWS = POS_CH + DIR_CH + 8 * W + W + W + HW + HW;   // 2906
+struct SaveLayout {
+    int64_t pe, de;      // embed(pts) [63][M], embed(viewdirs) [27][M]
+    int64_t h;           // relu outputs of mlps.0..7: [8][256][M]
+    int64_t f, q;        // rgb_feature / ins_feature (no activation): [256][M] each
+    int64_t g1, g2;      // relu outputs of rgb_feature_linears.0 / ins_feature_linears.0: [128][M] each
+    int64_t total;
+};
+DMN_HD inline SaveLayout make_save_layout(int64_t M) {
+    SaveLayout s;
+    int64_t o = 0;
+    s.pe = o; o += POS_CH * M;
+    s.de = o; o += DIR_CH * M;
+    s.h = o; o += 8 * (int64_t)W * M;
+    s.f = o; o += (int64_t)W * M;
+    s.q = o; o += (int64_t)W * M;
+    s.g1 = o; o += (int64_t)HW * M;
+    s.g2 = o; o += (int64_t)HW * M;
+    s.total = o;
+    return s;
+}
+
 }  // namespace dmn

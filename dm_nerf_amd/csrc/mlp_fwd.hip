@@ -17,11 +17,9 @@
 #include "../../include/dmnerf_hip.h"
 #include "common.h"
 #include "layout.h"
+#include "mlp_common.h"
 
 using namespace dmn;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -33,113 +31,12 @@ struct MlpArgs {
     const float* z;
     const float* x;        // embedded variant [M, 90]
     float* raw;            // [M, 4+C]
+    float* save;           // training: activation workspace, SAVE_ROWS x M floats (layout.h::SaveLayout)
     int64_t M;             // total samples
     int S;                 // samples per ray (rays variant)
 };
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// Weight stream: buffer loads through one wave-uniform descriptor (SGPRs) with the per-lane
-// part (lane*16 B) in a single voffset VGPR and the segment position in the scalar offset, so
-// no 64-bit per-load address ever occupies VGPRs (flat addressing spilled ~300 address pairs).
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ rsrc_t make_rsrc(const float* p, int64_t n_floats) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), /*stride*/ 0, (int)(n_floats * 4), 0x00020000);
-}
-
-__device__ __forceinline__ f32x4 ldw(rsrc_t r, int voff, int soff_bytes) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff_bytes, 0);
-    return __builtin_bit_cast(f32x4, v);
-}
-
-// acc[ob] += Wseg[ob-block rows, k] * B[k, samples] for NKG*4 k-pairs.  B lives in registers in
-// accumulator layout: k-pair p is B[p >> 4][p & 15].  `seg` = float offset of the segment.
-template <int NKG, int OB, int NB>
-__device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[NB],
-                                         f32x16 (&acc)[OB], int voff) {
-    static_assert(NB * 16 >= NKG * 4, "B operand too small");
-#pragma unroll
-    for (int g = 0; g < NKG; ++g) {
-        f32x4 a[OB];
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) a[ob] = ldw(rs, voff, (seg + (g * OB + ob) * 256) * 4);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob) {
-                const int p = g * 4 + kk;
-                acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
-            }
-        }
-    }
-}
-
-// acc[ob][r] = bias of row 32ob + (r&3) + 8(r>>2) + 4half; hoff = half * 64 bytes.
-template <int OB>
-__device__ __forceinline__ void init_bias(rsrc_t rs, int seg, f32x16 (&acc)[OB], int hoff) {
-#pragma unroll
-    for (int ob = 0; ob < OB; ++ob) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = ldw(rs, hoff, (seg + ob * 32 + q * 4) * 4);
-            acc[ob][4 * q + 0] = v[0]; acc[ob][4 * q + 1] = v[1];
-            acc[ob][4 * q + 2] = v[2]; acc[ob][4 * q + 3] = v[3];
-        }
-    }
-}
-
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
-    f32x16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = fmaxf(v[i], 0.f);
-    return r;
-}
-
-// Encoding of one 3-vector in the k-pair order of layout.h::pefeat: lanes 0-31 take the sin
-// slot (and x, z), lanes 32-63 the cos slot (and y, pad).  sin/cos are ocml's full-range f32
-// routines (arguments reach 2^9 * |x|: no fast-math approximations here).
-template <int L, int NV>
-__device__ __forceinline__ void encode(const float (&v)[3], f32x16 (&out)[NV], int half) {
-    static_assert(NV * 16 >= 2 + 3 * L, "encoding registers too small");
-#pragma unroll
-    for (int i = 0; i < NV; ++i) out[i] = (f32x16)(0.f);
-    out[0][0] = half ? v[1] : v[0];
-    out[0][1] = half ? 0.f : v[2];
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int p = 2 + 3 * k + c;
-            const float arg = v[c] * (float)(1 << k);   // exact: power of two (dm_nerf.py:25,31)
-            float s, co;
-            sincosf(arg, &s, &co);
-            out[p >> 4][p & 15] = half ? co : s;
-        }
-    }
-}
-
-// Same registers filled from a pre-embedded row (DM_NeRF.forward called directly on [M,90]).
-template <int L, int NV>
-__device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16 (&out)[NV], int half) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) out[i] = (f32x16)(0.f);
-    out[0][0] = e[half];
-    out[0][1] = half ? 0.f : e[2];
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int p = 2 + 3 * k + c;
-            out[p >> 4][p & 15] = e[3 + 6 * k + 3 * half + c];
-        }
-    }
-}
-
-template <int OBI, bool EMBEDDED>
+template <int OBI, bool EMBEDDED, bool SAVE>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -175,12 +72,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         encode<DIR_L, 1>(vd, de, half);
     }
 
+    const SaveLayout SL = make_save_layout(a.M);
+    if constexpr (SAVE) {
+        store_encoded_rows<POS_L, 2>(a.save + SL.pe, a.M, m, half, valid, pe);
+        store_encoded_rows<DIR_L, 1>(a.save + SL.de, a.M, m, half, valid, de);
+    }
+
     f32x16 h[8], acc[8];
     // mlps.0 : 63 -> 256
     init_bias<8>(rs, (int)L.b0, acc, hoff);
     gemm_seg<8, 8, 2>(rs, (int)L.w0, pe, acc, voff);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+    if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h, 256, a.M, m, half, valid), h);
 
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
@@ -193,6 +97,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         if (st < 7) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h + (int64_t)(st + 1) * 256 * a.M, 256, a.M, m, half, valid), h);
             if (st == 6) {
                 // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
                 float part = 0.f;
@@ -209,12 +114,14 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         } else if (st == 7) {
             // acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.f, 256, a.M, m, half, valid), acc);
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_rgbh, hid, hoff);
             gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
             gemm_seg<4, 4, 1>(rs, (int)L.w_rgbh_dir, de, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
+            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, a.M, m, half, valid), hid);
             // rgb_linear (dm_nerf.py:102) on the VALU
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -232,11 +139,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         } else {
             // acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.q, 256, a.M, m, half, valid), acc);
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_insh, hid, hoff);
             gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
+            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, a.M, m, half, valid), hid);
             f32x16 io[OBI];
             init_bias<OBI>(rs, (int)L.b_inso, io, hoff);
             gemm_seg<16, OBI, 4>(rs, (int)L.w_inso, hid, io, voff);     // ins_linear (:103)
@@ -261,17 +170,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
 }
 
-template <bool EMBEDDED>
+template <bool EMBEDDED, bool SAVE>
 int launch(const MlpArgs& a, hipStream_t stream) {
     const int64_t nblk = (a.M + 31) / 32;
     const int64_t grid = (nblk + 3) / 4;
     if (grid > 0x7fffffffLL) return dmn_fail(DMNERF_E_ARG, "mlp_fwd: %lld samples is too many for one launch", (long long)a.M);
+    if (SAVE && a.M > DMNERF_MAX_TRAIN_SAMPLES)
+        return dmn_fail(DMNERF_E_ARG, "mlp_fwd_train: %lld samples per launch exceed %lld (32-bit row offsets); split the batch",
+                        (long long)a.M, (long long)DMNERF_MAX_TRAIN_SAMPLES);
     dim3 g((unsigned)grid), b(256);
     switch (a.L.OBI) {
-        case 1: hipLaunchKernelGGL((mlp_fwd_kernel<1, EMBEDDED>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((mlp_fwd_kernel<2, EMBEDDED>), g, b, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((mlp_fwd_kernel<3, EMBEDDED>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((mlp_fwd_kernel<4, EMBEDDED>), g, b, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((mlp_fwd_kernel<1, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((mlp_fwd_kernel<2, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((mlp_fwd_kernel<3, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((mlp_fwd_kernel<4, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
         default: return dmn_fail(DMNERF_E_ARG, "mlp_fwd: unsupported logit count C=%d", a.L.C);
     }
     return dmn_check_launch("mlp_fwd");
@@ -287,7 +199,7 @@ extern "C" int dmnerf_mlp_fwd_embedded(const float* d_blob, int ins_num, const f
     if (!d_blob || !d_x || !d_raw) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_embedded: null pointer");
     MlpArgs a{};
     a.blob = d_blob; a.L = make_layout(ins_num); a.x = d_x; a.raw = d_raw; a.M = M; a.S = 1;
-    return launch<true>(a, (hipStream_t)stream);
+    return launch<true, false>(a, (hipStream_t)stream);
 }
 
 extern "C" int dmnerf_mlp_fwd_rays(const float* d_blob, int ins_num, const float* d_rays_o,
@@ -300,5 +212,20 @@ extern "C" int dmnerf_mlp_fwd_rays(const float* d_blob, int ins_num, const float
     MlpArgs a{};
     a.blob = d_blob; a.L = make_layout(ins_num); a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z;
     a.raw = d_raw; a.M = N * S; a.S = S;
-    return launch<false>(a, (hipStream_t)stream);
+    return launch<false, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int64_t dmnerf_train_save_floats(int64_t M) { return M < 0 ? -1 : make_save_layout(M).total; }
+
+extern "C" int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_rays_o,
+                                         const float* d_rays_d, const float* d_z, int64_t N, int S,
+                                         float* d_raw, float* d_save, void* stream) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_train: ins_num %d unsupported", ins_num);
+    if (N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_train: bad N=%lld S=%d", (long long)N, S);
+    if (N == 0) return DMNERF_OK;
+    if (!d_blob || !d_rays_o || !d_rays_d || !d_z || !d_raw || !d_save) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_train: null pointer");
+    MlpArgs a{};
+    a.blob = d_blob; a.L = make_layout(ins_num); a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z;
+    a.raw = d_raw; a.save = d_save; a.M = N * S; a.S = S;
+    return launch<false, true>(a, (hipStream_t)stream);
 }

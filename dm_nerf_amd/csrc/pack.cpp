@@ -66,6 +66,18 @@ void fill_seg(int32_t* idx, int64_t off, const Lin& l, int nkg, int ob_n, KMap k
                 }
 }
 
+// transposed segment for the backward: rows = inputs of `l`, k = outputs of `l`
+void fill_seg_t(int32_t* idx, int64_t off, const Lin& l, int nkg, int ob_n) {
+    for (int g = 0; g < nkg; ++g)
+        for (int ob = 0; ob < ob_n; ++ob)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int out = cfeat(4 * g + kk, lane >> 5);
+                    const int in = ob * 32 + (lane & 31);
+                    idx[off + (((int64_t)g * ob_n + ob) * 64 + lane) * 4 + kk] = (int32_t)l.w(out, in);
+                }
+}
+
 void fill_bias(int32_t* idx, int64_t off, const Lin& l, int ob_n) {
     for (int ob = 0; ob < ob_n; ++ob)
         for (int half = 0; half < 2; ++half)
@@ -119,5 +131,27 @@ extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx)
             for (int p = 0; p < 64; ++p)
                 idx[L.w_rgbo + (c * 2 + half) * 64 + p] = (int32_t)P.rgb_out.w(c, cfeat(p, half));
     for (int c = 0; c < 3; ++c) idx[L.b_rgbo + c] = (int32_t)P.rgb_out.b(c);
+    return DMNERF_OK;
+}
+
+extern "C" int64_t dmnerf_blob_t_floats(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_layout_t(ins_num).total;
+}
+
+extern "C" int dmnerf_build_pack_index_t(int ins_num, int32_t* idx, int64_t n_idx) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS)
+        return dmn_fail(DMNERF_E_ARG, "build_pack_index_t: ins_num %d outside [1,%d]", ins_num, DMNERF_MAX_LOGITS - 1);
+    const BlobTLayout L = make_layout_t(ins_num);
+    if (!idx || n_idx != L.total)
+        return dmn_fail(DMNERF_E_ARG, "build_pack_index_t: need %lld index slots, got %lld", (long long)L.total, (long long)n_idx);
+    const Params P = make_params(ins_num);
+    for (int64_t i = 0; i < L.total; ++i) idx[i] = -1;
+    fill_seg_t(idx, L.t_inso, P.ins_out, 4 * L.OBI, 4);
+    fill_seg_t(idx, L.t_insh, P.ins_hidden, 16, 8);
+    fill_seg_t(idx, L.t_rgbh, P.rgb_hidden, 16, 8);          // rows 0..255 = the rgb_feature columns; dirs get no gradient
+    const Lin* stage[NSTAGE_T] = {&P.rgb_feature, &P.mlps[7], &P.mlps[6], &P.mlps[5], &P.mlps[4],
+                                  &P.mlps[3], &P.mlps[2], &P.mlps[1]};
+    for (int s = 0; s < NSTAGE_T; ++s) fill_seg_t(idx, L.t_stage + s * seg_floats(32, 8), *stage[s], 32, 8);
     return DMNERF_OK;
 }

@@ -59,6 +59,12 @@ __device__ __forceinline__ double wave_scan_mul_d(double v, int lane) {
     return v;
 }
 
+__device__ __forceinline__ void lds_sync_wave() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------
@@ -201,6 +207,110 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// backward of render_train (autograd of networks/render.py:6-28): one wave per ray.
+//   G_s   = dL/dw_s = sum_c g_rgb_c sigmoid(raw_sc) + g_depth z_s + g_w_s      (ins path uses detached weights, :22-23)
+//   dL/da_s = G_s T_s - (sum_{t>s} G_t w_t) / (1 - a_s + 1e-10)                 (cumprod backward)
+//   d raw_s3 = [raw_s3 > 0] dL/da_s dist_s exp(-relu(raw_s3) dist_s)
+//   d raw_sc = g_rgb_c w_s s(1-s), c < 3;   d raw_s(4+k) = g_ins_k m_k (1 - m_k) w_s, k < C-1;  0 for the dropped channel
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
+    const float* __restrict__ ins_map, const float* __restrict__ g_rgb, const float* __restrict__ g_ins,
+    const float* __restrict__ g_depth, const float* __restrict__ g_w, int64_t N, int S, int C, float* __restrict__ d_raw) {
+    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float t_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float g_lds[RAYS_PER_BLOCK][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (n >= N) return;
+    const int ch = 4 + C;
+    const float* __restrict__ rr = raw + n * (int64_t)S * ch;
+    const float* __restrict__ zr = z + n * (int64_t)S;
+    float* __restrict__ dr = d_raw + n * (int64_t)S * ch;
+    float* wl = w_lds[wv];
+    float* tl = t_lds[wv];
+    float* gl = g_lds[wv];
+    const float dx = rays_d[n * 3 + 0], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float gr0 = g_rgb[n * 3 + 0], gr1 = g_rgb[n * 3 + 1], gr2 = g_rgb[n * 3 + 2];
+    const float gd = g_depth ? g_depth[n] : 0.f;
+
+    // pass 1 (front to back): recompute alpha, T, w; G_s
+    double carry = 1.0;
+    for (int base = 0; base < S; base += WAVE) {
+        const int s = base + lane;
+        const bool ok = s < S;
+        float f = 1.f, alpha = 0.f, zc = 0.f;
+        if (ok) {
+            zc = zr[s];
+            float dist = (s == S - 1) ? 1e10f : zr[s + 1] - zc;
+            dist = dist * nrm;
+            const float sig = fmaxf(rr[(int64_t)s * ch + 3], 0.f);
+            alpha = 1.f - expf(-sig * dist);
+            f = (1.f - alpha) + 1e-10f;
+        }
+        const double incl = wave_scan_mul_d((double)f, lane);
+        double excl = shfl_up_d(incl, 1);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(carry * excl);
+        if (ok) {
+            const float* r3 = rr + (int64_t)s * ch;
+            float G = gr0 * sigmoidf_ref(r3[0]) + gr1 * sigmoidf_ref(r3[1]) + gr2 * sigmoidf_ref(r3[2]) + gd * zc;
+            if (g_w) G += g_w[n * (int64_t)S + s];
+            wl[s] = alpha * T;
+            tl[s] = T;
+            gl[s] = G;
+        }
+        carry = carry * shfl_d(incl, WAVE - 1);
+    }
+    lds_sync_wave();
+
+    // pass 2 (back to front): suffix sums of G_t w_t, then d raw[..., 3]
+    double after = 0.0;                                   // sum over all later chunks
+    const int nchunk = (S + WAVE - 1) / WAVE;
+    for (int cidx = nchunk - 1; cidx >= 0; --cidx) {
+        const int s = cidx * WAVE + lane;
+        const bool ok = s < S;
+        const double P = ok ? (double)(gl[s] * wl[s]) : 0.0;
+        const double incl = wave_scan_add_d(P, lane);
+        const double total = shfl_d(incl, WAVE - 1);
+        const double R = (total - incl) + after;          // sum_{t > s} G_t w_t
+        if (ok) {
+            const float zc = zr[s];
+            float dist = (s == S - 1) ? 1e10f : zr[s + 1] - zc;
+            dist = dist * nrm;
+            const float rawsig = rr[(int64_t)s * ch + 3];
+            const float sig = fmaxf(rawsig, 0.f);
+            const float e = expf(-sig * dist);            // = 1 - alpha
+            const float f = ((1.f - (1.f - e))) + 1e-10f; // the forward's (1 - alpha) + 1e-10, bit for bit
+            const float dLda = gl[s] * tl[s] - (float)R / f;
+            dr[(int64_t)s * ch + 3] = rawsig > 0.f ? dLda * (dist * e) : 0.f;
+        }
+        after += total;
+    }
+
+    // pass 3: channel gradients, lane <-> channel
+    for (int c = lane; c < ch; c += WAVE) {
+        if (c == 3) continue;
+        if (c < 3) {
+            const float g = c == 0 ? gr0 : (c == 1 ? gr1 : gr2);
+            for (int s = 0; s < S; ++s) {
+                const float sg = sigmoidf_ref(rr[(int64_t)s * ch + c]);
+                dr[(int64_t)s * ch + c] = (g * wl[s]) * ((1.f - sg) * sg);
+            }
+        } else {
+            const int k = c - 4;
+            float coef = 0.f;
+            if (k < C - 1) {
+                const float mk = ins_map[n * (int64_t)(C - 1) + k];
+                coef = g_ins[n * (int64_t)(C - 1) + k] * ((1.f - mk) * mk);
+            }
+            for (int s = 0; s < S; ++s) dr[(int64_t)s * ch + c] = coef * wl[s];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // sample_pdf (helpers.py:123-155) [+ z_mid / sort-merge of render.py:66-70]: one wave per ray
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_NB = 512;      // bins per ray
@@ -244,12 +354,6 @@ __device__ __forceinline__ void build_cdf(const float* __restrict__ w_in, int nw
         if (j < nw) cdf[j + 1] = (float)(carry + incl);          // ATen CPU cumsum: double accumulate, round per element
         carry += shfl_d(incl, WAVE - 1);
     }
-}
-
-__device__ __forceinline__ void lds_sync_wave() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct SampleArgs {
@@ -430,4 +534,16 @@ extern "C" int dmnerf_importance_resample(const float* d_z_coarse, const float* 
     a.nb = S - 1; a.n_samples = n_imp; a.S = S; a.samples = d_z_samples; a.z_fine = d_z_fine;
     hipLaunchKernelGGL(sample_kernel<2>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, a);
     return dmn_check_launch("importance_resample");
+}
+
+extern "C" int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const float* d_rays_d, const float* d_ins_map,
+                                    const float* d_g_rgb, const float* d_g_ins, const float* d_g_depth,
+                                    const float* d_g_weights, int64_t N, int S, int C, float* d_grad_raw, void* stream) {
+    if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "composite_bwd: bad N=%lld S=%d (max %d) C=%d", (long long)N, S, MAX_S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_rays_d || !d_ins_map || !d_g_rgb || !d_g_ins || !d_grad_raw)
+        return dmn_fail(DMNERF_E_ARG, "composite_bwd: null pointer");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+                       d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw);
+    return dmn_check_launch("composite_bwd");
 }

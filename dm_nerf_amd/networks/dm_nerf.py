@@ -78,6 +78,8 @@ class DM_NeRF(nn.Module):
         self.rgb_linear = nn.Linear(W // 2, 3)
         self._blob = None
         self._blob_key = None
+        self._blob_t = None
+        self._blob_t_key = None
 
     # -- kernel-layout weights --------------------------------------------------------------
     def _check_supported(self):
@@ -97,6 +99,16 @@ class DM_NeRF(nn.Module):
                                            and self._blob.device == next(iter(state.values())).device else None)
             self._blob_key = key
         return self._blob
+
+    def blob_t(self):
+        """W^T blob for the backward data-gradient kernel (same refresh rule as ``blob``)."""
+        self._check_supported()
+        state = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in state.values())
+        if self._blob_t is None or key != self._blob_t_key:
+            self._blob_t = weights.pack_blob(state, self.ins_num, transposed=True)
+            self._blob_t_key = key
+        return self._blob_t
 
     def forward(self, x):
         """``[M, 63+27] -> [M, 4 + ins_num + 1]`` = cat[rgb, density, ins] (networks/dm_nerf.py:80-106)."""

@@ -26,10 +26,22 @@ def pack_index_host(ins_num):
     return idx
 
 
-def pack_index(ins_num, device):
-    key = (ins_num, str(device))
+def pack_index_t_host(ins_num):
+    """Gather index of the backward (W^T) blob."""
+    lib = _lib.load()
+    n = lib.dmnerf_blob_t_floats(ins_num)
+    if n <= 0:
+        raise ValueError(f"unsupported ins_num={ins_num}")
+    idx = np.empty(n, dtype=np.int32)
+    _lib.check(lib.dmnerf_build_pack_index_t(ins_num, idx.ctypes.data_as(ctypes.c_void_p), n), "dmnerf_build_pack_index_t")
+    return idx
+
+
+def pack_index(ins_num, device, transposed=False):
+    key = (ins_num, str(device), transposed)
     if key not in _index_cache:
-        _index_cache[key] = torch.from_numpy(pack_index_host(ins_num)).to(device)
+        host = pack_index_t_host(ins_num) if transposed else pack_index_host(ins_num)
+        _index_cache[key] = torch.from_numpy(host).to(device)
     return _index_cache[key]
 
 
@@ -38,15 +50,16 @@ def flat_params(state):
     return torch.cat([state[k].detach().reshape(-1).float() for k in PARAM_KEYS])
 
 
-def pack_blob(state, ins_num, out=None):
-    """Build (or refresh in place) the kernel blob for one DM_NeRF model."""
+def pack_blob(state, ins_num, out=None, transposed=False):
+    """Build (or refresh in place) the kernel blob for one DM_NeRF model (``transposed``: the W^T
+    blob of the backward data-gradient kernel)."""
     lib = _lib.load()
     flat = flat_params(state)
     if flat.numel() != lib.dmnerf_param_count(ins_num):
         raise ValueError(f"parameter count {flat.numel()} != {lib.dmnerf_param_count(ins_num)} "
                          f"(only D=8, W=256, skips=[4], 63+27 input channels are supported)")
     _lib.require_gpu(flat)
-    idx = pack_index(ins_num, flat.device)
+    idx = pack_index(ins_num, flat.device, transposed)
     n = idx.numel()
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=flat.device)

@@ -38,6 +38,7 @@ extern "C" {
 #define DMNERF_W 256       /* netwidth  (config.py:33 default; every shipped config) */
 #define DMNERF_D 8         /* netdepth  (config.py:31 default), skips=[4] (config.py:133) */
 #define DMNERF_MAX_LOGITS 128 /* C = ins_num+1 <= 128 (Replica room_0: 94) */
+#define DMNERF_MAX_TRAIN_SAMPLES 2097151LL /* samples per training launch: 256 rows x M x 4 B < 2^31 */
 
 int dmnerf_abi_version(void);
 const char* dmnerf_last_error(void);
@@ -115,6 +116,33 @@ int dmnerf_mlp_fwd_rays(const float* d_blob, int ins_num, const float* d_rays_o,
 int dmnerf_composite_fwd(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N,
                          int S, int C, float* d_rgb_map, float* d_weights, float* d_depth_map,
                          float* d_ins_map, void* stream);
+
+/* ---- training (autograd of the two entry points above) ------------------------------------
+ * Backward of render_train: given dL/d{rgb_map [N,3], ins_map [N,C-1], depth_map [N] (nullable),
+ * weights [N,S] (nullable)} -> dL/draw [N,S,4+C] (every element written).  d_ins_map = the forward's
+ * ins_map.  Honours weights.detach() on the ins path (render.py:22-23).                        */
+int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const float* d_rays_d,
+                         const float* d_ins_map, const float* d_g_rgb, const float* d_g_ins,
+                         const float* d_g_depth, const float* d_g_weights, int64_t N, int S, int C,
+                         float* d_grad_raw, void* stream);
+
+/* Training forward of dmnerf_mlp_fwd_rays: additionally saves every layer input / relu output
+ * feature-major ([rows][M], M = N*S) into d_save (dmnerf_train_save_floats(M) floats):
+ *   embed(pts) [63][M] | embed(dirs) [27][M] | h_0..h_7 [8][256][M] | rgb_feature [256][M] |
+ *   ins_feature [256][M] | rgb hidden [128][M] | ins hidden [128][M].   M <= DMNERF_MAX_TRAIN_SAMPLES. */
+int64_t dmnerf_train_save_floats(int64_t M);
+int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_rays_o,
+                              const float* d_rays_d, const float* d_z, int64_t N, int S,
+                              float* d_raw, float* d_save, void* stream);
+
+/* Backward blob (W^T as MFMA A operand) and the data-gradient pass: dL/draw [M,4+C] + d_save ->
+ * d_dsave (same layout as d_save): dy of mlps.0..7 in the h rows, d rgb_feature, d ins_feature,
+ * d(rgb hidden pre-act), d(ins hidden pre-act).  Weight gradients are dW = dy . x^T over M.
+ * Gradient barriers: h.detach() on the ins branch (dm_nerf.py:95); none to the encodings.     */
+int64_t dmnerf_blob_t_floats(int ins_num);
+int dmnerf_build_pack_index_t(int ins_num, int32_t* h_idx, int64_t n_idx);
+int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num, const float* d_save,
+                        const float* d_graw, int64_t M, float* d_dsave, void* stream);
 
 /* dm_nerf inference (networks/render.py:31-96, perturb handled by the caller passing t_rand/u):
  * all stages on `stream`, outputs = the 10 tensors of the reference dict (ins_* are [N, C-1]).

@@ -225,12 +225,14 @@ def render_train(raw, z_vals, rays_d):
 
 
 def dm_nerf(rays, sd_coarse, sd_fine, z_vals_coarse, perturb=0., N_importance=128,
-            is_train=False, N_ins=None, t_rand=None, u=None, multires=10, multires_views=4):
+            is_train=False, N_ins=None, t_rand=None, u=None, multires=10, multires_views=4,
+            z_fine_override=None):
     """``dm_nerf`` (networks/render.py:31-96) with weights as state_dicts.
 
     RNG: when ``perturb > 0`` the reference draws ``torch.rand([N,64])`` (:46) then
     ``torch.rand([N,N_importance])`` (helpers.py:135); pass ``t_rand`` / ``u`` to pin them,
-    otherwise they are drawn here in that order.
+    otherwise they are drawn here in that order.  ``z_fine_override`` (tests only) replaces the
+    resampled depths, to compare fine-level quantities without the ill-conditioned inverse-CDF step.
     """
     rays_o, rays_d = rays
     viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
@@ -255,6 +257,8 @@ def dm_nerf(rays, sd_coarse, sd_fine, z_vals_coarse, perturb=0., N_importance=12
     z_samples = sample_pdf(z_vals_mid, weights_coarse[..., 1:-1], N_importance, det=(perturb == 0.), u=u)
     z_samples = z_samples.detach()
     z_vals_fine, _ = torch.sort(torch.cat([z_vals_coarse, z_samples], -1), -1)
+    if z_fine_override is not None:
+        z_vals_fine = z_fine_override
     raw_fine = run(sd_fine, z_vals_fine)
     rgb_fine, weights_fine, depth_fine, ins_fine = render_train(raw_fine, z_vals_fine, rays_d)
     if is_train and N_ins is not None:
