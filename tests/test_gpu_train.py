@@ -178,7 +178,7 @@ def test_adam_steps_follow_the_oracle_trajectory(A):
     tgt_ins = torch.rand(N, ins_num, generator=g)
 
     def loss_fn(out, tc, ti):
-        return ((out['rgb_fine'] - tc) ** 2).mean() + ((out['rgb_coarse'] - tc) ** 2).mean() \\
+        return ((out['rgb_fine'] - tc) ** 2).mean() + ((out['rgb_coarse'] - tc) ** 2).mean() \
             + ((out['ins_fine'] - ti) ** 2).mean() + ((out['ins_coarse'] - ti) ** 2).mean()
 
     mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
