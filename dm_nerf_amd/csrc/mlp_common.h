@@ -126,6 +126,10 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16
 // A wave's accumulator block b, register r holds feature 32b + crow(r, half) of sample m: for a
 // fixed (b, r) lanes 0-31 are 32 consecutive samples of one row and lanes 32-63 of the row 4 below,
 // i.e. two fully coalesced 128-byte segments per instruction, with no transpose.
+// NOTE: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0
+// (hipcc 7.2): always go through a scalar copy.
+__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
+
 struct RowIO {
     rsrc_t rs;
     int voff;        // ((4*half)*M + m) * 4 bytes
@@ -166,7 +170,7 @@ __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[b][r]), io.rs, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, vo, 0, 0);
             vo += ((r & 3) == 3) ? step5 : step1;
         }
     }
@@ -196,8 +200,8 @@ __device__ __forceinline__ void store_encoded_rows(const float* base, int64_t M,
     const unsigned rowb = (unsigned)(M * 4);
     const int v1 = (int)(((int64_t)half * M + m) * 4);        // rows 0/1 (x, y)
     const int v3 = (int)((3 * (int64_t)half * M + m) * 4);    // sin row + 3 = cos row
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[0][0]), rs, v1, 0, 0);
-    if (half == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[0][1]), rs, v1 + (int)(2 * rowb), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(f2u(e[0][0]), rs, v1, 0, 0);
+    if (half == 0) __builtin_amdgcn_raw_buffer_store_b32(f2u(e[0][1]), rs, v1 + (int)(2 * rowb), 0, 0);
     int vo = v3 + (int)(3 * rowb);                            // row 3 + 6k + c (+3 for the cos half)
     asm volatile("" : "+v"(vo));
 #pragma unroll
@@ -205,7 +209,7 @@ __device__ __forceinline__ void store_encoded_rows(const float* base, int64_t M,
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int p = 2 + 3 * k + c;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[p >> 4][p & 15]), rs, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(e[p >> 4][p & 15]), rs, vo, 0, 0);
             vo += (c == 2) ? (int)(4 * rowb) : (int)rowb;
         }
     }

@@ -152,10 +152,16 @@ def test_dm_nerf_training_grads_vs_oracle(A):
     _loss_from(want, cts).backward()
     for k in ('rgb_fine', 'rgb_coarse', 'ins_fine', 'ins_coarse', 'depth_fine', 'raw_coarse'):
         tclose(out[k], want[k], k, rel=2e-5)
-    for k, p in mc.named_parameters():
-        tclose(p.grad, sdc[k].grad, f"coarse grad {k}")
-    for k, p in mf.named_parameters():
-        tclose(p.grad, sdf[k].grad, f"fine grad {k}")
+    # 3072 + 9216 samples x 2048 relu units: a handful of units sit within float noise of zero and flip
+    # their mask between the two f32 implementations (scripts/diag_e2e.py: HIP and the f32 oracle are
+    # equally far, ~1e-2, from an f64 run for that reason), so whole-tensor norms are compared here; the
+    # strict per-element check is test_mlp_backward_vs_autograd / test_composite_backward_vs_autograd.
+    for m_, sd_, tag in ((mc, sdc, "coarse"), (mf, sdf, "fine")):
+        for k, p in m_.named_parameters():
+            got, want = p.grad.cpu().double(), sd_[k].grad.double()
+            rel_l2 = float((got - want).norm() / (want.norm() + 1e-30))
+            rel_max = float((got - want).abs().max() / (want.abs().max() + 1e-30))
+            assert rel_l2 <= 2e-3 and rel_max <= 1e-2, (tag, k, rel_l2, rel_max)
     # the fine-level loss gives the coarse model nothing beyond its own terms: zero the coarse cotangents
     mc.zero_grad(); mf.zero_grad()
     out = A.R.dm_nerf(rays.cuda(), None, None, mc, mf, z.cuda(), args, t_rand=t_rand.cuda(), u=u.cuda())
@@ -192,10 +198,10 @@ def test_adam_steps_follow_the_oracle_trajectory(A):
         out = A.R.dm_nerf(rays.cuda(), None, None, mc, mf, z.cuda(), args)
         loss = loss_fn(out, target.cuda(), tgt_ins.cuda())
         opt.zero_grad(); loss.backward(); opt.step()
-        got.append(float(loss))
+        got.append(float(loss.detach()))
         o = O.dm_nerf(rays, sdc, sdf, z, perturb=0.)
         lo = loss_fn(o, target, tgt_ins)
         opt_o.zero_grad(); lo.backward(); opt_o.step()
-        want.append(float(lo))
+        want.append(float(lo.detach()))
     assert np.allclose(got, want, rtol=2e-3), (got, want)
     assert got[2] < got[0]
