@@ -76,8 +76,9 @@ class MLPRaysFunction(torch.autograd.Function):
         grads["rgb_feature_linears.0.weight"] = torch.cat([d["g1"] @ x["f"].t(), d["g1"] @ x["de"].t()], 1)
         grads["rgb_feature_linears.0.bias"] = d["g1"].sum(1)
         grads["ins_feature_linears.0.weight"], grads["ins_feature_linears.0.bias"] = d["g2"] @ x["q"].t(), d["g2"].sum(1)
-        gt = g.t()                                                  # [4+C, M]
-        grads["density_linear.weight"], grads["density_linear.bias"] = gt[3:4] @ h7.t(), gt[3:4].sum(1)
+        gt = g.t().contiguous()                                     # [4+C, M] feature-major like everything else
+        # 1 x M times M x 256 is a matrix-vector product (rocBLAS' skinny-GEMM path took 5 ms for it)
+        grads["density_linear.weight"], grads["density_linear.bias"] = (h7 @ gt[3]).unsqueeze(0), gt[3:4].sum(1)
         grads["ins_linear.weight"], grads["ins_linear.bias"] = gt[4:] @ x["g2"].t(), gt[4:].sum(1)
         grads["rgb_linear.weight"], grads["rgb_linear.bias"] = gt[:3] @ x["g1"].t(), gt[:3].sum(1)
         ctx.save = None
