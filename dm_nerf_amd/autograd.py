@@ -20,8 +20,15 @@ W = 256
 HW = 128
 
 
+def _row_len(M):
+    """Rows of the training workspace are padded to a multiple of 32 samples (csrc/layout.h::save_row_len)."""
+    return (M + 31) & ~31
+
+
 def _views(buf, M):
-    """Named [rows, M] views of a SaveLayout workspace (csrc/layout.h)."""
+    """Named [rows, row_len] views of a SaveLayout workspace (csrc/layout.h).  Padding columns hold
+    duplicates of the last sample in the activations and exact zeros in the gradients."""
+    M = _row_len(M)
     o = 0
     out = {}
     for name, rows in (("pe", 63), ("de", 27), ("h", 8 * W), ("f", W), ("q", W), ("g1", HW), ("g2", HW)):
@@ -77,6 +84,8 @@ class MLPRaysFunction(torch.autograd.Function):
         grads["rgb_feature_linears.0.bias"] = d["g1"].sum(1)
         grads["ins_feature_linears.0.weight"], grads["ins_feature_linears.0.bias"] = d["g2"] @ x["q"].t(), d["g2"].sum(1)
         gt = g.t().contiguous()                                     # [4+C, M] feature-major like everything else
+        if _row_len(M) != M:                                        # zero columns for the row padding
+            gt = torch.nn.functional.pad(gt, (0, _row_len(M) - M))
         # 1 x M times M x 256 is a matrix-vector product (rocBLAS' skinny-GEMM path took 5 ms for it)
         grads["density_linear.weight"], grads["density_linear.bias"] = (h7 @ gt[3]).unsqueeze(0), gt[3:4].sum(1)
         grads["ins_linear.weight"], grads["ins_linear.bias"] = gt[4:] @ x["g2"].t(), gt[4:].sum(1)

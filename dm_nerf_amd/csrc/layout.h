@@ -122,8 +122,13 @@ struct SaveLayout {
     int64_t g1, g2;      // relu outputs of rgb_feature_linears.0 / ins_feature_linears.0: [128][M] each
     int64_t total;
 };
-DMN_HD inline SaveLayout make_save_layout(int64_t M) {
+// Row length: M rounded up to a multiple of 32 so that a wave's 32-sample block never straddles
+// the end of a row (tail lanes store into / read from the padding columns).
+DMN_HD constexpr int64_t save_row_len(int64_t M) { return (M + 31) & ~(int64_t)31; }
+
+DMN_HD inline SaveLayout make_save_layout(int64_t M_samples) {
     SaveLayout s;
+    const int64_t M = save_row_len(M_samples);
     int64_t o = 0;
     s.pe = o; o += POS_CH * M;
     s.de = o; o += DIR_CH * M;

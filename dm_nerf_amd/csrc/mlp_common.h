@@ -28,11 +28,22 @@ __device__ __forceinline__ f32x4 ldw(rsrc_t r, int voff, int soff_bytes) {
     return __builtin_bit_cast(f32x4, v);
 }
 
+// NOTE: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0
+// (hipcc 7.2): always go through a scalar copy.
+__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
+
+struct RowIO {
+    rsrc_t rs;
+    int voff;        // ((4*half)*M + m) * 4 bytes
+    unsigned rowb;   // M * 4: bytes per row
+    bool valid;
+};
+
 // acc[ob] += Wseg[ob-block rows, k] * B[k, samples] for NKG*4 k-pairs.  B lives in registers in
 // accumulator layout: k-pair p is B[p >> 4][p & 15].  `seg` = float offset of the segment.
-template <int NKG, int OB, int NB>
+template <int NKG, int OB, int NB, bool STORE_B = false>
 __device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[NB],
-                                         f32x16 (&acc)[OB], int voff) {
+                                         f32x16 (&acc)[OB], int voff, const RowIO* sio = nullptr) {
     static_assert(NB * 16 >= NKG * 4, "B operand too small");
     // The segment is streamed front to back; its position lives in ONE scalar register that is
     // bumped every 4 KiB (imm offsets cover 0..3 KiB).  The empty asm makes the running value
@@ -40,6 +51,18 @@ __device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[N
     // spills hundreds of SGPRs (seen as v_writelane/v_readlane storms and scratch traffic).
     int so = seg * 4;
     asm volatile("" : "+s"(so));
+    // STORE_B (training): the B operand (this GEMM's input activations, in accumulator layout) is
+    // written feature-major to HBM *while it is being consumed*: 4 dword stores per k-group, i.e.
+    // one store per 8 MFMAs, instead of a 128-store burst at the layer boundary whose
+    // acknowledgements the next weight loads would have to wait behind (vmcnt is in-order).
+    // Stores are unconditional (no exec-mask branches inside the MFMA stream): rows are padded to a
+    // multiple of 32 samples so tail lanes write padding, and a descriptor with num_records = 0
+    // turns a whole call into no-ops through the hardware bounds check.
+    int svo = 0, step1 = 0, step5 = 0;
+    if constexpr (STORE_B) {
+        svo = sio->voff; step1 = (int)sio->rowb; step5 = (int)(5 * sio->rowb);
+        asm volatile("" : "+v"(svo));
+    }
 #pragma unroll
     for (int g = 0; g < NKG; ++g) {
         f32x4 a[OB];
@@ -51,9 +74,13 @@ __device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[N
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+            const int p = g * 4 + kk;
+            if constexpr (STORE_B) {
+                __builtin_amdgcn_raw_buffer_store_b32(f2u(B[p >> 4][p & 15]), sio->rs, svo, 0, 0);
+                svo += ((p & 3) == 3) ? step5 : step1;
+            }
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
-                const int p = g * 4 + kk;
                 acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
             }
         }
@@ -126,17 +153,6 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16
 // A wave's accumulator block b, register r holds feature 32b + crow(r, half) of sample m: for a
 // fixed (b, r) lanes 0-31 are 32 consecutive samples of one row and lanes 32-63 of the row 4 below,
 // i.e. two fully coalesced 128-byte segments per instruction, with no transpose.
-// NOTE: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0
-// (hipcc 7.2): always go through a scalar copy.
-__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
-
-struct RowIO {
-    rsrc_t rs;
-    int voff;        // ((4*half)*M + m) * 4 bytes
-    unsigned rowb;   // M * 4: bytes per row
-    bool valid;
-};
-
 // Descriptor from provably wave-uniform inputs: without the readfirstlane the compiler keeps the
 // (uniform) pointer in VGPRs under SGPR pressure and wraps every access in a waterfall loop.
 __device__ __forceinline__ rsrc_t uniform_rsrc(const float* base, int64_t n_floats) {
@@ -162,7 +178,6 @@ __device__ __forceinline__ RowIO make_rowio(const float* base, int rows, int64_t
 // (hoisted row*M products spilled SGPRs -> scratch in the first version).
 template <int NB>
 __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB]) {
-    if (!io.valid) return;
     int vo = io.voff;
     asm volatile("" : "+v"(vo));     // opaque per call: identical offset chains of different calls must not be CSE'd into ~128 live VGPRs
     const int step1 = (int)io.rowb, step5 = (int)(5 * io.rowb);
@@ -195,7 +210,7 @@ __device__ __forceinline__ void load_rows(const RowIO& io, f32x16 (&v)[NB]) {
 template <int L, int NV>
 __device__ __forceinline__ void store_encoded_rows(const float* base, int64_t M, int64_t m, int half, bool valid,
                                                    const f32x16 (&e)[NV]) {
-    if (!valid) return;
+    (void)valid;                                               // rows are padded: tail lanes write padding
     rsrc_t rs = uniform_rsrc(base, (int64_t)(3 + 6 * L) * M);
     const unsigned rowb = (unsigned)(M * 4);
     const int v1 = (int)(((int64_t)half * M + m) * 4);        // rows 0/1 (x, y)

@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
 
     const SaveLayout SL = make_save_layout(a.M);
+    const int64_t MP = save_row_len(a.M);          // padded row length of the training workspace
+    const int64_t ms = m_raw;                      // column this lane writes (tail lanes -> padding)
     if constexpr (SAVE) {
-        store_encoded_rows<POS_L, 2>(a.save + SL.pe, a.M, m, half, valid, pe);
-        store_encoded_rows<DIR_L, 1>(a.save + SL.de, a.M, m, half, valid, de);
+        store_encoded_rows<POS_L, 2>(a.save + SL.pe, MP, ms, half, valid, pe);
+        store_encoded_rows<DIR_L, 1>(a.save + SL.de, MP, ms, half, valid, de);
     }
 
     f32x16 h[8], acc[8];
@@ -84,7 +86,6 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     gemm_seg<8, 8, 2>(rs, (int)L.w0, pe, acc, voff);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
-    if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h, 256, a.M, m, half, valid), h);
 
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
@@ -92,12 +93,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma nounroll
     for (int st = 0; st < NSTAGE; ++st) {
         init_bias<8>(rs, (int)L.b_stage + st * (int)bias_floats(8), acc, hoff);
-        gemm_seg<32, 8, 8>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff);
+        if constexpr (SAVE) {
+            // stage st consumes h_st (st = 0..7; st = 8 re-reads h_7): save it while it is the B operand
+            // (st = 8 consumes h_7 a second time: an empty descriptor makes its stores bounds-checked no-ops)
+            const int sl = st < 8 ? st : 7;
+            const RowIO sio = make_rowio(a.save + SL.h + (int64_t)sl * 256 * MP, st < 8 ? 256 : 0, MP, ms, half, valid);
+            gemm_seg<32, 8, 8, true>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff, &sio);
+        } else {
+            gemm_seg<32, 8, 8>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff);
+        }
         if (st == 4) gemm_seg<8, 8, 2>(rs, (int)L.w5pe, pe, acc, voff);   // skip: cat[h, pts] (dm_nerf.py:87)
         if (st < 7) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h + (int64_t)(st + 1) * 256 * a.M, 256, a.M, m, half, valid), h);
             if (st == 6) {
                 // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
                 float part = 0.f;
@@ -114,14 +122,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         } else if (st == 7) {
             // acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.f, 256, a.M, m, half, valid), acc);
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_rgbh, hid, hoff);
-            gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
+            if constexpr (SAVE) {
+                const RowIO sio = make_rowio(a.save + SL.f, 256, MP, ms, half, valid);
+                gemm_seg<32, 4, 8, true>(rs, (int)L.w_rgbh, acc, hid, voff, &sio);
+            } else {
+                gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
+            }
             gemm_seg<4, 4, 1>(rs, (int)L.w_rgbh_dir, de, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, a.M, m, half, valid), hid);
+            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, MP, ms, half, valid), hid);
             // rgb_linear (dm_nerf.py:102) on the VALU
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -139,13 +151,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         } else {
             // acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.q, 256, a.M, m, half, valid), acc);
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_insh, hid, hoff);
-            gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
+            if constexpr (SAVE) {
+                const RowIO sio = make_rowio(a.save + SL.q, 256, MP, ms, half, valid);
+                gemm_seg<32, 4, 8, true>(rs, (int)L.w_insh, acc, hid, voff, &sio);
+            } else {
+                gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, a.M, m, half, valid), hid);
+            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, MP, ms, half, valid), hid);
             f32x16 io[OBI];
             init_bias<OBI>(rs, (int)L.b_inso, io, hoff);
             gemm_seg<16, OBI, 4>(rs, (int)L.w_inso, hid, io, voff);     // ins_linear (:103)
