@@ -7,9 +7,9 @@ Gradient barriers of the reference are reproduced structurally:
   * ``h.detach()`` on the ins branch (dm_nerf.py:95) -- mlp_bwd_data does not add d(ins_feature) to dh_7;
   * ``z_samples.detach()`` (render.py:68) -- the resampled depths are computed outside autograd.
 
-Weight gradients dW = dy . x^T (a plain GEMM over the M samples of the batch, both operands
-stored feature-major by the kernels) currently go through torch.mm (rocBLAS f32) -- see
-DESIGN.md section 6; bias gradients are row sums of dy.
+Weight gradients dW = dy . x^T (GEMMs over the M samples of the batch, both operands stored
+feature-major by the kernels) and the bias row sums run in the split-K f32-MFMA kernel of
+csrc/wgrad.hip (dmnerf_mlp_bwd_weights); no vendor BLAS is involved.
 """
 import torch
 
@@ -35,6 +35,40 @@ def _views(buf, M):
         out[name] = buf[o:o + rows * M].view(rows, M)
         o += rows * M
     out["h"] = out["h"].view(8, W, M)
+    return out
+
+
+_plan_cache = {}
+
+
+def wgrad_plan(ins_num, M, device, max_wgs=None):
+    """Device-resident split-K plan of the weight-gradient kernel for (ins_num, M): (jobs, n_jobs, outs, n_outs, part_floats)."""
+    import ctypes
+
+    import numpy as np
+    if max_wgs is None:
+        max_wgs = torch.cuda.get_device_properties(device).multi_processor_count     # one workgroup per CU
+    key = (ins_num, M, str(device), max_wgs)
+    if key not in _plan_cache:
+        lib = _lib.load()
+        jb, ob, pf = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        nj, no = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.dmnerf_wgrad_plan_sizes(ins_num, M, max_wgs, ctypes.byref(jb), ctypes.byref(ob), ctypes.byref(pf),
+                                               ctypes.byref(nj), ctypes.byref(no)), "dmnerf_wgrad_plan_sizes")
+        hj, ho = np.empty(jb.value, dtype=np.uint8), np.empty(ob.value, dtype=np.uint8)
+        _lib.check(lib.dmnerf_wgrad_plan(ins_num, M, max_wgs, hj.ctypes.data_as(ctypes.c_void_p), jb.value,
+                                         ho.ctypes.data_as(ctypes.c_void_p), ob.value), "dmnerf_wgrad_plan")
+        _plan_cache[key] = (torch.from_numpy(hj).to(device), nj.value, torch.from_numpy(ho).to(device), no.value, pf.value)
+    return _plan_cache[key]
+
+
+def split_flat_grads(model, flat):
+    """Views of the flat gradient vector (reference parameter order) as the model's parameter tensors."""
+    out, o = [], 0
+    for _, p in model.named_parameters():
+        n = p.numel()
+        out.append(flat[o:o + n].view_as(p))
+        o += n
     return out
 
 
@@ -65,34 +99,18 @@ class MLPRaysFunction(torch.autograd.Function):
         dsave = torch.empty_like(ctx.save)
         _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                            _lib.ptr(dsave), _lib.stream()), "dmnerf_mlp_bwd_data")
-        x, d = _views(ctx.save, M), _views(dsave, M)
-        grads = {}
-        # trunk: dW_l = dy_l . x_l^T, x_0 = embed(pts), x_l = h_{l-1}, x_5 = [h_4, embed(pts)]
-        for l in range(8):
-            dy = d["h"][l]
-            if l == 0:
-                gw = dy @ x["pe"].t()
-            elif l == 5:
-                gw = torch.cat([dy @ x["h"][4].t(), dy @ x["pe"].t()], 1)
-            else:
-                gw = dy @ x["h"][l - 1].t()
-            grads[f"mlps.{l}.weight"], grads[f"mlps.{l}.bias"] = gw, dy.sum(1)
-        h7 = x["h"][7]
-        grads["rgb_feature_linear.weight"], grads["rgb_feature_linear.bias"] = d["f"] @ h7.t(), d["f"].sum(1)
-        grads["ins_feature_linear.weight"], grads["ins_feature_linear.bias"] = d["q"] @ h7.t(), d["q"].sum(1)
-        grads["rgb_feature_linears.0.weight"] = torch.cat([d["g1"] @ x["f"].t(), d["g1"] @ x["de"].t()], 1)
-        grads["rgb_feature_linears.0.bias"] = d["g1"].sum(1)
-        grads["ins_feature_linears.0.weight"], grads["ins_feature_linears.0.bias"] = d["g2"] @ x["q"].t(), d["g2"].sum(1)
-        gt = g.t().contiguous()                                     # [4+C, M] feature-major like everything else
-        if _row_len(M) != M:                                        # zero columns for the row padding
-            gt = torch.nn.functional.pad(gt, (0, _row_len(M) - M))
-        # 1 x M times M x 256 is a matrix-vector product (rocBLAS' skinny-GEMM path took 5 ms for it)
-        grads["density_linear.weight"], grads["density_linear.bias"] = (h7 @ gt[3]).unsqueeze(0), gt[3:4].sum(1)
-        grads["ins_linear.weight"], grads["ins_linear.bias"] = gt[4:] @ x["g2"].t(), gt[4:].sum(1)
-        grads["rgb_linear.weight"], grads["rgb_linear.bias"] = gt[:3] @ x["g1"].t(), gt[:3].sum(1)
+        # dL/draw transposed to feature-major rows, zero padded to the row length of the workspace
+        Mp = _row_len(M)
+        gt = torch.zeros(4 + C, Mp, dtype=torch.float32, device=g.device)
+        gt[:, :M] = g.t()
+        jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
+        part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
+        flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)
+        _lib.check(lib.dmnerf_mlp_bwd_weights(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs,
+                                              _lib.ptr(outs), n_outs, _lib.ptr(part), _lib.ptr(flat), _lib.stream()),
+                   "dmnerf_mlp_bwd_weights")
         ctx.save = None
-        names = [n for n, _ in model.named_parameters()]
-        return (None, None, None, None) + tuple(grads[n] for n in names)
+        return (None, None, None, None) + tuple(split_flat_grads(model, flat))
 
 
 class CompositeFunction(torch.autograd.Function):

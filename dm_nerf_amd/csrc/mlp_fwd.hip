@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     gemm_seg<8, 8, 2>(rs, (int)L.w0, pe, acc, voff);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+    // Activation saves are issued as one burst per layer.  (Interleaving them into the next layer's
+    // MFMA stream was measured SLOWER, 14.3 vs 12.2 ms: vmcnt retires in order, so every later
+    // weight-load wait then also waits for a store acknowledgement.)
+    if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h, 256, MP, ms, half, valid), h);
 
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
@@ -93,19 +97,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma nounroll
     for (int st = 0; st < NSTAGE; ++st) {
         init_bias<8>(rs, (int)L.b_stage + st * (int)bias_floats(8), acc, hoff);
-        if constexpr (SAVE) {
-            // stage st consumes h_st (st = 0..7; st = 8 re-reads h_7): save it while it is the B operand
-            // (st = 8 consumes h_7 a second time: an empty descriptor makes its stores bounds-checked no-ops)
-            const int sl = st < 8 ? st : 7;
-            const RowIO sio = make_rowio(a.save + SL.h + (int64_t)sl * 256 * MP, st < 8 ? 256 : 0, MP, ms, half, valid);
-            gemm_seg<32, 8, 8, true>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff, &sio);
-        } else {
-            gemm_seg<32, 8, 8>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff);
-        }
+        gemm_seg<32, 8, 8>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff);
         if (st == 4) gemm_seg<8, 8, 2>(rs, (int)L.w5pe, pe, acc, voff);   // skip: cat[h, pts] (dm_nerf.py:87)
         if (st < 7) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h + (int64_t)(st + 1) * 256 * MP, 256, MP, ms, half, valid), h);
             if (st == 6) {
                 // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
                 float part = 0.f;
@@ -124,12 +121,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             // acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_rgbh, hid, hoff);
-            if constexpr (SAVE) {
-                const RowIO sio = make_rowio(a.save + SL.f, 256, MP, ms, half, valid);
-                gemm_seg<32, 4, 8, true>(rs, (int)L.w_rgbh, acc, hid, voff, &sio);
-            } else {
-                gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
-            }
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.f, 256, MP, ms, half, valid), acc);
+            gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
             gemm_seg<4, 4, 1>(rs, (int)L.w_rgbh_dir, de, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
@@ -153,12 +146,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             // acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_insh, hid, hoff);
-            if constexpr (SAVE) {
-                const RowIO sio = make_rowio(a.save + SL.q, 256, MP, ms, half, valid);
-                gemm_seg<32, 4, 8, true>(rs, (int)L.w_insh, acc, hid, voff, &sio);
-            } else {
-                gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
-            }
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.q, 256, MP, ms, half, valid), acc);
+            gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
             if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, MP, ms, half, valid), hid);

@@ -144,6 +144,19 @@ int dmnerf_build_pack_index_t(int ins_num, int32_t* h_idx, int64_t n_idx);
 int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num, const float* d_save,
                         const float* d_graw, int64_t M, float* d_dsave, void* stream);
 
+/* Weight / bias gradients dW = dy . x^T over the batch (split-K f32 MFMA, deterministic 2-stage sum).
+ * The plan (which workgroup does which job slice) depends only on (ins_num, M, max_wgs): build it once
+ * on the host, upload the two tables, reuse every step.  d_graw_t = dL/draw transposed to [4+C][Mp]
+ * (Mp = M rounded up to 32, zero padded).  d_grad_flat: dmnerf_param_count(ins_num) floats in the
+ * flat parameter order above.  d_part: workspace of `part_floats` floats.                         */
+int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes,
+                            int64_t* n_out_bytes, int64_t* part_floats, int* n_jobs, int* n_outs);
+int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes,
+                      void* h_outs, int64_t out_bytes);
+int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                           const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                           float* d_part, float* d_grad_flat, void* stream);
+
 /* dm_nerf inference (networks/render.py:31-96, perturb handled by the caller passing t_rand/u):
  * all stages on `stream`, outputs = the 10 tensors of the reference dict (ins_* are [N, C-1]).
  *   d_t_rand: [N,S] or NULL (no jitter); d_u / u_row_stride as in dmnerf_sample_pdf.
