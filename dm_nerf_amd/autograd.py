@@ -26,15 +26,18 @@ def _row_len(M):
 
 
 def _views(buf, M):
-    """Named [rows, row_len] views of a SaveLayout workspace (csrc/layout.h).  Padding columns hold
-    duplicates of the last sample in the activations and exact zeros in the gradients."""
-    M = _row_len(M)
+    """Feature-major [rows, row_len] COPIES of the tensors of a SaveLayout workspace (csrc/layout.h) --
+    diagnostics / tests only.  On the device every tensor is block-major [block][rows][32 samples];
+    padding columns hold duplicates of the last sample (activations) or exact zeros (gradients)."""
+    Mp = _row_len(M)
     o = 0
     out = {}
-    for name, rows in (("pe", 63), ("de", 27), ("h", 8 * W), ("f", W), ("q", W), ("g1", HW), ("g2", HW)):
-        out[name] = buf[o:o + rows * M].view(rows, M)
-        o += rows * M
-    out["h"] = out["h"].view(8, W, M)
+    for name, rows, n in (("pe", 63, 1), ("de", 27, 1), ("h", W, 8), ("f", W, 1), ("q", W, 1), ("g1", HW, 1), ("g2", HW, 1)):
+        ts = []
+        for _ in range(n):
+            ts.append(buf[o:o + rows * Mp].view(Mp // 32, rows, 32).permute(1, 0, 2).reshape(rows, Mp))
+            o += rows * Mp
+        out[name] = ts[0] if n == 1 else torch.stack(ts)
     return out
 
 
@@ -99,10 +102,10 @@ class MLPRaysFunction(torch.autograd.Function):
         dsave = torch.empty_like(ctx.save)
         _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                            _lib.ptr(dsave), _lib.stream()), "dmnerf_mlp_bwd_data")
-        # dL/draw transposed to feature-major rows, zero padded to the row length of the workspace
+        # dL/draw in the block-major form of the workspace ([block][4+C rows][32 samples]), zero padded
         Mp = _row_len(M)
-        gt = torch.zeros(4 + C, Mp, dtype=torch.float32, device=g.device)
-        gt[:, :M] = g.t()
+        gp = g if Mp == M else torch.nn.functional.pad(g, (0, 0, 0, Mp - M))
+        gt = gp.view(Mp // 32, 32, 4 + C).permute(0, 2, 1).contiguous()
         jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
         part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)

@@ -64,7 +64,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     const int voff = lane * 16;
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t M = save_row_len(a.M);            // padded row length (see layout.h)
-    const int64_t mcol = m_raw;                     // column of this lane (tail lanes -> padding, written as zeros)
 
     // ---- incoming gradient of this lane's sample --------------------------------------------
     const float* __restrict__ gr = a.graw + m * (4 + L.C);
@@ -87,12 +86,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         f32x16 t4[4], act4[4], d4[4];
         zero<4>(t4);
         gemm_seg<4 * OBI, 4, OBI>(rsT, (int)LT.t_inso, gi, t4, voff);
-        load_rows<4>(make_rowio(a.save + SL.g2, 128, M, mcol, half, valid), act4);
+        load_rows<4>(make_rowio(a.save + SL.g2, 128, M, blk, lane), act4);
         mask_relu<4>(d4, act4, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g2, 128, M, mcol, half, valid), d4);
+        store_rows<4>(make_rowio(a.dsave + SL.g2, 128, M, blk, lane), d4);
         zero<8>(acc);
         gemm_seg<16, 8, 4>(rsT, (int)LT.t_insh, d4, acc, voff);
-        store_rows<8>(make_rowio(a.dsave + SL.q, 256, M, mcol, half, valid), acc);      // dq (ins_feature has no activation)
+        store_rows<8>(make_rowio(a.dsave + SL.q, 256, M, blk, lane), acc);      // dq (ins_feature has no activation)
 
         // ---- rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU;  df = (W_rh^T dg1)[:256] ----
         zero<4>(t4);
@@ -108,12 +107,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
                 }
             }
         }
-        load_rows<4>(make_rowio(a.save + SL.g1, 128, M, mcol, half, valid), act4);
+        load_rows<4>(make_rowio(a.save + SL.g1, 128, M, blk, lane), act4);
         mask_relu<4>(d4, act4, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, M, mcol, half, valid), d4);
+        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, M, blk, lane), d4);
         zero<8>(acc);
         gemm_seg<16, 8, 4>(rsT, (int)LT.t_rgbh, d4, acc, voff);
-        store_rows<8>(make_rowio(a.dsave + SL.f, 256, M, mcol, half, valid), acc);      // df (rgb_feature has no activation)
+        store_rows<8>(make_rowio(a.dsave + SL.f, 256, M, blk, lane), acc);      // df (rgb_feature has no activation)
 #pragma unroll
         for (int b = 0; b < 8; ++b) d[b] = acc[b];
     }
@@ -137,9 +136,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         }
         const int l = 7 - st;                                   // layer whose pre-activation gradient this is
         f32x16 act[8];
-        load_rows<8>(make_rowio(a.save + SL.h + (int64_t)l * 256 * M, 256, M, mcol, half, valid), act);
+        load_rows<8>(make_rowio(a.save + SL.h + (int64_t)l * 256 * M, 256, M, blk, lane), act);
         mask_relu<8>(d, act, acc);
-        store_rows<8>(make_rowio(a.dsave + SL.h + (int64_t)l * 256 * M, 256, M, mcol, half, valid), d);
+        store_rows<8>(make_rowio(a.dsave + SL.h + (int64_t)l * 256 * M, 256, M, blk, lane), d);
     }
 }
 

@@ -28,22 +28,11 @@ __device__ __forceinline__ f32x4 ldw(rsrc_t r, int voff, int soff_bytes) {
     return __builtin_bit_cast(f32x4, v);
 }
 
-// NOTE: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0
-// (hipcc 7.2): always go through a scalar copy.
-__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
-
-struct RowIO {
-    rsrc_t rs;
-    int voff;        // ((4*half)*M + m) * 4 bytes
-    unsigned rowb;   // M * 4: bytes per row
-    bool valid;
-};
-
 // acc[ob] += Wseg[ob-block rows, k] * B[k, samples] for NKG*4 k-pairs.  B lives in registers in
 // accumulator layout: k-pair p is B[p >> 4][p & 15].  `seg` = float offset of the segment.
-template <int NKG, int OB, int NB, bool STORE_B = false>
+template <int NKG, int OB, int NB>
 __device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[NB],
-                                         f32x16 (&acc)[OB], int voff, const RowIO* sio = nullptr) {
+                                         f32x16 (&acc)[OB], int voff) {
     static_assert(NB * 16 >= NKG * 4, "B operand too small");
     // The segment is streamed front to back; its position lives in ONE scalar register that is
     // bumped every 4 KiB (imm offsets cover 0..3 KiB).  The empty asm makes the running value
@@ -51,18 +40,6 @@ __device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[N
     // spills hundreds of SGPRs (seen as v_writelane/v_readlane storms and scratch traffic).
     int so = seg * 4;
     asm volatile("" : "+s"(so));
-    // STORE_B (training): the B operand (this GEMM's input activations, in accumulator layout) is
-    // written feature-major to HBM *while it is being consumed*: 4 dword stores per k-group, i.e.
-    // one store per 8 MFMAs, instead of a 128-store burst at the layer boundary whose
-    // acknowledgements the next weight loads would have to wait behind (vmcnt is in-order).
-    // Stores are unconditional (no exec-mask branches inside the MFMA stream): rows are padded to a
-    // multiple of 32 samples so tail lanes write padding, and a descriptor with num_records = 0
-    // turns a whole call into no-ops through the hardware bounds check.
-    int svo = 0, step1 = 0, step5 = 0;
-    if constexpr (STORE_B) {
-        svo = sio->voff; step1 = (int)sio->rowb; step5 = (int)(5 * sio->rowb);
-        asm volatile("" : "+v"(svo));
-    }
 #pragma unroll
     for (int g = 0; g < NKG; ++g) {
         f32x4 a[OB];
@@ -75,10 +52,6 @@ __device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[N
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int p = g * 4 + kk;
-            if constexpr (STORE_B) {
-                __builtin_amdgcn_raw_buffer_store_b32(f2u(B[p >> 4][p & 15]), sio->rs, svo, 0, 0);
-                svo += ((p & 3) == 3) ? step5 : step1;
-            }
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
                 acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
@@ -149,10 +122,24 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16
 }
 
 
-// ---- feature-major activation tensors [rows][M] (training): row = feature, column = sample ----
-// A wave's accumulator block b, register r holds feature 32b + crow(r, half) of sample m: for a
-// fixed (b, r) lanes 0-31 are 32 consecutive samples of one row and lanes 32-63 of the row 4 below,
-// i.e. two fully coalesced 128-byte segments per instruction, with no transpose.
+// ---- block-major activation tensors (training) ------------------------------------------------
+// Every saved tensor with R rows (features) is stored as [block of 32 samples][R rows][32 samples]:
+//   addr(blk, row, j) = ((blk * R + row) * 32 + j) floats.
+// A wave's accumulator block b, register r holds feature 32b + crow(r, half) of sample j: for a
+// fixed (b, r) lanes 0-31 write the 128-byte row segment of feature f and lanes 32-63 that of
+// f + 4, and ALL the stores of a layer land in one contiguous R*128-byte region (32 KiB for 256
+// rows): one TLB entry, a handful of DRAM pages.  (The first version used feature-major [R][M]
+// rows 3 MB apart: every store / every wgrad row hit a different page and the kernels ran at a
+// quarter of their speed.)  The weight-gradient kernel reads the same regions as contiguous tiles.
+struct RowIO {
+    rsrc_t rs;
+    int voff;        // ((blk*R + 4*half) * 32 + j) * 4 bytes
+};
+
+// NOTE: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0
+// (hipcc 7.2): always go through a scalar copy.
+__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
+
 // Descriptor from provably wave-uniform inputs: without the readfirstlane the compiler keeps the
 // (uniform) pointer in VGPRs under SGPR pressure and wraps every access in a waterfall loop.
 __device__ __forceinline__ rsrc_t uniform_rsrc(const float* base, int64_t n_floats) {
@@ -164,68 +151,55 @@ __device__ __forceinline__ rsrc_t uniform_rsrc(const float* base, int64_t n_floa
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)nb, 0x00020000);
 }
 
-__device__ __forceinline__ RowIO make_rowio(const float* base, int rows, int64_t M, int64_t m, int half, bool valid) {
+// base: tensor start; R: its row count; Mp: padded sample count (multiple of 32); blk: this wave's block.
+__device__ __forceinline__ RowIO make_rowio(const float* base, int R, int64_t Mp, int64_t blk, int lane) {
     RowIO io;
-    io.rs = uniform_rsrc(base, (int64_t)rows * M);
-    io.voff = (int)((4 * (int64_t)half * M + m) * 4);
-    io.rowb = (unsigned)(M * 4);
-    io.valid = valid;
+    io.rs = uniform_rsrc(base, (int64_t)R * Mp);
+    io.voff = (int)(((blk * R + 4 * (lane >> 5)) * 32 + (lane & 31)) * 4);
     return io;
 }
 
-// Rows are visited in increasing order with a running per-lane byte offset (one VALU add per
-// access): row steps are +1,+1,+1,+5 (crow pattern), so no per-row scalar offset is ever live
-// (hoisted row*M products spilled SGPRs -> scratch in the first version).
 template <int NB>
 __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB]) {
-    int vo = io.voff;
-    asm volatile("" : "+v"(vo));     // opaque per call: identical offset chains of different calls must not be CSE'd into ~128 live VGPRs
-    const int step1 = (int)io.rowb, step5 = (int)(5 * io.rowb);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, vo, 0, 0);
-            vo += ((r & 3) == 3) ? step5 : step1;
+            const int row = 32 * b + (r & 3) + 8 * (r >> 2);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, io.voff + row * 128, 0, 0);
         }
     }
 }
 
 template <int NB>
 __device__ __forceinline__ void load_rows(const RowIO& io, f32x16 (&v)[NB]) {
-    int vo = io.voff;
-    asm volatile("" : "+v"(vo));
-    const int step1 = (int)io.rowb, step5 = (int)(5 * io.rowb);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            v[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(io.rs, vo, 0, 0));
-            vo += ((r & 3) == 3) ? step5 : step1;
+            const int row = 32 * b + (r & 3) + 8 * (r >> 2);
+            v[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(io.rs, io.voff + row * 128, 0, 0));
         }
     }
 }
 
-// Encoded inputs are saved in Embedder.embed's own column order (rows of a [3+6L][M] matrix).
+// Encoded inputs are saved in Embedder.embed's own column order (rows of a [blk][3+6L][32] tensor).
 template <int L, int NV>
-__device__ __forceinline__ void store_encoded_rows(const float* base, int64_t M, int64_t m, int half, bool valid,
+__device__ __forceinline__ void store_encoded_rows(const float* base, int64_t Mp, int64_t blk, int lane,
                                                    const f32x16 (&e)[NV]) {
-    (void)valid;                                               // rows are padded: tail lanes write padding
-    rsrc_t rs = uniform_rsrc(base, (int64_t)(3 + 6 * L) * M);
-    const unsigned rowb = (unsigned)(M * 4);
-    const int v1 = (int)(((int64_t)half * M + m) * 4);        // rows 0/1 (x, y)
-    const int v3 = (int)((3 * (int64_t)half * M + m) * 4);    // sin row + 3 = cos row
-    __builtin_amdgcn_raw_buffer_store_b32(f2u(e[0][0]), rs, v1, 0, 0);
-    if (half == 0) __builtin_amdgcn_raw_buffer_store_b32(f2u(e[0][1]), rs, v1 + (int)(2 * rowb), 0, 0);
-    int vo = v3 + (int)(3 * rowb);                            // row 3 + 6k + c (+3 for the cos half)
-    asm volatile("" : "+v"(vo));
+    constexpr int R = 3 + 6 * L;
+    const int half = lane >> 5, j = lane & 31;
+    rsrc_t rs = uniform_rsrc(base, (int64_t)R * Mp);
+    const int v0 = (int)((blk * R * 32 + j) * 4);
+    __builtin_amdgcn_raw_buffer_store_b32(f2u(e[0][0]), rs, v0 + half * 128, 0, 0);           // rows 0 / 1: x, y
+    if (half == 0) __builtin_amdgcn_raw_buffer_store_b32(f2u(e[0][1]), rs, v0 + 2 * 128, 0, 0);  // row 2: z
+    const int v3 = v0 + 3 * half * 128;                                                        // sin row, +3 rows = cos row
 #pragma unroll
     for (int k = 0; k < L; ++k) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int p = 2 + 3 * k + c;
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(e[p >> 4][p & 15]), rs, vo, 0, 0);
-            vo += (c == 2) ? (int)(4 * rowb) : (int)rowb;
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(e[p >> 4][p & 15]), rs, v3 + (3 + 6 * k + c) * 128, 0, 0);
         }
     }
 }

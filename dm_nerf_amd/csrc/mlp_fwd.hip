@@ -74,10 +74,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);          // padded row length of the training workspace
-    const int64_t ms = m_raw;                      // column this lane writes (tail lanes -> padding)
-    if constexpr (SAVE) {
-        store_encoded_rows<POS_L, 2>(a.save + SL.pe, MP, ms, half, valid, pe);
-        store_encoded_rows<DIR_L, 1>(a.save + SL.de, MP, ms, half, valid, de);
+    if constexpr (SAVE) {                          // tail lanes write the padding columns of the last block
+        store_encoded_rows<POS_L, 2>(a.save + SL.pe, MP, blk, lane, pe);
+        store_encoded_rows<DIR_L, 1>(a.save + SL.de, MP, blk, lane, de);
     }
 
     f32x16 h[8], acc[8];
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     // Activation saves are issued as one burst per layer.  (Interleaving them into the next layer's
     // MFMA stream was measured SLOWER, 14.3 vs 12.2 ms: vmcnt retires in order, so every later
     // weight-load wait then also waits for a store acknowledgement.)
-    if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h, 256, MP, ms, half, valid), h);
+    if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h, 256, MP, blk, lane), h);
 
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         if (st < 7) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h + (int64_t)(st + 1) * 256 * MP, 256, MP, ms, half, valid), h);
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h + (int64_t)(st + 1) * 256 * MP, 256, MP, blk, lane), h);
             if (st == 6) {
                 // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
                 float part = 0.f;
@@ -121,12 +120,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             // acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_rgbh, hid, hoff);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.f, 256, MP, ms, half, valid), acc);
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.f, 256, MP, blk, lane), acc);
             gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
             gemm_seg<4, 4, 1>(rs, (int)L.w_rgbh_dir, de, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, MP, ms, half, valid), hid);
+            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, MP, blk, lane), hid);
             // rgb_linear (dm_nerf.py:102) on the VALU
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -146,11 +145,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             // acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
             f32x16 hid[4];
             init_bias<4>(rs, (int)L.b_insh, hid, hoff);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.q, 256, MP, ms, half, valid), acc);
+            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.q, 256, MP, blk, lane), acc);
             gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
 #pragma unroll
             for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, MP, ms, half, valid), hid);
+            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, MP, blk, lane), hid);
             f32x16 io[OBI];
             init_bias<OBI>(rs, (int)L.b_inso, io, hoff);
             gemm_seg<16, OBI, 4>(rs, (int)L.w_inso, hid, io, voff);     // ins_linear (:103)

@@ -1,8 +1,9 @@
 // wgrad.hip -- weight / bias gradients of the DM-NeRF MLP for gfx950:  dW = dy . x^T  over the batch.
 //
-// Both operands are the feature-major [rows][Mp] tensors the training forward (x: layer inputs) and
-// the dgrad pass (dy: pre-activation gradients) wrote, so every job is an "NT" GEMM whose K dimension
-// (samples, up to ~10^6) is contiguous in memory and whose output is at most 256 x 256:
+// Both operands are the block-major [32-sample block][rows][32] tensors the training forward
+// (x: layer inputs) and the dgrad pass (dy: pre-activation gradients) wrote, so every job is an "NT"
+// GEMM over K = samples (up to ~10^6) whose output is at most 256 x 256, and the operands of one
+// 32-sample chunk are two CONTIGUOUS tiles of rows*128 bytes:
 //   * split-K: the samples are cut into slices, one workgroup per (job, slice); slice counts are
 //     proportional to the job's FLOPs so that ~one wave of workgroups (<= 256 CUs, one per CU) is
 //     balanced; per-slice partials go to a workspace and a second kernel adds them in fixed order
@@ -34,7 +35,9 @@ constexpr int MAX_ROWS = 512;     // A rows + B rows staged per chunk
 
 // One workgroup's work (device table, offsets only => reusable across steps).
 struct WgJob {
-    int64_t a_off, b_off;     // float offsets of the first A / B row inside their source buffers
+    int64_t a_off, b_off;     // float offsets of the A / B TENSORS inside their source buffers
+    int a_R, b_R;             // total rows of those tensors (block stride = R*32 floats)
+    int a_row0, b_row0;       // first row of the job inside the tensor
     int64_t part_off;         // float offset of this workgroup's partial [NBA*32][NBB*32] in the workspace
     int64_t bias_off;         // float offset of its partial row sums [NBA*32], or -1
     int a_src, b_src;         // 0 = saved activations, 1 = dgrad output, 2 = transposed d raw
@@ -43,6 +46,7 @@ struct WgJob {
     int chunk0, nchunk;       // 32-sample chunks [chunk0, chunk0 + nchunk)
     int pad;
 };
+static_assert(sizeof(WgJob) % 8 == 0, "WgJob layout");
 
 // One output tensor slice (weight columns [col_off, col_off + rowsB) of a parameter, plus its bias).
 struct WgOut {
@@ -75,9 +79,10 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
     constexpr int NL = NBA + NBB;                  // 16-byte pieces per thread per chunk (ROWS*8/256)
     constexpr int BUF = ROWS * LDS_STRIDE;         // floats per ring slot
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, li = lane & 31;
-    const float* __restrict__ A = a.src[jb.a_src] + jb.a_off;
-    const float* __restrict__ B = a.src[jb.b_src] + jb.b_off;
-    const int64_t Mp = a.Mp;
+    // tile of chunk c: rows [row0, row0 + rows) of block (chunk0 + c): contiguous rows*32 floats
+    const float* __restrict__ A = a.src[jb.a_src] + jb.a_off + (int64_t)jb.a_row0 * 32;
+    const float* __restrict__ B = a.src[jb.b_src] + jb.b_off + (int64_t)jb.b_row0 * 32;
+    const int64_t strideA = (int64_t)jb.a_R * 32, strideB = (int64_t)jb.b_R * 32;       // floats per block
 
     f32x16 acc[SP::SAn * SP::SBn];
 #pragma unroll
@@ -88,28 +93,25 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
     const bool do_bias = jb.bias_off >= 0 && (NBB >= 4 ? w == 0 : (NBB == 2 ? (w & 1) == 0 : true));
 
     // per-thread staging geometry: piece e = tid + 256 i -> (row = e >> 3, 16-byte piece = e & 7)
-    const float* src[NL];
-    int ldst[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int e = tid + 256 * i, row = e >> 3, pc = e & 7;
-        const bool isA = row < NBA * 32;
-        const int r = isA ? row : row - NBA * 32;
-        const bool ok = isA ? r < jb.rowsA : r < jb.rowsB;
-        src[i] = ok ? (isA ? A : B) + (int64_t)r * Mp + pc * 4 : nullptr;
-        ldst[i] = row * LDS_STRIDE + pc * 4;
-    }
+    // pieces i < NBA come from the A tile, the rest from the B tile; inside a tile piece e*4 floats
+    const int prow = tid >> 3, pcol = (tid & 7) * 4;
     f32x4 stage[NL];
     auto load_chunk = [&](int c) {
-        const int64_t m0 = (int64_t)(jb.chunk0 + c) * KT;
+        const float* ta = A + (int64_t)(jb.chunk0 + c) * strideA + tid * 4;
+        const float* tb = B + (int64_t)(jb.chunk0 + c) * strideB + tid * 4;
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
-            stage[i] = src[i] ? *reinterpret_cast<const f32x4*>(src[i] + m0) : (f32x4)(0.f);
+        for (int i = 0; i < NL; ++i) {
+            const bool isA = i < NBA;
+            const int r = prow + 32 * (isA ? i : i - NBA);
+            const bool ok = r < (isA ? jb.rowsA : jb.rowsB);
+            const float* p = (isA ? ta : tb) + 1024 * (isA ? i : i - NBA);
+            stage[i] = ok ? *reinterpret_cast<const f32x4*>(p) : (f32x4)(0.f);
+        }
     };
     auto write_chunk = [&](float* buf) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            float2* d = reinterpret_cast<float2*>(buf + ldst[i]);          // 8-byte aligned (stride 34, piece*4)
+            float2* d = reinterpret_cast<float2*>(buf + (prow + 32 * i) * LDS_STRIDE + pcol);   // 8-byte aligned (stride 34, piece*4)
             d[0] = make_float2(stage[i][0], stage[i][1]);
             d[1] = make_float2(stage[i][2], stage[i][3]);
         }
@@ -225,8 +227,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const WgOut*
 // host: the plan
 // ------------------------------------------------------------------------------------------
 struct JobDesc {
-    int a_src; int64_t a_row;   // first row (row index inside the source buffer, in units of rows)
-    int b_src; int64_t b_row;
+    int a_src; int64_t a_base; int a_R, a_row0;   // tensor: base (in rows of the SaveLayout), its total rows, first row used
+    int b_src; int64_t b_base; int b_R, b_row0;
     int rowsA, rowsB, cls;
     int64_t out_off; int ld_out, col_off;
     int64_t bias_out_off;       // -1: bias handled by another job with the same A
@@ -262,21 +264,22 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
     lin(1, W, w_d, b_d); lin(C, HW, w_io, b_io); lin(3, HW, w_ro, b_ro);
 
     std::vector<JobDesc> d;
-    // src ids: 0 = save (x), 1 = dsave (dy), 2 = transposed d raw [4+C][Mp]
-    d.push_back({1, R_h + 0 * W, 0, R_pe, W, POS_CH, 0, w_m[0], POS_CH, 0, b_m[0]});
+    // src ids: 0 = save (x), 1 = dsave (dy), 2 = transposed d raw [blk][4+C][32]
+    const int GT = 4 + C;
+    d.push_back({1, R_h + 0 * W, W, 0, 0, R_pe, POS_CH, 0, W, POS_CH, 0, w_m[0], POS_CH, 0, b_m[0]});
     for (int l = 1; l < 8; ++l) {
         const int ld = l == 5 ? W + POS_CH : W;
-        d.push_back({1, R_h + (int64_t)l * W, 0, R_h + (int64_t)(l - 1) * W, W, W, 0, w_m[l], ld, 0, b_m[l]});
-        if (l == 5) d.push_back({1, R_h + 5 * W, 0, R_pe, W, POS_CH, 0, w_m[5], ld, W, -1});          // cat[h, pts] (dm_nerf.py:87)
+        d.push_back({1, R_h + (int64_t)l * W, W, 0, 0, R_h + (int64_t)(l - 1) * W, W, 0, W, W, 0, w_m[l], ld, 0, b_m[l]});
+        if (l == 5) d.push_back({1, R_h + 5 * W, W, 0, 0, R_pe, POS_CH, 0, W, POS_CH, 0, w_m[5], ld, W, -1});   // cat[h, pts] (dm_nerf.py:87)
     }
-    d.push_back({1, R_f, 0, R_h + 7 * W, W, W, 0, w_rf, W, 0, b_rf});
-    d.push_back({1, R_q, 0, R_h + 7 * W, W, W, 0, w_if, W, 0, b_if});
-    d.push_back({1, R_g1, 0, R_f, HW, W, 0, w_rh, W + DIR_CH, 0, b_rh});
-    d.push_back({1, R_g1, 0, R_de, HW, DIR_CH, 0, w_rh, W + DIR_CH, W, -1});                         // cat[rgb_feature, dirs] (:90)
-    d.push_back({1, R_g2, 0, R_q, HW, W, 0, w_ih, W, 0, b_ih});
-    d.push_back({2, 3, 0, R_h + 7 * W, 1, W, 0, w_d, W, 0, b_d});                                     // density_linear
-    d.push_back({2, 4, 0, R_g2, C, HW, 0, w_io, HW, 0, b_io});                                        // ins_linear
-    d.push_back({2, 0, 0, R_g1, 3, HW, 0, w_ro, HW, 0, b_ro});                                        // rgb_linear
+    d.push_back({1, R_f, W, 0, 0, R_h + 7 * W, W, 0, W, W, 0, w_rf, W, 0, b_rf});
+    d.push_back({1, R_q, W, 0, 0, R_h + 7 * W, W, 0, W, W, 0, w_if, W, 0, b_if});
+    d.push_back({1, R_g1, HW, 0, 0, R_f, W, 0, HW, W, 0, w_rh, W + DIR_CH, 0, b_rh});
+    d.push_back({1, R_g1, HW, 0, 0, R_de, DIR_CH, 0, HW, DIR_CH, 0, w_rh, W + DIR_CH, W, -1});                 // cat[rgb_feature, dirs] (:90)
+    d.push_back({1, R_g2, HW, 0, 0, R_q, W, 0, HW, W, 0, w_ih, W, 0, b_ih});
+    d.push_back({2, 0, GT, 3, 0, R_h + 7 * W, W, 0, 1, W, 0, w_d, W, 0, b_d});                                  // density_linear
+    d.push_back({2, 0, GT, 4, 0, R_g2, HW, 0, C, HW, 0, w_io, HW, 0, b_io});                                   // ins_linear
+    d.push_back({2, 0, GT, 0, 0, R_g1, HW, 0, 3, HW, 0, w_ro, HW, 0, b_ro});                                   // rgb_linear
     double total = 0;
     for (auto& j : d) { j.cls = class_for(j.rowsA, j.rowsB); total += (double)CLS_NBA[j.cls] * CLS_NBB[j.cls]; }
 
@@ -296,7 +299,8 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
         for (int s = 0; s < ns; ++s) {
             WgJob g{};
             g.a_src = j.a_src; g.b_src = j.b_src;
-            g.a_off = j.a_row * Mp; g.b_off = j.b_row * Mp;
+            g.a_off = j.a_base * Mp; g.b_off = j.b_base * Mp;
+            g.a_R = j.a_R; g.b_R = j.b_R; g.a_row0 = j.a_row0; g.b_row0 = j.b_row0;
             g.part_off = P.part_floats; g.bias_off = j.bias_out_off >= 0 ? P.part_floats + tile : -1;
             g.rowsA = j.rowsA; g.rowsB = j.rowsB; g.cls = j.cls;
             g.chunk0 = (int)((int64_t)nchunks * s / ns);

@@ -38,7 +38,7 @@ extern "C" {
 #define DMNERF_W 256       /* netwidth  (config.py:33 default; every shipped config) */
 #define DMNERF_D 8         /* netdepth  (config.py:31 default), skips=[4] (config.py:133) */
 #define DMNERF_MAX_LOGITS 128 /* C = ins_num+1 <= 128 (Replica room_0: 94) */
-#define DMNERF_MAX_TRAIN_SAMPLES 2097151LL /* samples per training launch: 256 rows x M x 4 B < 2^31 */
+#define DMNERF_MAX_TRAIN_SAMPLES 1048576LL /* samples per training launch: 32-bit byte offsets into a 256-row tensor */
 
 int dmnerf_abi_version(void);
 const char* dmnerf_last_error(void);
@@ -126,10 +126,11 @@ int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const float* d_ra
                          const float* d_g_depth, const float* d_g_weights, int64_t N, int S, int C,
                          float* d_grad_raw, void* stream);
 
-/* Training forward of dmnerf_mlp_fwd_rays: additionally saves every layer input / relu output
- * feature-major ([rows][M], M = N*S) into d_save (dmnerf_train_save_floats(M) floats):
- *   embed(pts) [63][M] | embed(dirs) [27][M] | h_0..h_7 [8][256][M] | rgb_feature [256][M] |
- *   ins_feature [256][M] | rgb hidden [128][M] | ins hidden [128][M].   M <= DMNERF_MAX_TRAIN_SAMPLES. */
+/* Training forward of dmnerf_mlp_fwd_rays: additionally saves every layer input / relu output into
+ * d_save (dmnerf_train_save_floats(M) floats, M = N*S, Mp = M rounded up to 32).  Each tensor with R
+ * rows is stored block-major: addr(sample m, row) = ((m/32 * R + row) * 32 + m%32); tensors in order:
+ *   embed(pts) R=63 | embed(dirs) R=27 | h_0..h_7 8 x R=256 | rgb_feature 256 | ins_feature 256 |
+ *   rgb hidden 128 | ins hidden 128, each R*Mp floats.   M <= DMNERF_MAX_TRAIN_SAMPLES.          */
 int64_t dmnerf_train_save_floats(int64_t M);
 int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_rays_o,
                               const float* d_rays_d, const float* d_z, int64_t N, int S,
@@ -146,8 +147,8 @@ int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num,
 
 /* Weight / bias gradients dW = dy . x^T over the batch (split-K f32 MFMA, deterministic 2-stage sum).
  * The plan (which workgroup does which job slice) depends only on (ins_num, M, max_wgs): build it once
- * on the host, upload the two tables, reuse every step.  d_graw_t = dL/draw transposed to [4+C][Mp]
- * (Mp = M rounded up to 32, zero padded).  d_grad_flat: dmnerf_param_count(ins_num) floats in the
+ * on the host, upload the two tables, reuse every step.  d_graw_t = dL/draw in the same block-major
+ * form, R = 4+C rows, zero in the padding columns.  d_grad_flat: dmnerf_param_count(ins_num) floats in the
  * flat parameter order above.  d_part: workspace of `part_floats` floats.                         */
 int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes,
                             int64_t* n_out_bytes, int64_t* part_floats, int* n_jobs, int* n_outs);
