@@ -280,13 +280,18 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
     d.push_back({2, 0, GT, 3, 0, R_h + 7 * W, W, 0, 1, W, 0, w_d, W, 0, b_d});                                  // density_linear
     d.push_back({2, 0, GT, 4, 0, R_g2, HW, 0, C, HW, 0, w_io, HW, 0, b_io});                                   // ins_linear
     d.push_back({2, 0, GT, 0, 0, R_g1, HW, 0, 3, HW, 0, w_ro, HW, 0, b_ro});                                   // rgb_linear
+    // Cost of one 32-sample chunk for a workgroup: its MFMA time (NBA*NBB blocks * 16 MFMAs * 64 cycles
+    // over 4 SIMDs = 256 cycles per block pair) but never less than the fixed per-chunk latency of the
+    // load -> LDS -> barrier pipeline (measured ~2.5 us: the skinny jobs were the long pole when slices
+    // were allotted by FLOPs alone).
+    auto chunk_cost = [](int cls) { const double c = 256.0 * CLS_NBA[cls] * CLS_NBB[cls]; return c < 6000.0 ? 6000.0 : c; };
     double total = 0;
-    for (auto& j : d) { j.cls = class_for(j.rowsA, j.rowsB); total += (double)CLS_NBA[j.cls] * CLS_NBB[j.cls]; }
+    for (auto& j : d) { j.cls = class_for(j.rowsA, j.rowsB); total += chunk_cost(j.cls); }
 
     Plan P;
     for (auto& j : d) {
         const int nba = CLS_NBA[j.cls], nbb = CLS_NBB[j.cls];
-        int ns = (int)((double)max_wgs * nba * nbb / total);        // floor => sum <= max_wgs
+        int ns = (int)((double)max_wgs * chunk_cost(j.cls) / total);   // floor => sum <= max_wgs
         if (ns < 1) ns = 1;
         if (ns > nchunks) ns = nchunks;
         const int64_t tile = (int64_t)nba * 32 * nbb * 32, brow = (int64_t)nba * 32;
