@@ -50,40 +50,68 @@ constexpr int64_t seg_floats(int nkg, int ob) { return (int64_t)nkg * ob * 256; 
 // bias segment: seg[(ob*2 + half)*16 + r] = bias[32ob + (r&3) + 8(r>>2) + 4half]
 constexpr int64_t bias_floats(int ob) { return (int64_t)ob * 32; }
 
+// Forward blob = [table | weight stream | 2 dummy quarters].
+//   table  (TAB_FLOATS, staged once per workgroup in LDS): every bias in accumulator order plus the
+//          two VALU heads (density_linear, rgb_linear);
+//   stream: the GEMM segments in EXACT consumption order, cut into "quarters" of 64 KiB (one LDS
+//          ring slot); segments shorter than a quarter are padded to one, so the stream pointer
+//          always advances by 64 KiB and the DMA schedule is completely static:
+//            w0 | st0..st4 (4 quarters each) | w5pe | st5 st6 st7 | rgbh (2) | rgbh_dir | st8 | insh (2) | inso
+//          st = the nine 256->256 stages L1..L4, L5(h part), L6, L7, rgb_feature, ins_feature.
+constexpr int QUARTER_FLOATS = 16384;    // 64 KiB: 8 k-groups x 8 out-blocks x 1 KiB
+constexpr int TAB_FLOATS = 4096;         // 16 KiB
+constexpr int N_QUARTERS = 1 + 5 * 4 + 1 + 3 * 4 + 3 + 4 + 3;   // 44
+
 struct BlobLayout {
     int C, OBI;                   // logits, out-blocks of the ins_linear head
-    int64_t w0, b0;               // mlps.0: PE k-order, NKG=8, OB=8
-    int64_t w_stage, b_stage;     // NSTAGE x (NKG=32, OB=8) + NSTAGE x bias(8)
-    int64_t w5pe;                 // mlps.5 columns 256..318: PE k-order, NKG=8, OB=8
-    int64_t w_rgbh, w_rgbh_dir, b_rgbh;   // rgb_feature_linears.0: (NKG=32,OB=4) + dir (NKG=4,OB=4)
-    int64_t w_insh, b_insh;       // ins_feature_linears.0: NKG=32, OB=4
-    int64_t w_inso, b_inso;       // ins_linear: NKG=16, OB=OBI
+    // table
+    int64_t b0, b_stage;          // bias of mlps.0; NSTAGE x bias(8)
+    int64_t b_rgbh, b_insh, b_inso;
     int64_t w_den, b_den;         // density_linear on VALU: [half][128] + bias (padded to 4)
     int64_t w_rgbo, b_rgbo;       // rgb_linear on VALU: [c][half][64] + bias[3] (padded to 4)
+    // stream (float offsets from the blob start; every one a multiple of QUARTER_FLOATS past `stream`)
+    int64_t stream;
+    int64_t w0;                   // mlps.0: PE k-order, NKG=8, OB=8 (1 quarter)
+    int64_t w_stage_lo;           // stages 0..4 (4 quarters each)
+    int64_t w5pe;                 // mlps.5 columns 256..318 (1 quarter)
+    int64_t w_stage_mid;          // stages 5..7
+    int64_t w_rgbh, w_rgbh_dir;   // rgb_feature_linears.0: (NKG=32,OB=4) 2 quarters + dirs (NKG=4,OB=4) 1 padded quarter
+    int64_t w_stage_hi;           // stage 8 (ins_feature)
+    int64_t w_insh;               // ins_feature_linears.0: 2 quarters
+    int64_t w_inso;               // ins_linear: NKG=16, OB=OBI, 1 padded quarter
     int64_t total;
 };
+
+DMN_HD inline int64_t stage_off(const BlobLayout& L, int st) {
+    return st < 5 ? L.w_stage_lo + st * seg_floats(32, 8) : (st < 8 ? L.w_stage_mid + (st - 5) * seg_floats(32, 8) : L.w_stage_hi);
+}
 
 DMN_HD inline BlobLayout make_layout(int ins_num) {
     BlobLayout L;
     L.C = ins_num + 1;
     L.OBI = (L.C + 31) / 32;
     int64_t o = 0;
-    L.w0 = o; o += seg_floats(8, 8);
     L.b0 = o; o += bias_floats(8);
-    L.w_stage = o; o += NSTAGE * seg_floats(32, 8);
     L.b_stage = o; o += NSTAGE * bias_floats(8);
-    L.w5pe = o; o += seg_floats(8, 8);
-    L.w_rgbh = o; o += seg_floats(32, 4);
-    L.w_rgbh_dir = o; o += seg_floats(4, 4);
     L.b_rgbh = o; o += bias_floats(4);
-    L.w_insh = o; o += seg_floats(32, 4);
     L.b_insh = o; o += bias_floats(4);
-    L.w_inso = o; o += seg_floats(16, L.OBI);
     L.b_inso = o; o += bias_floats(L.OBI);
     L.w_den = o; o += 256;
     L.b_den = o; o += 4;
     L.w_rgbo = o; o += 3 * 2 * 64;
     L.b_rgbo = o; o += 4;
+    o = TAB_FLOATS;
+    L.stream = o;
+    L.w0 = o; o += QUARTER_FLOATS;
+    L.w_stage_lo = o; o += 5 * seg_floats(32, 8);
+    L.w5pe = o; o += QUARTER_FLOATS;
+    L.w_stage_mid = o; o += 3 * seg_floats(32, 8);
+    L.w_rgbh = o; o += seg_floats(32, 4);
+    L.w_rgbh_dir = o; o += QUARTER_FLOATS;
+    L.w_stage_hi = o; o += seg_floats(32, 8);
+    L.w_insh = o; o += seg_floats(32, 4);
+    L.w_inso = o; o += QUARTER_FLOATS;
+    o += 2 * QUARTER_FLOATS;            // the DMA engine always runs two quarters ahead: zero-filled landing zone
     L.total = o;
     return L;
 }

@@ -131,6 +131,9 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16
 // rows): one TLB entry, a handful of DRAM pages.  (The first version used feature-major [R][M]
 // rows 3 MB apart: every store / every wgrad row hit a different page and the kernels ran at a
 // quarter of their speed.)  The weight-gradient kernel reads the same regions as contiguous tiles.
+#ifndef DMN_STORE_AUX
+#define DMN_STORE_AUX 0   /* cache policy bits of the activation stores (2 = nt) */
+#endif
 struct RowIO {
     rsrc_t rs;
     int voff;        // ((blk*R + 4*half) * 32 + j) * 4 bytes
@@ -166,7 +169,7 @@ __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * b + (r & 3) + 8 * (r >> 2);
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, io.voff + row * 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, DMN_STORE_AUX);
         }
     }
 }
@@ -178,7 +181,7 @@ __device__ __forceinline__ void load_rows(const RowIO& io, f32x16 (&v)[NB]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * b + (r & 3) + 8 * (r >> 2);
-            v[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(io.rs, io.voff + row * 128, 0, 0));
+            v[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, 0));
         }
     }
 }
@@ -199,8 +202,111 @@ __device__ __forceinline__ void store_encoded_rows(const float* base, int64_t Mp
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int p = 2 + 3 * k + c;
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(e[p >> 4][p & 15]), rs, v3 + (3 + 6 * k + c) * 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(e[p >> 4][p & 15]), rs, v3 + ((3 + 6 * k + c) * 128) % 4096, ((3 + 6 * k + c) * 128) / 4096 * 4096, 0);
         }
+    }
+}
+
+
+// ==========================================================================================
+// Weight streaming through LDS (the "loader-less" engine of the fused MLP kernels)
+// ==========================================================================================
+// LDS = [ring: 2 slots x 64 KiB][table: 16 KiB].  The weight stream (layout.h) is consumed one
+// 64 KiB quarter at a time; quarter q lives in slot q & 1.  All four waves of the workgroup issue
+// the LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, 16 per wave and quarter) for
+// quarter q+2 the moment quarter q has been released, i.e. one full quarter (256 MFMAs per wave,
+// ~6.8 us) before it is needed, and read their A operands with ds_read_b128 (lgkmcnt), so
+//   * no VMEM load is ever issued inside the MFMA stream, and every DMA is OLDER than the activation
+//     stores issued after it: waiting for a DMA (vmcnt retires in order) never waits for a store ack;
+//   * the L2 -> CU weight traffic drops 4x (one copy per workgroup instead of one per wave).
+// Protocol per quarter:  acquire<Y>()  = s_waitcnt vmcnt(Y) ; s_barrier      (Y = VMEM ops younger than its DMA)
+//                        ... ds_read_b128 / MFMA ...
+//                        release()     = s_waitcnt lgkmcnt(0) ; s_barrier ; [stores] ; DMA(q+2)
+constexpr int SLOT_FLOATS = QUARTER_FLOATS;
+constexpr int RING_FLOATS = 2 * SLOT_FLOATS;
+constexpr int LDS_FLOATS = RING_FLOATS + TAB_FLOATS;       // 147 456 bytes
+constexpr int DMA_PER_QUARTER = 16;                        // LDS-DMA instructions per wave per quarter
+
+#define DMN_GAS __attribute__((address_space(1)))
+#define DMN_LAS __attribute__((address_space(3)))
+
+struct WStream {
+    const char* gsrc;     // blob + lane*16 + wave*1024 (per-lane global source of piece 0)
+    float* ring;          // LDS ring base
+    int wave;             // wave id in the workgroup (uniform)
+    unsigned off;         // byte offset from the blob start of the next quarter to fetch
+    int fslot;            // ring slot the next fetch goes to
+    int cslot;            // ring slot of the next quarter to consume
+};
+
+__device__ __forceinline__ void ws_fetch(WStream& ws) {
+    const char* g = ws.gsrc + ws.off;
+    float* dst = ws.ring + ws.fslot * SLOT_FLOATS + ws.wave * 256;
+#pragma unroll
+    for (int i = 0; i < DMA_PER_QUARTER; ++i)     // piece p = 4 i + wave: 1 KiB each
+        __builtin_amdgcn_global_load_lds((DMN_GAS void*)(g + i * 4096), (DMN_LAS void*)(dst + i * 1024), 16, 0, 0);
+    ws.off += QUARTER_FLOATS * 4;
+    ws.fslot ^= 1;
+}
+
+template <int YOUNGER>
+__device__ __forceinline__ void ws_acquire() {
+    static_assert(YOUNGER >= 0 && YOUNGER <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// All of this wave's ds_reads of the slot have returned; after the barrier nobody reads it any more.
+__device__ __forceinline__ void ws_release_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
+// operands from the LDS slot (group-local index), B from registers (accumulator layout).
+template <int G0, int NG, int OB, int NB>
+__device__ __forceinline__ void gemm_quarter(const float* slot, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
+    static_assert(NB * 16 >= (G0 + NG) * 4, "B operand too small");
+    static_assert(NG * OB <= 64, "more than one quarter");
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(slot) + lane;
+#pragma unroll
+    for (int gl = 0; gl < NG; ++gl) {
+        f32x4 a[OB];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) a[ob] = s4[(gl * OB + ob) * 64];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int p = (G0 + gl) * 4 + kk;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
+        }
+    }
+}
+
+// acc[ob][r] = bias of row 32ob + crow(r, half), from the LDS table
+template <int OB>
+__device__ __forceinline__ void init_bias_lds(const float* tab_seg, f32x16 (&acc)[OB], int half) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(tab_seg + (ob * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b4[q];
+            acc[ob][4 * q + 0] = v[0]; acc[ob][4 * q + 1] = v[1];
+            acc[ob][4 * q + 2] = v[2]; acc[ob][4 * q + 3] = v[3];
+        }
+    }
+}
+
+// Stores registers [P0, P0 + NP) (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
+template <int P0, int NP, int NB>
+__device__ __forceinline__ void store_rows_part(const RowIO& io, const f32x16 (&v)[NB]) {
+#pragma unroll
+    for (int p = P0; p < P0 + NP; ++p) {
+        const int row = 32 * (p >> 4) + ((p & 15) & 3) + 8 * ((p & 15) >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[p >> 4][p & 15]), io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, DMN_STORE_AUX);
     }
 }
 

@@ -38,129 +38,233 @@ struct MlpArgs {
 
 template <int OBI, bool EMBEDDED, bool SAVE>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 16 KiB]
+    float* const tab = lds + RING_FLOATS;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // 32-sample block of this wave
-    if (blk * 32 >= a.M) return;                                          // wave-uniform
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Every wave of the workgroup takes part in the DMA + barrier protocol; a wave beyond the end of
+    // the batch (only in the last workgroup) recomputes the last block and stores nothing.
+    const int64_t nblk = (a.M + 31) / 32;
+    const int64_t blk_raw = (int64_t)blockIdx.x * 4 + wave;
+    const bool wave_active = blk_raw < nblk;
+    const int64_t blk = wave_active ? blk_raw : nblk - 1;
     const int64_t m_raw = blk * 32 + (lane & 31);
-    const bool valid = m_raw < a.M;
-    const int64_t m = valid ? m_raw : a.M - 1;                            // tail lanes recompute the last sample
+    const bool valid = wave_active && m_raw < a.M;
+    const int64_t m = m_raw < a.M ? m_raw : a.M - 1;                      // tail lanes recompute the last sample
 
     const float* __restrict__ blob = a.blob;
     const BlobLayout& L = a.L;
-    const rsrc_t rs = make_rsrc(blob, L.total);
-    const int voff = lane * 16;     // per-lane byte offset inside a 1 KiB (64 x float4) weight row
-    const int hoff = half * 64;     // per-half byte offset inside a bias row pair
 
-    f32x16 pe[2];   // 32 k-pairs of the position encoding (63 columns + pad)
-    f32x16 de[1];   // 16 k-pairs of the direction encoding (27 columns + pad)
+    // ---- inputs first (their loads are the oldest VMEM ops), then the table, then the first two quarters
+    float pt[3], vd[3];
+    const float* xr = nullptr;
     if constexpr (EMBEDDED) {
-        const float* xr = a.x + m * (POS_CH + DIR_CH);
-        load_encoded<POS_L, 2>(xr, pe, half);
-        load_encoded<DIR_L, 1>(xr + POS_CH, de, half);
+        xr = a.x + m * (POS_CH + DIR_CH);
     } else {
         const int64_t n = m / a.S;
         const float ox = a.rays_o[n * 3 + 0], oy = a.rays_o[n * 3 + 1], oz = a.rays_o[n * 3 + 2];
         const float dx = a.rays_d[n * 3 + 0], dy = a.rays_d[n * 3 + 1], dz = a.rays_d[n * 3 + 2];
         const float zv = a.z[m];
         // pts = rays_o + rays_d * z   (render.py:49: separate multiply and add, no fma)
-        const float pt[3] = {ox + dx * zv, oy + dy * zv, oz + dz * zv};
+        pt[0] = ox + dx * zv; pt[1] = oy + dy * zv; pt[2] = oz + dz * zv;
         // viewdirs = rays_d / ||rays_d||   (render.py:37)
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float vd[3] = {dx / nrm, dy / nrm, dz / nrm};
+        vd[0] = dx / nrm; vd[1] = dy / nrm; vd[2] = dz / nrm;
+    }
+    f32x16 pe[2];   // 32 k-pairs of the position encoding (63 columns + pad)
+    f32x16 de[1];   // 16 k-pairs of the direction encoding (27 columns + pad)
+    if constexpr (EMBEDDED) {
+        load_encoded<POS_L, 2>(xr, pe, half);
+        load_encoded<DIR_L, 1>(xr + POS_CH, de, half);
+    }
+    {   // biases + VALU heads -> LDS table
+        const f32x4* src = reinterpret_cast<const f32x4*>(blob) + threadIdx.x;
+        f32x4* dst = reinterpret_cast<f32x4*>(tab) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < TAB_FLOATS / 1024; ++k) dst[k * 256] = src[k * 256];
+    }
+    WStream ws;
+    ws.gsrc = reinterpret_cast<const char*>(blob) + lane * 16 + wave * 1024;
+    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(L.stream * 4); ws.fslot = 0; ws.cslot = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // inputs + table landed: the counters below start clean
+    ws_fetch(ws);                                                         // quarter 0: mlps.0
+    ws_fetch(ws);                                                         // quarter 1: first quarter of stage 0
+    if constexpr (!EMBEDDED) {                                            // full-range sin/cos under the DMA flight
         encode<POS_L, 2>(pt, pe, half);
         encode<DIR_L, 1>(vd, de, half);
     }
 
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);          // padded row length of the training workspace
-    if constexpr (SAVE) {                          // tail lanes write the padding columns of the last block
-        store_encoded_rows<POS_L, 2>(a.save + SL.pe, MP, blk, lane, pe);
-        store_encoded_rows<DIR_L, 1>(a.save + SL.de, MP, blk, lane, de);
-    }
+    const int srows = wave_active ? 1 : 0;         // an inactive wave gets empty descriptors: its stores are bounds-checked no-ops
+    constexpr int Y0 = DMA_PER_QUARTER;            // younger VMEM ops at an acquire whose preceding boundary stored nothing
+    constexpr int YS = SAVE ? DMA_PER_QUARTER + 43 : DMA_PER_QUARTER;   // ... preceded by a 43-store batch
 
     f32x16 h[8], acc[8];
-    // mlps.0 : 63 -> 256
-    init_bias<8>(rs, (int)L.b0, acc, hoff);
-    gemm_seg<8, 8, 2>(rs, (int)L.w0, pe, acc, voff);
+    // ---- mlps.0 : 63 -> 256 (quarter 0)
+    ws_acquire<Y0>();
+    if constexpr (SAVE) {                          // issued after the acquire: 90 stores with a whole quarter to retire
+        store_encoded_rows<POS_L, 2>(a.save + SL.pe, srows * MP, blk, lane, pe);
+        store_encoded_rows<DIR_L, 1>(a.save + SL.de, srows * MP, blk, lane, de);
+    }
+    init_bias_lds<8>(tab + L.b0, acc, half);
+    gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, pe, acc, lane);
+    ws.cslot ^= 1;
+    ws_release_barrier();
+    ws_fetch(ws);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
-    // Activation saves are issued as one burst per layer.  (Interleaving them into the next layer's
-    // MFMA stream was measured SLOWER, 14.3 vs 12.2 ms: vmcnt retires in order, so every later
-    // weight-load wait then also waits for a store acknowledgement.)
-    if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h, 256, MP, blk, lane), h);
 
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
 
+    // One 256 -> 256 stage = 4 quarters.  Stage st consumes h_st (st = 0..7; st = 8 re-reads h_7): training
+    // saves it in three batches at the quarter boundaries, BEFORE the next DMA is issued, so that DMA
+    // stays older than them (see mlp_common.h).  The body is instantiated three times (trunk loop,
+    // rgb_feature, ins_feature) to keep the register live ranges of the two heads out of the loop.
+    auto stage = [&](int st) {
+        RowIO hio;
+        if constexpr (SAVE) hio = make_rowio(a.save + SL.h + (int64_t)(st < 8 ? st : 7) * 256 * MP, 256, (st < 8 ? srows : 0) * MP, blk, lane);
+        ws_acquire<Y0>();
+        init_bias_lds<8>(tab + L.b_stage + st * (int)bias_floats(8), acc, half);
+        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<0, 43>(hio, h);
+        ws_fetch(ws);
+        ws_acquire<YS>();
+        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<43, 43>(hio, h);
+        ws_fetch(ws);
+        ws_acquire<YS>();
+        gemm_quarter<16, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<86, 42>(hio, h);
+        ws_fetch(ws);
+        ws_acquire<SAVE ? DMA_PER_QUARTER + 42 : DMA_PER_QUARTER>();
+        gemm_quarter<24, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
+    };
+
+    // ---- trunk: mlps.1 .. mlps.7
 #pragma nounroll
-    for (int st = 0; st < NSTAGE; ++st) {
-        init_bias<8>(rs, (int)L.b_stage + st * (int)bias_floats(8), acc, hoff);
-        gemm_seg<32, 8, 8>(rs, (int)L.w_stage + st * (int)seg_floats(32, 8), h, acc, voff);
-        if (st == 4) gemm_seg<8, 8, 2>(rs, (int)L.w5pe, pe, acc, voff);   // skip: cat[h, pts] (dm_nerf.py:87)
-        if (st < 7) {
+    for (int st = 0; st < 7; ++st) {
+        stage(st);
+        if (st == 4) {                                                    // skip: cat[h, pts] (dm_nerf.py:87)
+            ws_acquire<Y0>();
+            gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, pe, acc, lane);
+            ws.cslot ^= 1;
+            ws_release_barrier();
+            ws_fetch(ws);
+        }
 #pragma unroll
-            for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.h + (int64_t)(st + 1) * 256 * MP, 256, MP, blk, lane), h);
-            if (st == 6) {
-                // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
-                float part = 0.f;
+        for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+    }
+    {
+        // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
+        const f32x4* wd = reinterpret_cast<const f32x4*>(tab + L.w_den + half * 128);
+        float part = 0.f;
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const f32x4 w = ldw(rs, half * 512, ((int)L.w_den + 4 * i) * 4);
+        for (int i = 0; i < 32; ++i) {
+            const f32x4 w = wd[i];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int p = 4 * i + j;
-                        part = fmaf(h[p >> 4][p & 15], w[j], part);
-                    }
-                }
-                sigma = part + __shfl_xor(part, 32) + blob[L.b_den];
+            for (int j = 0; j < 4; ++j) {
+                const int p = 4 * i + j;
+                part = fmaf(h[p >> 4][p & 15], w[j], part);
             }
-        } else if (st == 7) {
-            // acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
-            f32x16 hid[4];
-            init_bias<4>(rs, (int)L.b_rgbh, hid, hoff);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.f, 256, MP, blk, lane), acc);
-            gemm_seg<32, 4, 8>(rs, (int)L.w_rgbh, acc, hid, voff);
-            gemm_seg<4, 4, 1>(rs, (int)L.w_rgbh_dir, de, hid, voff);
+        }
+        sigma = part + __shfl_xor(part, 32) + tab[L.b_den];
+    }
+
+    // ---- rgb branch: acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
+    stage(7);
+    {
+        RowIO fio;
+        if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
+        f32x16 hid[4];
+        ws_acquire<Y0>();
+        init_bias_lds<4>(tab + L.b_rgbh, hid, half);
+        gemm_quarter<0, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<0, 43>(fio, acc);
+        ws_fetch(ws);
+        ws_acquire<YS>();
+        gemm_quarter<16, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<43, 43>(fio, acc);
+        ws_fetch(ws);
+        ws_acquire<YS>();
+        gemm_quarter<0, 4, 4>(lds + ws.cslot * SLOT_FLOATS, de, hid, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<86, 42>(fio, acc);
+        ws_fetch(ws);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, MP, blk, lane), hid);
-            // rgb_linear (dm_nerf.py:102) on the VALU
+        for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
+        // (these 64 stores are younger than the DMA above: stage 8's first acquire over-waits once per block)
+        if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, srows * MP, blk, lane), hid);
+        // rgb_linear (dm_nerf.py:102) on the VALU
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float part = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const f32x4* wr = reinterpret_cast<const f32x4*>(tab + L.w_rgbo + (c * 2 + half) * 64);
+            float part = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const f32x4 w = ldw(rs, half * 256, ((int)L.w_rgbo + c * 128 + 4 * i) * 4);
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 w = wr[i];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int p = 4 * i + j;
-                        part = fmaf(hid[p >> 4][p & 15], w[j], part);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int p = 4 * i + j;
+                    part = fmaf(hid[p >> 4][p & 15], w[j], part);
                 }
-                rgb_out[c] = part + __shfl_xor(part, 32) + blob[L.b_rgbo + c];
             }
-        } else {
-            // acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
-            f32x16 hid[4];
-            init_bias<4>(rs, (int)L.b_insh, hid, hoff);
-            if constexpr (SAVE) store_rows<8>(make_rowio(a.save + SL.q, 256, MP, blk, lane), acc);
-            gemm_seg<32, 4, 8>(rs, (int)L.w_insh, acc, hid, voff);
+            rgb_out[c] = part + __shfl_xor(part, 32) + tab[L.b_rgbo + c];
+        }
+    }
+
+    // ---- ins branch: acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
+    stage(8);
+    {
+        RowIO qio;
+        if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);
+        f32x16 hid[4];
+        ws_acquire<Y0>();
+        init_bias_lds<4>(tab + L.b_insh, hid, half);
+        gemm_quarter<0, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<0, 43>(qio, acc);
+        ws_fetch(ws);                                                 // (runs into the zero-filled landing zone)
+        ws_acquire<YS>();
+        gemm_quarter<16, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        if constexpr (SAVE) store_rows_part<43, 43>(qio, acc);
+        ws_fetch(ws);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-            if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g2, 128, MP, blk, lane), hid);
-            f32x16 io[OBI];
-            init_bias<OBI>(rs, (int)L.b_inso, io, hoff);
-            gemm_seg<16, OBI, 4>(rs, (int)L.w_inso, hid, io, voff);     // ins_linear (:103)
-            if (valid) {
+        for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
+        ws_acquire<YS>();
+        if constexpr (SAVE) {
+            store_rows_part<86, 42>(qio, acc);
+            store_rows<4>(make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane), hid);
+        }
+        f32x16 io[OBI];
+        init_bias_lds<OBI>(tab + L.b_inso, io, half);
+        gemm_quarter<0, 16, OBI>(lds + ws.cslot * SLOT_FLOATS, hid, io, lane);     // ins_linear (:103)
+        if (valid) {
 #pragma unroll
-                for (int b = 0; b < OBI; ++b) {
+            for (int b = 0; b < OBI; ++b) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (ch < L.C) out_row[4 + ch] = io[b][r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (ch < L.C) out_row[4 + ch] = io[b][r];
                 }
             }
         }
@@ -183,13 +287,26 @@ int launch(const MlpArgs& a, hipStream_t stream) {
         return dmn_fail(DMNERF_E_ARG, "mlp_fwd_train: %lld samples per launch exceed %lld (32-bit row offsets); split the batch",
                         (long long)a.M, (long long)DMNERF_MAX_TRAIN_SAMPLES);
     dim3 g((unsigned)grid), b(256);
+    constexpr size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);      // 147 456 B: one workgroup per CU
+#define DMN_LAUNCH(OBI_)                                                                                              \
+    {                                                                                                                \
+        static bool attr_done = false;                                                                               \
+        if (!attr_done) {                                                                                            \
+            if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<OBI_, EMBEDDED, SAVE>,                                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)       \
+                return dmn_check_launch("mlp_fwd: hipFuncSetAttribute");                                             \
+            attr_done = true;                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL((mlp_fwd_kernel<OBI_, EMBEDDED, SAVE>), g, b, lds_bytes, stream, a);                       \
+    }
     switch (a.L.OBI) {
-        case 1: hipLaunchKernelGGL((mlp_fwd_kernel<1, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((mlp_fwd_kernel<2, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((mlp_fwd_kernel<3, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((mlp_fwd_kernel<4, EMBEDDED, SAVE>), g, b, 0, stream, a); break;
+        case 1: DMN_LAUNCH(1) break;
+        case 2: DMN_LAUNCH(2) break;
+        case 3: DMN_LAUNCH(3) break;
+        case 4: DMN_LAUNCH(4) break;
         default: return dmn_fail(DMNERF_E_ARG, "mlp_fwd: unsupported logit count C=%d", a.L.C);
     }
+#undef DMN_LAUNCH
     return dmn_check_launch("mlp_fwd");
 }
 

@@ -112,7 +112,7 @@ extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx)
     const Lin* stage[NSTAGE] = {&P.mlps[1], &P.mlps[2], &P.mlps[3], &P.mlps[4], &P.mlps[5],
                                 &P.mlps[6], &P.mlps[7], &P.rgb_feature, &P.ins_feature};
     for (int s = 0; s < NSTAGE; ++s) {
-        fill_seg(idx, L.w_stage + s * seg_floats(32, 8), *stage[s], 32, 8, K_ACC, 0);
+        fill_seg(idx, stage_off(L, s), *stage[s], 32, 8, K_ACC, 0);
         fill_bias(idx, L.b_stage + s * bias_floats(8), *stage[s], 8);
     }
     fill_seg(idx, L.w5pe, P.mlps[5], 8, 8, K_POS, W);            // skip concat [h, pts] (dm_nerf.py:87)

@@ -34,22 +34,28 @@ def mfma(a, b, c):
 
 
 def layout(ins_num):
+    """Python mirror of csrc/layout.h::make_layout: [table | weight stream in consumption order | 2 dummy quarters]."""
     C = ins_num + 1
     OBI = (C + 31) // 32
-    o = 0
+    Q = 16384
     L = {}
+    o = 0
     def take(name, n):
         nonlocal o
         L[name] = o; o += n
-    take("w0", 8 * 8 * 256); take("b0", 256)
-    take("w_stage", 9 * 32 * 8 * 256); take("b_stage", 9 * 256)
-    take("w5pe", 8 * 8 * 256)
-    take("w_rgbh", 32 * 4 * 256); take("w_rgbh_dir", 4 * 4 * 256); take("b_rgbh", 128)
-    take("w_insh", 32 * 4 * 256); take("b_insh", 128)
-    take("w_inso", 16 * OBI * 256); take("b_inso", OBI * 32)
+    take("b0", 256); take("b_stage", 9 * 256); take("b_rgbh", 128); take("b_insh", 128); take("b_inso", OBI * 32)
     take("w_den", 256); take("b_den", 4); take("w_rgbo", 384); take("b_rgbo", 4)
+    assert o <= 4096
+    o = 4096
+    take("w0", Q); take("w_stage_lo", 5 * 65536); take("w5pe", Q); take("w_stage_mid", 3 * 65536)
+    take("w_rgbh", 32768); take("w_rgbh_dir", Q); take("w_stage_hi", 65536); take("w_insh", 32768); take("w_inso", Q)
+    o += 2 * Q
     L["total"] = o; L["OBI"] = OBI; L["C"] = C
     return L
+
+
+def stage_off(L, st):
+    return L["w_stage_lo"] + st * 65536 if st < 5 else (L["w_stage_mid"] + (st - 5) * 65536 if st < 8 else L["w_stage_hi"])
 
 
 def gemm_seg(blob, seg, nkg, ob_n, B, acc):
@@ -91,7 +97,7 @@ def emulate_wave(blob, ins_num, x):
     raw = np.zeros((32, 4 + L["C"]))
     for st in range(9):
         acc = init_bias(blob, L["b_stage"] + st * 256, 8)
-        acc = gemm_seg(blob, L["w_stage"] + st * 65536, 32, 8, h, acc)
+        acc = gemm_seg(blob, stage_off(L, st), 32, 8, h, acc)
         if st == 4:
             acc = gemm_seg(blob, L["w5pe"], 8, 8, pe, acc)
         if st < 7:
