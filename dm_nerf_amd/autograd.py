@@ -100,12 +100,10 @@ class MLPRaysFunction(torch.autograd.Function):
         C = ins_num + 1
         g = _lib.f32(g_raw).reshape(M, 4 + C)
         dsave = torch.empty_like(ctx.save)
-        _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
-                                           _lib.ptr(dsave), _lib.stream()), "dmnerf_mlp_bwd_data")
-        # dL/draw in the block-major form of the workspace ([block][4+C rows][32 samples]), zero padded
         Mp = _row_len(M)
-        gp = g if Mp == M else torch.nn.functional.pad(g, (0, 0, 0, Mp - M))
-        gt = gp.view(Mp // 32, 32, 4 + C).permute(0, 2, 1).contiguous()
+        gt = torch.empty(Mp // 32, 4 + C, 32, dtype=torch.float32, device=g.device)   # d raw, block-major, written by the kernel
+        _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                                           _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
         jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
         part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)

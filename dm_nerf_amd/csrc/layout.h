@@ -119,8 +119,13 @@ DMN_HD inline BlobLayout make_layout(int ins_num) {
 // Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
 //   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
 constexpr int NSTAGE_T = 8;   // rgb_feature^T, mlps.7^T .. mlps.1^T (mlps.5: its 256 h-columns)
+constexpr int TAB_T_FLOATS = 1024;       // table of the backward blob: the two VALU heads (4 KiB)
+// Backward blob = [table: w_rgbo [c][half][64] | w_den [half][128]] [stream: ins_linear^T (1 padded quarter) |
+// ins_feature_linears.0^T (2) | rgb_feature_linears.0^T (2) | 8 stages x 4] [2 dummy quarters].
 struct BlobTLayout {
     int C, OBI;
+    int64_t w_rgbo, w_den;   // table
+    int64_t stream;
     int64_t t_inso;     // ins_linear^T:            K = 32*OBI logits (NKG = 4*OBI), rows 128 (OB = 4)
     int64_t t_insh;     // ins_feature_linears.0^T: K = 128 (NKG = 16), rows 256 (OB = 8)
     int64_t t_rgbh;     // rgb_feature_linears.0^T: K = 128 (NKG = 16), rows 256 = the rgb_feature columns (OB = 8)
@@ -131,23 +136,31 @@ DMN_HD inline BlobTLayout make_layout_t(int ins_num) {
     BlobTLayout L;
     L.C = ins_num + 1;
     L.OBI = (L.C + 31) / 32;
-    int64_t o = 0;
-    L.t_inso = o; o += seg_floats(4 * L.OBI, 4);
+    L.w_rgbo = 0;
+    L.w_den = 3 * 2 * 64;
+    int64_t o = TAB_T_FLOATS;
+    L.stream = o;
+    L.t_inso = o; o += QUARTER_FLOATS;
     L.t_insh = o; o += seg_floats(16, 8);
     L.t_rgbh = o; o += seg_floats(16, 8);
     L.t_stage = o; o += NSTAGE_T * seg_floats(32, 8);
+    o += 2 * QUARTER_FLOATS;
     L.total = o;
     return L;
 }
 
 // Training workspace: activations saved by the forward for the backward, every tensor stored
 // feature-major [rows][M] (row = feature in reference order, column = sample).
-constexpr int SAVE_ROWS = POS_CH + DIR_CH + 8 * W + W + W + HW + HW;   // 2906
+// 1-bit ReLU masks: per 32-sample block [8 layers][64 lanes][4 words] + [g1][64][2] + [g2][64][2] words;
+// word (p >> 5) bit (p & 31) of a lane = (activation register p of that lane > 0), p = 16 b + r.
+constexpr int BITS_WORDS_PER_BLOCK = 8 * 64 * 4 + 2 * 64 * 2;          // 2304 = 72 per sample
+constexpr int SAVE_ROWS = POS_CH + DIR_CH + 8 * W + W + W + HW + HW + BITS_WORDS_PER_BLOCK / 32;   // 2978
 struct SaveLayout {
     int64_t pe, de;      // embed(pts) [63][M], embed(viewdirs) [27][M]
     int64_t h;           // relu outputs of mlps.0..7: [8][256][M]
     int64_t f, q;        // rgb_feature / ins_feature (no activation): [256][M] each
     int64_t g1, g2;      // relu outputs of rgb_feature_linears.0 / ins_feature_linears.0: [128][M] each
+    int64_t bits;        // ReLU bit masks, BITS_WORDS_PER_BLOCK words per block (forward workspace only)
     int64_t total;
 };
 // Row length: M rounded up to a multiple of 32 so that a wave's 32-sample block never straddles
@@ -165,6 +178,7 @@ DMN_HD inline SaveLayout make_save_layout(int64_t M_samples) {
     s.q = o; o += (int64_t)W * M;
     s.g1 = o; o += (int64_t)HW * M;
     s.g2 = o; o += (int64_t)HW * M;
+    s.bits = o; o += (int64_t)(BITS_WORDS_PER_BLOCK / 32) * M;
     s.total = o;
     return s;
 }

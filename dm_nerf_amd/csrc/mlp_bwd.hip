@@ -30,16 +30,9 @@ struct BwdArgs {
     const float* save;     // forward activations (SaveLayout)
     const float* graw;     // [M, 4+C]
     float* dsave;          // gradients, same SaveLayout (rows of pe/de unused)
+    float* graw_t;         // optional: d raw in block-major form [blk][4+C][32] for the weight-gradient kernel
     int64_t M;
 };
-
-template <int NB>
-__device__ __forceinline__ void mask_relu(f32x16 (&d)[NB], const f32x16 (&act)[NB], const f32x16 (&g)[NB]) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[b][r] = act[b][r] > 0.f ? g[b][r] : 0.f;      // relu backward: grad * (result > 0)
-}
 
 template <int NB>
 __device__ __forceinline__ void zero(f32x16 (&v)[NB]) {
@@ -47,25 +40,31 @@ __device__ __forceinline__ void zero(f32x16 (&v)[NB]) {
     for (int b = 0; b < NB; ++b) v[b] = (f32x16)(0.f);
 }
 
+// Same LDS weight-streaming engine as the forward (mlp_common.h): the W^T stream is consumed one 64 KiB
+// quarter at a time, fetched two quarters ahead; the dy stores of a stage are issued in three batches
+// at the quarter boundaries of the NEXT stage (while dy is its B operand), always before the next DMA.
 template <int OBI>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 4 KiB]
+    float* const tab = lds + RING_FLOATS;
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk * 32 >= a.M) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nblk = (a.M + 31) / 32;
+    const int64_t blk_raw = (int64_t)blockIdx.x * 4 + wave;
+    const bool wave_active = blk_raw < nblk;
+    const int64_t blk = wave_active ? blk_raw : nblk - 1;
     const int64_t m_raw = blk * 32 + (lane & 31);
-    const bool valid = m_raw < a.M;
-    const int64_t m = valid ? m_raw : a.M - 1;
+    const bool valid = wave_active && m_raw < a.M;
+    const int64_t m = m_raw < a.M ? m_raw : a.M - 1;
 
     const BlobLayout& L = a.L;
     const BlobTLayout& LT = a.LT;
-    const rsrc_t rsF = make_rsrc(a.blob, L.total);
-    const rsrc_t rsT = make_rsrc(a.blobT, LT.total);
-    const int voff = lane * 16;
     const SaveLayout SL = make_save_layout(a.M);
-    const int64_t M = save_row_len(a.M);            // padded row length (see layout.h)
+    const int64_t MP = save_row_len(a.M);
+    const int srows = wave_active ? 1 : 0;           // inactive waves: empty descriptors, stores become no-ops
 
-    // ---- incoming gradient of this lane's sample --------------------------------------------
+    // ---- oldest VMEM ops: incoming gradient, ReLU bit masks, table --------------------------------
     const float* __restrict__ gr = a.graw + m * (4 + L.C);
     // tail lanes get a zero gradient: every dy they produce is then exactly 0, so the padding
     // columns contribute nothing to the weight / bias gradients
@@ -79,27 +78,83 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
             const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
             gi[b][r] = (ch < L.C && valid) ? gr[4 + ch] : 0.f;
         }
+    unsigned hbits[8][4], g1bits[2], g2bits[2];
+    {
+        const unsigned* bw = reinterpret_cast<const unsigned*>(a.save + SL.bits) + blk * BITS_WORDS_PER_BLOCK;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(bw + l * 256 + lane * 4);
+            hbits[l][0] = v[0]; hbits[l][1] = v[1]; hbits[l][2] = v[2]; hbits[l][3] = v[3];
+        }
+        g1bits[0] = bw[2048 + lane * 2]; g1bits[1] = bw[2048 + lane * 2 + 1];
+        g2bits[0] = bw[2176 + lane * 2]; g2bits[1] = bw[2176 + lane * 2 + 1];
+    }
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.blobT) + threadIdx.x;
+        reinterpret_cast<f32x4*>(tab)[threadIdx.x] = src[0];              // TAB_T_FLOATS = 1024 = 256 x float4
+    }
+    // d raw transposed for the weight-gradient kernel: [blk][4+C rows][32]
+    if (a.graw_t) {
+        const int GR = 4 + L.C;
+        rsrc_t grs = uniform_rsrc(a.graw_t, (int64_t)srows * GR * MP);
+        const int gv = (int)((blk * GR * 32 + (lane & 31)) * 4);
+        if (half == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[0]), grs, gv, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[1]), grs, gv + 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[2]), grs, gv + 256, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_sigma), grs, gv + 384, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < OBI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ch < L.C) __builtin_amdgcn_raw_buffer_store_b32(f2u(gi[b][r]), grs, gv + (4 + ch) * 128, 0, 0);
+            }
+    }
+    WStream ws;
+    ws.gsrc = reinterpret_cast<const char*>(a.blobT) + lane * 16 + wave * 1024;
+    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(LT.stream * 4); ws.fslot = 0; ws.cslot = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // inputs, masks, table: counters start clean
+    ws_fetch(ws);                                                         // quarter 0: ins_linear^T
+    ws_fetch(ws);                                                         // quarter 1: ins_feature_linears.0^T, first half
+    constexpr int Y0 = DMA_PER_QUARTER;
+    constexpr int YS = DMA_PER_QUARTER + 43;
+    constexpr int YMAX = 63;                                              // "everything but the newest 63": used after a burst
 
     f32x16 d[8], acc[8];
     {
         // ---- ins branch: dg2 = relu'(g2) . (W_io^T g_ins);  dq = W_ih^T dg2 ----------------------
-        f32x16 t4[4], act4[4], d4[4];
+        f32x16 t4[4], d4[4];
         zero<4>(t4);
-        gemm_seg<4 * OBI, 4, OBI>(rsT, (int)LT.t_inso, gi, t4, voff);
-        load_rows<4>(make_rowio(a.save + SL.g2, 128, M, blk, lane), act4);
-        mask_relu<4>(d4, act4, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g2, 128, M, blk, lane), d4);
+        ws_acquire<Y0>();
+        gemm_quarter<0, 4 * OBI, 4>(lds + ws.cslot * SLOT_FLOATS, gi, t4, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
+        apply_mask<4>(d4, g2bits, t4);
+        store_rows<4>(make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane), d4);     // burst (once per block)
         zero<8>(acc);
-        gemm_seg<16, 8, 4>(rsT, (int)LT.t_insh, d4, acc, voff);
-        store_rows<8>(make_rowio(a.dsave + SL.q, 256, M, blk, lane), acc);      // dq (ins_feature has no activation)
+        ws_acquire<YMAX>();
+        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
+        ws_acquire<Y0>();
+        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
+        store_rows<8>(make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane), acc);      // dq (ins_feature has no activation)
 
         // ---- rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU;  df = (W_rh^T dg1)[:256] ----
         zero<4>(t4);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            const f32x4* wr = reinterpret_cast<const f32x4*>(tab + LT.w_rgbo + (c * 2 + half) * 64);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const f32x4 w = ldw(rsF, half * 256, ((int)L.w_rgbo + c * 128 + 4 * i) * 4);
+                const f32x4 w = wr[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int p = 4 * i + j;
@@ -107,26 +162,58 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
                 }
             }
         }
-        load_rows<4>(make_rowio(a.save + SL.g1, 128, M, blk, lane), act4);
-        mask_relu<4>(d4, act4, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, M, blk, lane), d4);
+        apply_mask<4>(d4, g1bits, t4);
+        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);
         zero<8>(acc);
-        gemm_seg<16, 8, 4>(rsT, (int)LT.t_rgbh, d4, acc, voff);
-        store_rows<8>(make_rowio(a.dsave + SL.f, 256, M, blk, lane), acc);      // df (rgb_feature has no activation)
+        ws_acquire<YMAX>();
+        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
+        ws_acquire<Y0>();
+        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) d[b] = acc[b];
+        for (int b = 0; b < 8; ++b) d[b] = acc[b];                        // df (rgb_feature has no activation)
     }
 
     // ---- trunk: st = 0: dh_7 = W_rf^T df + w_d g_sigma;  st = k: dh_{7-k} = W_{8-k}^T dy_{8-k} -----
+    // The stage's input d (df, then dy_7 .. dy_1) is saved while it is consumed.
 #pragma nounroll
     for (int st = 0; st < NSTAGE_T; ++st) {
+        const RowIO dio = make_rowio(st == 0 ? a.dsave + SL.f : a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
         zero<8>(acc);
-        gemm_seg<32, 8, 8>(rsT, (int)LT.t_stage + st * (int)seg_floats(32, 8), d, acc, voff);
+        ws_acquire<Y0>();
+        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        store_rows_part<0, 43>(dio, d);
+        ws_fetch(ws);
+        ws_acquire<YS>();
+        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        store_rows_part<43, 43>(dio, d);
+        ws_fetch(ws);
+        ws_acquire<YS>();
+        gemm_quarter<16, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        store_rows_part<86, 42>(dio, d);
+        ws_fetch(ws);
+        ws_acquire<DMA_PER_QUARTER + 42>();
+        gemm_quarter<24, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
+        ws.cslot ^= 1;
+        ws_release_barrier();
+        ws_fetch(ws);
         if (st == 0) {
             // density_linear (dm_nerf.py:101): dh_7 += w_d * g_sigma
+            const f32x4* wd = reinterpret_cast<const f32x4*>(tab + LT.w_den + half * 128);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                const f32x4 w = ldw(rsF, half * 512, ((int)L.w_den + 4 * i) * 4);
+                const f32x4 w = wd[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int p = 4 * i + j;
@@ -134,33 +221,51 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
                 }
             }
         }
-        const int l = 7 - st;                                   // layer whose pre-activation gradient this is
-        f32x16 act[8];
-        load_rows<8>(make_rowio(a.save + SL.h + (int64_t)l * 256 * M, 256, M, blk, lane), act);
-        mask_relu<8>(d, act, acc);
-        store_rows<8>(make_rowio(a.dsave + SL.h + (int64_t)l * 256 * M, 256, M, blk, lane), d);
+        // dy_l = dh_l . relu'(h_l), l = 7 - st: the bit masks were loaded up front; select the layer with a
+        // wave-uniform switch (register arrays cannot be indexed dynamically)
+        unsigned mb[4];
+        switch (7 - st) {
+#define DMN_PICK(l_) case l_: mb[0] = hbits[l_][0]; mb[1] = hbits[l_][1]; mb[2] = hbits[l_][2]; mb[3] = hbits[l_][3]; break;
+            DMN_PICK(0) DMN_PICK(1) DMN_PICK(2) DMN_PICK(3) DMN_PICK(4) DMN_PICK(5) DMN_PICK(6) default: DMN_PICK(7)
+#undef DMN_PICK
+        }
+        apply_mask<8>(d, mb, acc);
     }
+    store_rows<8>(make_rowio(a.dsave + SL.h, 256, srows * MP, blk, lane), d);             // dy_0
 }
 
 }  // namespace
 
 extern "C" int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num, const float* d_save,
-                                   const float* d_graw, int64_t M, float* d_dsave, void* stream) {
+                                   const float* d_graw, int64_t M, float* d_dsave, float* d_graw_t, void* stream) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data: ins_num %d unsupported", ins_num);
     if (M < 0 || M > DMNERF_MAX_TRAIN_SAMPLES) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data: M=%lld outside [0,%lld]", (long long)M, (long long)DMNERF_MAX_TRAIN_SAMPLES);
     if (M == 0) return DMNERF_OK;
     if (!d_blob || !d_blob_t || !d_save || !d_graw || !d_dsave) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data: null pointer");
     BwdArgs a{};
     a.blob = d_blob; a.blobT = d_blob_t; a.L = make_layout(ins_num); a.LT = make_layout_t(ins_num);
-    a.save = d_save; a.graw = d_graw; a.dsave = d_dsave; a.M = M;
+    a.save = d_save; a.graw = d_graw; a.dsave = d_dsave; a.graw_t = d_graw_t; a.M = M;
     const int64_t nblk = (M + 31) / 32;
     dim3 g((unsigned)((nblk + 3) / 4)), b(256);
+    constexpr size_t lds_bytes = (size_t)(RING_FLOATS + TAB_T_FLOATS) * sizeof(float);
+#define DMN_LAUNCH(OBI_)                                                                                          \
+    {                                                                                                            \
+        static bool attr_done = false;                                                                           \
+        if (!attr_done) {                                                                                        \
+            if (hipFuncSetAttribute((const void*)mlp_bwd_kernel<OBI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds_bytes) != hipSuccess)                                               \
+                return dmn_check_launch("mlp_bwd_data: hipFuncSetAttribute");                                    \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(mlp_bwd_kernel<OBI_>, g, b, lds_bytes, (hipStream_t)stream, a);                        \
+    }
     switch (a.L.OBI) {
-        case 1: hipLaunchKernelGGL(mlp_bwd_kernel<1>, g, b, 0, (hipStream_t)stream, a); break;
-        case 2: hipLaunchKernelGGL(mlp_bwd_kernel<2>, g, b, 0, (hipStream_t)stream, a); break;
-        case 3: hipLaunchKernelGGL(mlp_bwd_kernel<3>, g, b, 0, (hipStream_t)stream, a); break;
-        case 4: hipLaunchKernelGGL(mlp_bwd_kernel<4>, g, b, 0, (hipStream_t)stream, a); break;
+        case 1: DMN_LAUNCH(1) break;
+        case 2: DMN_LAUNCH(2) break;
+        case 3: DMN_LAUNCH(3) break;
+        case 4: DMN_LAUNCH(4) break;
         default: return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data: unsupported logit count C=%d", a.L.C);
     }
+#undef DMN_LAUNCH
     return dmn_check_launch("mlp_bwd_data");
 }

@@ -300,6 +300,27 @@ __device__ __forceinline__ void init_bias_lds(const float* tab_seg, f32x16 (&acc
     }
 }
 
+// ---- 1-bit ReLU masks (layout.h::BITS_WORDS_PER_BLOCK) ---------------------------------------------
+template <int NB>
+__device__ __forceinline__ void pack_mask(const f32x16 (&h)[NB], unsigned (&m)[NB / 2]) {
+#pragma unroll
+    for (int w = 0; w < NB / 2; ++w) {
+        unsigned v = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int p = 32 * w + i;
+            v |= (h[p >> 4][p & 15] > 0.f ? 1u : 0u) << i;          // relu backward: grad * (result > 0)
+        }
+        m[w] = v;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void apply_mask(f32x16 (&d)[NB], const unsigned (&m)[NB / 2], const f32x16 (&g)[NB]) {
+#pragma unroll
+    for (int p = 0; p < NB * 16; ++p) d[p >> 4][p & 15] = ((m[p >> 5] >> (p & 31)) & 1u) ? g[p >> 4][p & 15] : 0.f;
+}
+
 // Stores registers [P0, P0 + NP) (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
 template <int P0, int NP, int NB>
 __device__ __forceinline__ void store_rows_part(const RowIO& io, const f32x16 (&v)[NB]) {

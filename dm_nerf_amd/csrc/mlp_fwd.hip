@@ -98,10 +98,23 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);          // padded row length of the training workspace
     const int srows = wave_active ? 1 : 0;         // an inactive wave gets empty descriptors: its stores are bounds-checked no-ops
+    // ReLU bit masks for the backward pass (one 16-byte store per lane and layer instead of 128 row loads there)
+    rsrc_t bits_rs;
+    int bits_voff = 0;
+    if constexpr (SAVE) {
+        bits_rs = uniform_rsrc(a.save + SL.bits, (int64_t)srows * (BITS_WORDS_PER_BLOCK / 32) * MP);
+        bits_voff = (int)((blk * BITS_WORDS_PER_BLOCK + lane * 4) * 4);
+    }
     constexpr int Y0 = DMA_PER_QUARTER;            // younger VMEM ops at an acquire whose preceding boundary stored nothing
     constexpr int YS = SAVE ? DMA_PER_QUARTER + 43 : DMA_PER_QUARTER;   // ... preceded by a 43-store batch
 
     f32x16 h[8], acc[8];
+    auto save_mask8 = [&](int layer) {
+        unsigned m[4];
+        pack_mask<8>(h, m);
+        u32x4 v = {m[0], m[1], m[2], m[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, bits_rs, bits_voff + layer * 1024, 0, 0);
+    };
     // ---- mlps.0 : 63 -> 256 (quarter 0)
     ws_acquire<Y0>();
     if constexpr (SAVE) {                          // issued after the acquire: 90 stores with a whole quarter to retire
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     ws_fetch(ws);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+    if constexpr (SAVE) save_mask8(0);
 
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
@@ -165,6 +179,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         }
 #pragma unroll
         for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
+        if constexpr (SAVE) save_mask8(st + 1);
     }
     {
         // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
@@ -210,7 +225,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
         // (these 64 stores are younger than the DMA above: stage 8's first acquire over-waits once per block)
-        if constexpr (SAVE) store_rows<4>(make_rowio(a.save + SL.g1, 128, srows * MP, blk, lane), hid);
+        if constexpr (SAVE) {
+            store_rows<4>(make_rowio(a.save + SL.g1, 128, srows * MP, blk, lane), hid);
+            unsigned m[2];
+            pack_mask<4>(hid, m);
+            __builtin_amdgcn_raw_buffer_store_b32(m[0], bits_rs, (int)((blk * BITS_WORDS_PER_BLOCK + 2048 + lane * 2) * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(m[1], bits_rs, (int)((blk * BITS_WORDS_PER_BLOCK + 2048 + lane * 2 + 1) * 4), 0, 0);
+        }
         // rgb_linear (dm_nerf.py:102) on the VALU
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -254,6 +275,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         if constexpr (SAVE) {
             store_rows_part<86, 42>(qio, acc);
             store_rows<4>(make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane), hid);
+            unsigned m[2];
+            pack_mask<4>(hid, m);
+            __builtin_amdgcn_raw_buffer_store_b32(m[0], bits_rs, (int)((blk * BITS_WORDS_PER_BLOCK + 2176 + lane * 2) * 4), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(m[1], bits_rs, (int)((blk * BITS_WORDS_PER_BLOCK + 2176 + lane * 2 + 1) * 4), 0, 0);
         }
         f32x16 io[OBI];
         init_bias_lds<OBI>(tab + L.b_inso, io, half);

@@ -153,5 +153,12 @@ extern "C" int dmnerf_build_pack_index_t(int ins_num, int32_t* idx, int64_t n_id
     const Lin* stage[NSTAGE_T] = {&P.rgb_feature, &P.mlps[7], &P.mlps[6], &P.mlps[5], &P.mlps[4],
                                   &P.mlps[3], &P.mlps[2], &P.mlps[1]};
     for (int s = 0; s < NSTAGE_T; ++s) fill_seg_t(idx, L.t_stage + s * seg_floats(32, 8), *stage[s], 32, 8);
+    // table: the VALU heads in accumulator order (same packing as the forward table)
+    for (int c = 0; c < 3; ++c)
+        for (int half = 0; half < 2; ++half)
+            for (int q = 0; q < 64; ++q)
+                idx[L.w_rgbo + (c * 2 + half) * 64 + q] = (int32_t)P.rgb_out.w(c, cfeat(q, half));
+    for (int half = 0; half < 2; ++half)
+        for (int q = 0; q < 128; ++q) idx[L.w_den + half * 128 + q] = (int32_t)P.density.w(0, cfeat(q, half));
     return DMNERF_OK;
 }

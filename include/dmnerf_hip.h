@@ -139,11 +139,13 @@ int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_r
 /* Backward blob (W^T as MFMA A operand) and the data-gradient pass: dL/draw [M,4+C] + d_save ->
  * d_dsave (same layout as d_save): dy of mlps.0..7 in the h rows, d rgb_feature, d ins_feature,
  * d(rgb hidden pre-act), d(ins hidden pre-act).  Weight gradients are dW = dy . x^T over M.
+ * d_graw_t (nullable): receives dL/draw in block-major form [block][4+C][32] (zero padding columns),
+ * the third operand of dmnerf_mlp_bwd_weights.
  * Gradient barriers: h.detach() on the ins branch (dm_nerf.py:95); none to the encodings.     */
 int64_t dmnerf_blob_t_floats(int ins_num);
 int dmnerf_build_pack_index_t(int ins_num, int32_t* h_idx, int64_t n_idx);
 int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num, const float* d_save,
-                        const float* d_graw, int64_t M, float* d_dsave, void* stream);
+                        const float* d_graw, int64_t M, float* d_dsave, float* d_graw_t, void* stream);
 
 /* Weight / bias gradients dW = dy . x^T over the batch (split-K f32 MFMA, deterministic 2-stage sum).
  * The plan (which workgroup does which job slice) depends only on (ins_num, M, max_wgs): build it once
