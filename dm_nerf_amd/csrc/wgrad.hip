@@ -136,6 +136,9 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
         for (int k = 0; k < SP::SBn; ++k) brow[k] = cur + ((NBA + SP::sb(w, k)) * 32 + li) * LDS_STRIDE + 2 * half;
 #pragma unroll
         for (int t = 0; t < KT / 4; ++t) {
+            // half-way through the chunk the next tile (in flight since the top of the loop) is written to
+            // the other ring slot, so the ds_writes issue in the shadow of the remaining MFMAs
+            if (t == KT / 8 && more) write_chunk(lds + ((c + 1) & 1) * BUF);
             float2 av[SP::SAn], bv[SP::SBn];
 #pragma unroll
             for (int k = 0; k < SP::SAn; ++k) av[k] = *reinterpret_cast<const float2*>(arow[k] + 4 * t);
@@ -152,7 +155,6 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
                 if (do_bias) bsum[ia] += av[ia].x + av[ia].y;
             }
         }
-        if (more) write_chunk(lds + ((c + 1) & 1) * BUF);
         __syncthreads();
     }
 
