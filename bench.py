@@ -69,15 +69,18 @@ def build_models(device):
 
 def train_leg(mc, mf, ro, rd, z, steps, dev):
     """Secondary measurement: rays/s of one full optimisation step on a 4096-ray batch (64+128 samples,
-    perturb=1): dm_nerf forward with saved activations, losses, backward (HIP dgrad + composite_bwd,
-    weight gradients as GEMMs over the batch), Adam(lr 5e-4).  The reference's Hungarian ins_criterion
-    and penalizer are host/eager code outside the hot path (SURVEY 2 #7,#8); a dense surrogate with the
-    same gradient sparsity (MSE on rgb, on the object probabilities and a small term on raw[..., 4:]) is used."""
+    perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
+    levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
+    configs/dmsr/train/study.txt), an object-code loss, backward (composite_bwd, dgrad, wgrad kernels),
+    Adam(lr 5e-4).  The reference's object-code loss is a Hungarian-matched CE + soft-IoU solved by scipy on
+    the host (out of scope); a dense MSE on the same [N, ins_num] probabilities stands in for it
+    (identical gradient sparsity: only the ins head receives it)."""
+    from dm_nerf_amd.networks import penalizer as P
     from dm_nerf_amd.networks import render as R
     mc.train(); mf.train()
     params = list(mc.parameters()) + list(mf.parameters())
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
-    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, tolerance=0.05, deta_w=0.05)
     g = torch.Generator(device=dev).manual_seed(0)
     target = torch.rand(N_RAYS, 3, device=dev, generator=g)
     tgt_ins = torch.rand(N_RAYS, INS_NUM, device=dev, generator=g)
@@ -87,7 +90,8 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
         out = R.dm_nerf(rays, None, None, mc, mf, z, args)
         loss = ((out['rgb_fine'] - target) ** 2).mean() + ((out['rgb_coarse'] - target) ** 2).mean() \
             + ((out['ins_fine'] - tgt_ins) ** 2).mean() + ((out['ins_coarse'] - tgt_ins) ** 2).mean() \
-            + 1e-4 * (out['raw_fine'][..., 4:] ** 2).mean() + 1e-4 * (out['raw_coarse'][..., 4:] ** 2).mean()
+            + P.ins_penalizer(out['raw_fine'], out['z_vals_fine'], out['depth_fine'], rays[1], args).sum() \
+            + P.ins_penalizer(out['raw_coarse'], out['z_vals_coarse'], out['depth_coarse'], rays[1], args).sum()
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -103,7 +107,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
     flop = 2.0 * (2 * MAC_PER_SAMPLE + (MAC_PER_SAMPLE - 101248)) * (2 * S_COARSE + N_IMP) * N_RAYS
     return {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "tflops": flop / dt / 1e12,
             "frac_of_f32_mfma_peak": flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "final_loss": float(loss.detach()),
-            "batch_rays": N_RAYS, "note": "fwd+loss+bwd+Adam, perturb=1, surrogate dense losses (see bench.py::train_leg)"}
+            "batch_rays": N_RAYS, "note": "fwd + img2mse + fused emptiness penalizer + object-code MSE (stand-in for the host-side Hungarian loss) + bwd + Adam, perturb=1"}
 
 
 def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):

@@ -13,66 +13,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// Weight stream: buffer loads through one wave-uniform descriptor (SGPRs) with the per-lane
-// part (lane*16 B) in a single voffset VGPR and the segment position in the scalar offset, so
-// no 64-bit per-load address ever occupies VGPRs (flat addressing spilled ~300 address pairs).
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ rsrc_t make_rsrc(const float* p, int64_t n_floats) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), /*stride*/ 0, (int)(n_floats * 4), 0x00020000);
-}
-
-__device__ __forceinline__ f32x4 ldw(rsrc_t r, int voff, int soff_bytes) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff_bytes, 0);
-    return __builtin_bit_cast(f32x4, v);
-}
-
-// acc[ob] += Wseg[ob-block rows, k] * B[k, samples] for NKG*4 k-pairs.  B lives in registers in
-// accumulator layout: k-pair p is B[p >> 4][p & 15].  `seg` = float offset of the segment.
-template <int NKG, int OB, int NB>
-__device__ __forceinline__ void gemm_seg(rsrc_t rs, int seg, const f32x16 (&B)[NB],
-                                         f32x16 (&acc)[OB], int voff) {
-    static_assert(NB * 16 >= NKG * 4, "B operand too small");
-    // The segment is streamed front to back; its position lives in ONE scalar register that is
-    // bumped every 4 KiB (imm offsets cover 0..3 KiB).  The empty asm makes the running value
-    // opaque, otherwise the scheduler materialises every `base + const` offset up front and
-    // spills hundreds of SGPRs (seen as v_writelane/v_readlane storms and scratch traffic).
-    int so = seg * 4;
-    asm volatile("" : "+s"(so));
-#pragma unroll
-    for (int g = 0; g < NKG; ++g) {
-        f32x4 a[OB];
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) {
-            const int lin = g * OB + ob;                 // KiB index inside the segment
-            a[ob] = ldw(rs, voff, so + (lin & 3) * 1024);
-            if ((lin & 3) == 3) { so += 4096; asm volatile("" : "+s"(so)); }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int p = g * 4 + kk;
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob) {
-                acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
-            }
-        }
-    }
-}
-
-// acc[ob][r] = bias of row 32ob + (r&3) + 8(r>>2) + 4half; hoff = half * 64 bytes.
-template <int OB>
-__device__ __forceinline__ void init_bias(rsrc_t rs, int seg, f32x16 (&acc)[OB], int hoff) {
-#pragma unroll
-    for (int ob = 0; ob < OB; ++ob) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = ldw(rs, hoff, (seg + ob * 32 + q * 4) * 4);
-            acc[ob][4 * q + 0] = v[0]; acc[ob][4 * q + 1] = v[1];
-            acc[ob][4 * q + 2] = v[2]; acc[ob][4 * q + 3] = v[3];
-        }
-    }
-}
 
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     f32x16 r;
@@ -170,18 +112,6 @@ __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * b + (r & 3) + 8 * (r >> 2);
             __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, DMN_STORE_AUX);
-        }
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void load_rows(const RowIO& io, f32x16 (&v)[NB]) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * b + (r & 3) + 8 * (r >> 2);
-            v[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, 0));
         }
     }
 }

@@ -7,7 +7,8 @@
 // never leave registers: with Y^T = W . X^T on v_mfma_f32_32x32x2_f32 (A = weights, B = X^T),
 // the accumulator layout of layer n IS the B-operand layout of layer n+1 (see layout.h), so a
 // layer is 8 x 128 back-to-back MFMAs whose only memory traffic is the pre-permuted weight
-// stream (one coalesced dwordx4 per lane per 4 MFMAs, L2-resident: a model is 2.8 MB).
+// stream, which the workgroup's 4 waves pull through a 2 x 64 KiB LDS ring by LDS-DMA two
+// quarters ahead of use (mlp_common.h): A operands are ds_read_b128, no VMEM load in the MFMA stream.
 // Exact f32: the MFMA is bitwise an fmaf chain in k order (MI355X guide), so results are in the
 // f32-roundoff class of the reference's sgemm.
 //

@@ -311,6 +311,87 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// emptiness_penalizer (networks/penalizer.py:5-55), forward partial sums and backward: one wave per ray.
+//   p = z |d|;  G = exp(-(depth|d| - p)^2 / (2 deta_w^2)) / (0.4 sqrt(2 pi)) + 1e-8;  A = 1 - G
+//   m_b = [p < (depth - tol)|d|], m_a = [p > (depth + tol)|d|], m_m = 1 - (m_a + m_b)
+//   P = sigmoid(raw[..., 4:]);  before: BCE(P, e_last) A m_b summed / (C max(sum m_b, 1e-8))
+//                              middle: -log(1 - P_last + 1e-8) G m_m summed / max(sum m_m, 1e-8)
+// mode 0: out4[n] = {sum lb*w_b, sum m_b, sum lm*w_m, sum m_m} (double);  mode 1: d raw (zeros in channels 0..3)
+// ------------------------------------------------------------------------------------------
+struct PenArgs {
+    const float* raw; const float* z; const float* depth; const float* rays_d;
+    int64_t N; int S, C;
+    float tol, k2w, kh;          // tolerance, 2*deta_w^2, 0.4*sqrt(2 pi) -- float32 values computed as the reference does
+    double* out4;                // mode 0
+    const float* scales;         // mode 1: {up / (C * max(sum m_b,1e-8)), up / max(sum m_m,1e-8)}
+    float* d_raw;                // mode 1
+};
+
+template <int MODE>
+__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void penalizer_kernel(const PenArgs a) {
+    __shared__ float wb_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float wm_lds[RAYS_PER_BLOCK][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (n >= a.N) return;
+    const int S = a.S, C = a.C, ch = 4 + C;
+    const float* __restrict__ rr = a.raw + n * (int64_t)S * ch;
+    const float* __restrict__ zr = a.z + n * (int64_t)S;
+    float* wb = wb_lds[wv];
+    float* wm = wm_lds[wv];
+    const float dx = a.rays_d[n * 3 + 0], dy = a.rays_d[n * 3 + 1], dz = a.rays_d[n * 3 + 2];
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float dep = a.depth[n];
+    const float d_before = (dep - a.tol) * nrm, d_after = (dep + a.tol) * nrm, d_depth = dep * nrm;
+    double n_b = 0.0, n_m = 0.0;
+    for (int s = lane; s < S; s += WAVE) {
+        const float p = zr[s] * nrm;
+        const float dd = d_depth - p;
+        const float G = expf(-(dd * dd) / a.k2w) / a.kh + 1e-8f;
+        const float mb = p < d_before ? 1.f : 0.f;
+        const float ma = p > d_after ? 1.f : 0.f;
+        const float mm = 1.f - (ma + mb);
+        wb[s] = (1.f - G) * mb;
+        wm[s] = G * mm;
+        n_b += mb;
+        n_m += mm;
+    }
+    lds_sync_wave();
+    float sc_b = 0.f, sc_m = 0.f;
+    if (MODE == 1) { sc_b = a.scales[0]; sc_m = a.scales[1]; }
+    double s_b = 0.0, s_m = 0.0;
+    const unsigned total = (unsigned)S * (unsigned)ch;
+    float* __restrict__ dr = MODE == 1 ? a.d_raw + n * (int64_t)S * ch : nullptr;
+    for (unsigned e = lane; e < total; e += WAVE) {
+        const unsigned s = e / (unsigned)ch;
+        const int c = (int)(e - s * (unsigned)ch) - 4;
+        if (c < 0) {
+            if (MODE == 1) dr[e] = 0.f;
+            continue;
+        }
+        const float P = sigmoidf_ref(rr[e]);
+        const float q = (1.f - P) + 1e-8f;                   // 1 - pred_ins + 1e-8
+        const bool last = c == C - 1;
+        if (MODE == 0) {
+            const float lb = last ? -logf(P + 1e-8f) : -logf(q);
+            s_b += (double)(lb * wb[s]);
+            if (last) s_m += (double)(-logf(q) * wm[s]);
+        } else {
+            const float sp = P * (1.f - P);                  // sigmoid backward
+            float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * wb[s] * sc_b;
+            if (last) g += (sp / q) * wm[s] * sc_m;
+            dr[e] = g;
+        }
+    }
+    if (MODE == 0) {
+        s_b = wave_sum_d(s_b); s_m = wave_sum_d(s_m); n_b = wave_sum_d(n_b); n_m = wave_sum_d(n_m);
+        if (lane == 0) {
+            a.out4[n * 4 + 0] = s_b; a.out4[n * 4 + 1] = n_b; a.out4[n * 4 + 2] = s_m; a.out4[n * 4 + 3] = n_m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // sample_pdf (helpers.py:123-155) [+ z_mid / sort-merge of render.py:66-70]: one wave per ray
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_NB = 512;      // bins per ray
@@ -546,4 +627,30 @@ extern "C" int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const 
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
                        d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw);
     return dmn_check_launch("composite_bwd");
+}
+
+extern "C" int dmnerf_penalizer_fwd(const float* d_raw, const float* d_z, const float* d_depth, const float* d_rays_d,
+                                    int64_t N, int S, int C, float tolerance, float two_deta_w_sq, float gauss_norm,
+                                    double* d_partials, void* stream) {
+    if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "penalizer_fwd: bad N=%lld S=%d C=%d", (long long)N, S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_depth || !d_rays_d || !d_partials) return dmn_fail(DMNERF_E_ARG, "penalizer_fwd: null pointer");
+    PenArgs a{};
+    a.raw = d_raw; a.z = d_z; a.depth = d_depth; a.rays_d = d_rays_d; a.N = N; a.S = S; a.C = C;
+    a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.out4 = d_partials;
+    hipLaunchKernelGGL(penalizer_kernel<0>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, a);
+    return dmn_check_launch("penalizer_fwd");
+}
+
+extern "C" int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const float* d_depth, const float* d_rays_d,
+                                    int64_t N, int S, int C, float tolerance, float two_deta_w_sq, float gauss_norm,
+                                    const float* d_scales, float* d_grad_raw, void* stream) {
+    if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "penalizer_bwd: bad N=%lld S=%d C=%d", (long long)N, S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_depth || !d_rays_d || !d_scales || !d_grad_raw) return dmn_fail(DMNERF_E_ARG, "penalizer_bwd: null pointer");
+    PenArgs a{};
+    a.raw = d_raw; a.z = d_z; a.depth = d_depth; a.rays_d = d_rays_d; a.N = N; a.S = S; a.C = C;
+    a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.scales = d_scales; a.d_raw = d_grad_raw;
+    hipLaunchKernelGGL(penalizer_kernel<1>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, a);
+    return dmn_check_launch("penalizer_bwd");
 }

@@ -160,6 +160,20 @@ int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const floa
                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                            float* d_part, float* d_grad_flat, void* stream);
 
+/* ---- penalizer.py (the consumer of raw / z_vals / depth) ---------------------------
+ * emptiness_penalizer (networks/penalizer.py:5-55) fused: _fwd writes per-ray partial sums
+ * d_partials [N,4] (double): {sum BCE*w_before, sum m_before, sum loss_middle*w_middle, sum m_middle};
+ *   loss = S0 / (C max(S1,1e-8)) + S2 / max(S3,1e-8) with Sk = sum over rays.
+ * _bwd writes dL/draw [N,S,4+C] (zero in channels 0..3) given d_scales = {up/(C max(S1,1e-8)), up/max(S3,1e-8)}.
+ * two_deta_w_sq = 2*deta_w^2 and gauss_norm = 0.4*sqrt(2 pi), both rounded to float32 as the reference forms them.
+ * depth is a constant (the reference detaches it, penalizer.py:59).                                   */
+int dmnerf_penalizer_fwd(const float* d_raw, const float* d_z, const float* d_depth, const float* d_rays_d,
+                         int64_t N, int S, int C, float tolerance, float two_deta_w_sq, float gauss_norm,
+                         double* d_partials, void* stream);
+int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const float* d_depth, const float* d_rays_d,
+                         int64_t N, int S, int C, float tolerance, float two_deta_w_sq, float gauss_norm,
+                         const float* d_scales, float* d_grad_raw, void* stream);
+
 /* dm_nerf inference (networks/render.py:31-96, perturb handled by the caller passing t_rand/u):
  * all stages on `stream`, outputs = the 10 tensors of the reference dict (ins_* are [N, C-1]).
  *   d_t_rand: [N,S] or NULL (no jitter); d_u / u_row_stride as in dmnerf_sample_pdf.

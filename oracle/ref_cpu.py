@@ -270,6 +270,45 @@ def dm_nerf(rays, sd_coarse, sd_fine, z_vals_coarse, perturb=0., N_importance=12
 
 
 # --------------------------------------------------------------------------------------
+# emptiness penalizer  (networks/penalizer.py) -- SURVEY 8(f)-1, the consumer of raw_* / z_vals_* / depth_*
+# --------------------------------------------------------------------------------------
+
+def emptiness_penalizer(raw, z_vals, depths, rays_d, tolerance, deta_w):
+    """``emptiness_penalizer`` (networks/penalizer.py:5-55), device-explicit."""
+    dev = raw.device
+    delta_H, delta_W = torch.tensor([0.4], device=dev), torch.tensor([deta_w], device=dev)
+    gauss = lambda dd, dh, dw: torch.exp(-(dd ** 2) / (2 * (dw ** 2))) / (dh * torch.sqrt(torch.tensor([2 * np.pi], device=dev))) + 1e-8
+    norm = torch.norm(rays_d[..., None, :], dim=-1)
+    dists_before = (depths - tolerance) * norm
+    dists_after = (depths + tolerance) * norm
+    depth_dist = depths * norm
+    p_dists = z_vals * norm
+    delta_dist = depth_dist - p_dists
+    penalize_weights = gauss(delta_dist, delta_H, delta_W)
+    penalize_weights_air = 1 - penalize_weights
+    mask_before = (p_dists < dists_before).type(torch.float32)
+    mask_after = (p_dists > dists_after).type(torch.float32)
+    mask_middle = 1 - (mask_after + mask_before)
+    pred_ins = torch.sigmoid(raw[..., 4:])
+    gt = torch.zeros_like(pred_ins)
+    gt[..., -1] = 1
+    loss_before = -gt * torch.log(pred_ins + 1e-8) - (1 - gt) * torch.log(1 - pred_ins + 1e-8)
+    loss_before = loss_before * (penalize_weights_air * mask_before)[..., None]
+    loss_before = torch.sum(loss_before) / (pred_ins.shape[-1] * torch.maximum(torch.sum(mask_before), torch.tensor([1e-8], device=dev)))
+    pm = pred_ins[..., -1]
+    gtm = torch.zeros_like(pm)
+    loss_middle = -gtm * torch.log(pm + 1e-8) - (1 - gtm) * torch.log(1 - pm + 1e-8)
+    loss_middle = loss_middle * (penalize_weights * mask_middle)
+    loss_middle = torch.sum(loss_middle) / torch.maximum(torch.sum(mask_middle), torch.tensor([1e-8], device=dev))
+    return loss_before + loss_middle
+
+
+def ins_penalizer(raw, z_vals, depth, rays_d, tolerance, deta_w):
+    """``ins_penalizer`` (networks/penalizer.py:58-62): depth is detached."""
+    return emptiness_penalizer(raw, z_vals, depth[..., None].detach(), rays_d, tolerance, deta_w)
+
+
+# --------------------------------------------------------------------------------------
 # synthetic scene (SURVEY.md section 8(d)); used by tests and bench
 # --------------------------------------------------------------------------------------
 

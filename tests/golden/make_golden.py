@@ -32,6 +32,7 @@ from oracle import ref_cpu as O  # noqa: E402
 import networks.dm_nerf as R_model  # noqa: E402  (reference)
 import networks.render as R_render  # noqa: E402
 import networks.helpers as R_helpers  # noqa: E402
+import networks.penalizer as R_pen  # noqa: E402
 
 torch.autograd.set_detect_anomaly(False)  # the reference switches it on at import (dm_nerf.py:5)
 torch.set_num_threads(1)                  # fixtures must not depend on the thread count
@@ -242,6 +243,33 @@ def gen_dm_nerf():
     save("dm_nerf", **out)
 
 
+def gen_penalizer():
+    """``ins_penalizer`` (penalizer.py:58-62) value and its gradient w.r.t. raw, tolerance/deta_w of the configs."""
+    out = {}
+    for S, C, seed, tol in ((64, 14, 501, 0.05), (192, 14, 502, 0.05), (192, 60, 503, 0.1)):
+        gen = torch.Generator().manual_seed(seed)
+        N = 6
+        raw = torch.randn(N, S, 4 + C, generator=gen) * 2.0
+        z = torch.sort(torch.rand(N, S, generator=gen) * 11 + 4, -1)[0]
+        depth = 4 + 11 * torch.rand(N, generator=gen)
+        depth[0] = 3.0            # surface in front of every sample: mask_before empty
+        depth[1] = 20.0           # behind every sample
+        depth[2] = z[2, S // 2]   # exactly on a sample
+        d = torch.randn(N, 3, generator=gen)
+        a = types.SimpleNamespace(tolerance=tol, deta_w=0.05)
+        r0 = raw.clone().requires_grad_(True)
+        loss = R_pen.ins_penalizer(r0, z, depth, d, a)
+        grad, = torch.autograd.grad(loss.sum(), r0)
+        r1 = raw.clone().requires_grad_(True)
+        lo = O.ins_penalizer(r1, z, depth, d, tol, 0.05)
+        go, = torch.autograd.grad(lo.sum(), r1)
+        beq(lo, loss, f"penalizer S={S} C={C}"); beq(go, grad, f"penalizer grad S={S} C={C}")
+        k = f"S{S}_C{C}"
+        out.update({f"{k}_raw": raw, f"{k}_z": z, f"{k}_depth": depth, f"{k}_d": d, f"{k}_loss": loss.detach(),
+                    f"{k}_grad": grad[..., 4:].contiguous(), f"{k}_tol": np.float64(tol)})
+    save("penalizer", **out)
+
+
 if __name__ == "__main__":
     print("reference:", REF, "| torch", torch.__version__)
     gen_embed()
@@ -250,4 +278,5 @@ if __name__ == "__main__":
     gen_sample_pdf()
     gen_rays()
     gen_dm_nerf()
+    gen_penalizer()
     print("all oracle == reference checks passed (bit-exact)")

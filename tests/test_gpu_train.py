@@ -205,3 +205,18 @@ def test_adam_steps_follow_the_oracle_trajectory(A):
         want.append(float(lo.detach()))
     assert np.allclose(got, want, rtol=2e-3), (got, want)
     assert got[2] < got[0]
+
+
+def test_penalizer_golden_value_and_gradient(A, golden):
+    """fused emptiness penalizer vs the vectors produced by the reference's own ins_penalizer."""
+    from dm_nerf_amd.networks import penalizer as P
+    g = golden("penalizer")
+    for k in ("S64_C14", "S192_C14", "S192_C60"):
+        a = types.SimpleNamespace(tolerance=float(g[f"{k}_tol"]), deta_w=0.05)
+        raw = g[f"{k}_raw"].cuda().requires_grad_(True)
+        loss = P.ins_penalizer(raw, g[f"{k}_z"].cuda(), g[f"{k}_depth"].cuda(), g[f"{k}_d"].cuda(), a)
+        assert loss.shape == g[f"{k}_loss"].shape
+        assert abs(float(loss.detach()) - float(g[f"{k}_loss"])) <= 2e-6 * abs(float(g[f"{k}_loss"])) + 1e-7
+        grad, = torch.autograd.grad(loss.sum() * 1.5, raw)
+        assert float(grad[..., :4].abs().max()) == 0.0
+        tclose(grad[..., 4:] / 1.5, g[f"{k}_grad"], f"penalizer grad {k}", rel=2e-5)
