@@ -41,6 +41,7 @@ SIGNATURES = {
     "dmnerf_build_pack_index": (c_int, [c_int, c_vp, c_i64]),
     "dmnerf_pack_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dmnerf_raygen": (c_int, [c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_raygen_select": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dmnerf_z_val_sample": (c_int, [c_vp, c_float, c_float, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_stratify": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_sample_pdf": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),

@@ -98,6 +98,22 @@ __global__ void raygen_kernel(const RaygenArgs a) {
     }
 }
 
+// rays of selected pixels only (get_select_full, helpers.py:99-111: flat index k -> row k / W, col k % W)
+__global__ void raygen_select_kernel(const RaygenArgs a, const int64_t* __restrict__ idx) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    const int64_t k = idx[t];
+    const float i = (float)(int)(k % a.W), j = (float)(int)(k / a.W);
+    const float d0 = (i - a.cx) / a.fx;
+    const float d1 = (j - a.cy) / a.fy;
+    const float d2 = a.k22 * 1.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        a.rays_d[t * 3 + r] = (d0 * a.r[3 * r + 0] + d1 * a.r[3 * r + 1]) + d2 * a.r[3 * r + 2];
+        a.rays_o[t * 3 + r] = a.t[r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // z_val_sample (helpers.py:114-119) and the stratified jitter (render.py:42-47)
 // ------------------------------------------------------------------------------------------
@@ -653,4 +669,20 @@ extern "C" int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const 
     a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.scales = d_scales; a.d_raw = d_grad_raw;
     hipLaunchKernelGGL(penalizer_kernel<1>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, a);
     return dmn_check_launch("penalizer_bwd");
+}
+
+extern "C" int dmnerf_raygen_select(int H, int W, const float* h_intr, const float* h_c2w, const int64_t* d_idx, int64_t n,
+                                    float* d_rays_o, float* d_rays_d, void* stream) {
+    if (H < 1 || W < 1 || n < 0) return dmn_fail(DMNERF_E_ARG, "raygen_select: bad size");
+    if (n == 0) return DMNERF_OK;
+    if (!h_intr || !h_c2w || !d_idx || !d_rays_o || !d_rays_d) return dmn_fail(DMNERF_E_ARG, "raygen_select: null pointer");
+    RaygenArgs a;
+    a.fx = h_intr[0]; a.fy = h_intr[1]; a.cx = h_intr[2]; a.cy = h_intr[3]; a.k22 = h_intr[4];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) a.r[3 * r + c] = h_c2w[4 * r + c];
+        a.t[r] = h_c2w[4 * r + 3];
+    }
+    a.W = W; a.row0 = 0; a.n = n; a.rays_o = d_rays_o; a.rays_d = d_rays_d;
+    hipLaunchKernelGGL(raygen_select_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, d_idx);
+    return dmn_check_launch("raygen_select");
 }

@@ -43,6 +43,34 @@ def get_rays_k(H, W, K, c2w, row0=0, nrows=None):
     return rays_o, rays_d
 
 
+def _camera(K, c2w):
+    K = np.asarray(K)
+    intr = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[2, 2]], dtype=np.float64).astype(np.float32)
+    c = (c2w.detach().cpu().numpy() if torch.is_tensor(c2w) else np.asarray(c2w)).astype(np.float32)[:3, :4]
+    return intr, np.ascontiguousarray(c)
+
+
+def get_select_full(rgb, pose, K, ins_target, N_train):
+    """``get_select_full`` (networks/helpers.py:99-111): a random batch of ``N_train`` pixels of one image.
+
+    Same host RNG stream as the reference -- one ``np.random.choice(H*W, N_train, replace=False)`` -- but only
+    the selected rays are generated (the reference builds all H*W rays every step and gathers).
+    Returns ``target_c [N,3], target_i [N], batch_rays [2,N,3]`` on the image's device.
+    """
+    H, W, _ = rgb.shape
+    _lib.require_gpu(rgb.contiguous())
+    selected_index = np.random.choice(H * W, size=[N_train], replace=False)
+    idx = torch.from_numpy(selected_index).to(rgb.device)
+    intr, c = _camera(K, pose)
+    rays = torch.empty(2, N_train, 3, dtype=torch.float32, device=rgb.device)
+    _lib.check(_lib.load().dmnerf_raygen_select(int(H), int(W), intr.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p),
+                                                _lib.ptr(idx), int(N_train), _lib.ptr(rays[0]), _lib.ptr(rays[1]), _lib.stream()),
+               "dmnerf_raygen_select")
+    target_c = rgb.reshape(-1, rgb.shape[-1])[idx]
+    target_i = ins_target.reshape(-1)[idx]
+    return target_c, target_i, rays
+
+
 def z_val_sample(N_rays, near, far, N_samples, device=None):
     """``z_val_sample`` (networks/helpers.py:114-119): ``near + linspace(0,1,S) * (far - near)`` -> [N, S]."""
     dev = _device(device)

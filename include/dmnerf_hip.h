@@ -68,6 +68,11 @@ int dmnerf_pack_weights(const float* d_flat, const int32_t* d_idx, float* d_blob
 int dmnerf_raygen(int H, int W, const float* h_intr, const float* h_c2w, int row0, int nrows,
                   float* d_rays_o, float* d_rays_d, void* stream);
 
+/* Rays of selected pixels only: what get_select_full (networks/helpers.py:99-111) gathers out of a
+ * full-frame get_rays_k.  d_idx: int64 flat pixel indices k = row*W + col; outputs [n,3].           */
+int dmnerf_raygen_select(int H, int W, const float* h_intr, const float* h_c2w, const int64_t* d_idx,
+                         int64_t n, float* d_rays_o, float* d_rays_d, void* stream);
+
 /* z_val_sample (networks/helpers.py:114-119): z[n,s] = near + t[s]*(far-near); d_t = linspace(0,1,S). */
 int dmnerf_z_val_sample(const float* d_t, float near_, float far_, int64_t N, int S, float* d_z,
                         void* stream);

@@ -243,6 +243,21 @@ def gen_dm_nerf():
     save("dm_nerf", **out)
 
 
+def gen_select():
+    """``get_select_full`` under np.random.seed(0) (helpers.py:99-111): indices and gathered rays."""
+    H, W, N = 12, 16, 40
+    K = O.dmsr_intrinsics(H, W)
+    c2w = O.pose_spherical(37.0, -65.0, 7.0)
+    gen = torch.Generator().manual_seed(601)
+    rgb = torch.rand(H, W, 3, generator=gen)
+    lab = torch.randint(0, 13, (H, W), generator=gen).to(torch.int16)
+    np.random.seed(0)
+    tc, ti, rays = R_helpers.get_select_full(rgb, c2w[:3, :4], K, lab, N)
+    np.random.seed(0)
+    idx = np.random.choice(H * W, size=[N], replace=False)
+    save("select", rgb=rgb, lab=lab, c2w=c2w, K=K, idx=idx, target_c=tc, target_i=ti, rays=rays, HWN=np.array([H, W, N]))
+
+
 def gen_penalizer():
     """``ins_penalizer`` (penalizer.py:58-62) value and its gradient w.r.t. raw, tolerance/deta_w of the configs."""
     out = {}
@@ -279,4 +294,5 @@ if __name__ == "__main__":
     gen_rays()
     gen_dm_nerf()
     gen_penalizer()
+    gen_select()
     print("all oracle == reference checks passed (bit-exact)")

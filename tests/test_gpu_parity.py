@@ -316,3 +316,22 @@ def test_errors_are_loud(A):
     with pytest.raises(RuntimeError):
         A.R.render_train(torch.zeros(2, 2000, 8, device="cuda"), torch.zeros(2, 2000, device="cuda"),
                          torch.ones(2, 3, device="cuda"))    # S beyond the kernel's per-ray staging
+
+
+def test_get_select_full_same_rng_stream_as_reference(A, golden):
+    """identical numpy stream => identical pixels, targets and rays."""
+    g = golden("select")
+    H_, W_, N = [int(v) for v in g["HWN"]]
+    np.random.seed(0)
+    tc, ti, rays = A.H.get_select_full(dev(g["rgb"]), dev(g["c2w"])[:3, :4], g["K"].numpy(), dev(g["lab"]), N)
+    assert rays.shape == (2, N, 3)
+    assert torch.equal(cpu(tc), g["target_c"]) and torch.equal(cpu(ti), g["target_i"])
+    assert torch.equal(cpu(rays[0]), g["rays"][0])
+    assert torch.allclose(cpu(rays[1]), g["rays"][1], rtol=3e-7, atol=1e-7)
+    # and the host RNG advanced exactly as in the reference: the next draw matches
+    np.random.seed(0)
+    np.random.choice(H_ * W_, size=[N], replace=False)
+    want_next = np.random.rand()
+    np.random.seed(0)
+    A.H.get_select_full(dev(g["rgb"]), dev(g["c2w"])[:3, :4], g["K"].numpy(), dev(g["lab"]), N)
+    assert np.random.rand() == want_next
