@@ -41,7 +41,7 @@ __device__ __forceinline__ void zero(f32x16 (&v)[NB]) {
 }
 
 // Same LDS weight-streaming engine as the forward (mlp_common.h): the W^T stream is consumed one 64 KiB
-// quarter at a time, fetched two quarters ahead; the dy stores of a stage are issued in three batches
+// quarter at a time, fetched one quarter ahead; the dy stores of a stage are issued in three batches
 // at the quarter boundaries of the NEXT stage (while dy is its B operand), always before the next DMA.
 template <int OBI>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
@@ -114,37 +114,23 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     }
     WStream ws;
     ws.gsrc = reinterpret_cast<const char*>(a.blobT) + lane * 16 + wave * 1024;
-    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(LT.stream * 4); ws.fslot = 0; ws.cslot = 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // inputs, masks, table: counters start clean
-    ws_fetch(ws);                                                         // quarter 0: ins_linear^T
-    ws_fetch(ws);                                                         // quarter 1: ins_feature_linears.0^T, first half
-    constexpr int Y0 = DMA_PER_QUARTER;
-    constexpr int YS = DMA_PER_QUARTER + 43;
-    constexpr int YMAX = 63;                                              // "everything but the newest 63": used after a burst
+    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(LT.stream * 4); ws.cslot = 0;
+    ws_fetch_first(ws);                                                   // quarter 0: ins_linear^T
 
     f32x16 d[8], acc[8];
     {
         // ---- ins branch: dg2 = relu'(g2) . (W_io^T g_ins);  dq = W_ih^T dg2 ----------------------
         f32x16 t4[4], d4[4];
         zero<4>(t4);
-        ws_acquire<Y0>();
-        gemm_quarter<0, 4 * OBI, 4>(lds + ws.cslot * SLOT_FLOATS, gi, t4, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
+        ws_begin();
+        gemm_quarter<0, 4 * OBI, 4>(ws, gi, t4, lane);
         apply_mask<4>(d4, g2bits, t4);
         store_rows<4>(make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane), d4);     // burst (once per block)
         zero<8>(acc);
-        ws_acquire<YMAX>();
-        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
-        ws_acquire<Y0>();
-        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
+        ws_begin();
+        gemm_quarter<0, 8, 8>(ws, d4, acc, lane);
+        ws_begin();
+        gemm_quarter<8, 8, 8>(ws, d4, acc, lane);
         store_rows<8>(make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane), acc);      // dq (ins_feature has no activation)
 
         // ---- rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU;  df = (W_rh^T dg1)[:256] ----
@@ -165,16 +151,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         apply_mask<4>(d4, g1bits, t4);
         store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);
         zero<8>(acc);
-        ws_acquire<YMAX>();
-        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
-        ws_acquire<Y0>();
-        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d4, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
+        ws_begin();
+        gemm_quarter<0, 8, 8>(ws, d4, acc, lane);
+        ws_begin();
+        gemm_quarter<8, 8, 8>(ws, d4, acc, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) d[b] = acc[b];                        // df (rgb_feature has no activation)
     }
@@ -185,29 +165,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     for (int st = 0; st < NSTAGE_T; ++st) {
         const RowIO dio = make_rowio(st == 0 ? a.dsave + SL.f : a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
         zero<8>(acc);
-        ws_acquire<Y0>();
-        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        ws_begin();
+        gemm_quarter<0, 8, 8>(ws, d, acc, lane);
+        ws_begin();
         store_rows_part<0, 43>(dio, d);
-        ws_fetch(ws);
-        ws_acquire<YS>();
-        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<8, 8, 8>(ws, d, acc, lane);
+        ws_begin();
         store_rows_part<43, 43>(dio, d);
-        ws_fetch(ws);
-        ws_acquire<YS>();
-        gemm_quarter<16, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<16, 8, 8>(ws, d, acc, lane);
+        ws_begin();
         store_rows_part<86, 42>(dio, d);
-        ws_fetch(ws);
-        ws_acquire<DMA_PER_QUARTER + 42>();
-        gemm_quarter<24, 8, 8>(lds + ws.cslot * SLOT_FLOATS, d, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
+        gemm_quarter<24, 8, 8>(ws, d, acc, lane);
         if (st == 0) {
             // density_linear (dm_nerf.py:101): dh_7 += w_d * g_sigma
             const f32x4* wd = reinterpret_cast<const f32x4*>(tab + LT.w_den + half * 128);

@@ -149,13 +149,18 @@ __device__ __forceinline__ void store_encoded_rows(const float* base, int64_t Mp
 //   * no VMEM load is ever issued inside the MFMA stream, and every DMA is OLDER than the activation
 //     stores issued after it: waiting for a DMA (vmcnt retires in order) never waits for a store ack;
 //   * the L2 -> CU weight traffic drops 4x (one copy per workgroup instead of one per wave).
-// Protocol per quarter:  acquire<Y>()  = s_waitcnt vmcnt(Y) ; s_barrier      (Y = VMEM ops younger than its DMA)
-//                        ... ds_read_b128 / MFMA ...
-//                        release()     = s_waitcnt lgkmcnt(0) ; s_barrier ; [stores] ; DMA(q+2)
+// Protocol per quarter q (slot q & 1):
+//   ws_begin()   = s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier   -- ONE barrier: every wave's DMA pieces of quarter q
+//                  have landed AND every wave is done reading the other slot (quarter q-1)
+//   [training: this boundary's batch of activation stores]
+//   first k-group (8 ds_read_b128 + 32 MFMAs), then ws_fetch(): DMA of quarter q+1 into the other slot, issued
+//                  in the shadow of the MFMA stream, then the remaining k-groups.
+// vmcnt(0) at a boundary only ever waits for operations issued a full quarter earlier (the DMA and the store
+// batch in front of it), except after the two small once-per-block bursts of the heads.
 constexpr int SLOT_FLOATS = QUARTER_FLOATS;
 constexpr int RING_FLOATS = 2 * SLOT_FLOATS;
 constexpr int LDS_FLOATS = RING_FLOATS + TAB_FLOATS;       // 147 456 bytes
-constexpr int DMA_PER_QUARTER = 16;                        // LDS-DMA instructions per wave per quarter
+constexpr int DMA_PER_QUARTER = 16;                        // LDS-DMA instructions per wave per quarter (1 KiB each)
 
 #define DMN_GAS __attribute__((address_space(1)))
 #define DMN_LAS __attribute__((address_space(3)))
@@ -165,31 +170,27 @@ struct WStream {
     float* ring;          // LDS ring base
     int wave;             // wave id in the workgroup (uniform)
     unsigned off;         // byte offset from the blob start of the next quarter to fetch
-    int fslot;            // ring slot the next fetch goes to
     int cslot;            // ring slot of the next quarter to consume
 };
 
 __device__ __forceinline__ void ws_fetch(WStream& ws) {
     const char* g = ws.gsrc + ws.off;
-    float* dst = ws.ring + ws.fslot * SLOT_FLOATS + ws.wave * 256;
+    float* dst = ws.ring + (ws.cslot ^ 1) * SLOT_FLOATS + ws.wave * 256;
 #pragma unroll
     for (int i = 0; i < DMA_PER_QUARTER; ++i)     // piece p = 4 i + wave: 1 KiB each
         __builtin_amdgcn_global_load_lds((DMN_GAS void*)(g + i * 4096), (DMN_LAS void*)(dst + i * 1024), 16, 0, 0);
     ws.off += QUARTER_FLOATS * 4;
-    ws.fslot ^= 1;
 }
 
-template <int YOUNGER>
-__device__ __forceinline__ void ws_acquire() {
-    static_assert(YOUNGER >= 0 && YOUNGER <= 63, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+// Prologue: quarter 0 into slot 0 (nothing is being consumed yet).
+__device__ __forceinline__ void ws_fetch_first(WStream& ws) {
+    ws.cslot = 1;
+    ws_fetch(ws);
+    ws.cslot = 0;
 }
 
-// All of this wave's ds_reads of the slot have returned; after the barrier nobody reads it any more.
-__device__ __forceinline__ void ws_release_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+__device__ __forceinline__ void ws_begin() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -197,10 +198,10 @@ __device__ __forceinline__ void ws_release_barrier() {
 // One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
 // operands from the LDS slot (group-local index), B from registers (accumulator layout).
 template <int G0, int NG, int OB, int NB>
-__device__ __forceinline__ void gemm_quarter(const float* slot, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
+__device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
     static_assert(NB * 16 >= (G0 + NG) * 4, "B operand too small");
     static_assert(NG * OB <= 64, "more than one quarter");
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(slot) + lane;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(ws.ring + ws.cslot * SLOT_FLOATS) + lane;
 #pragma unroll
     for (int gl = 0; gl < NG; ++gl) {
         f32x4 a[OB];
@@ -212,7 +213,9 @@ __device__ __forceinline__ void gemm_quarter(const float* slot, const f32x16 (&B
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
         }
+        if (gl == 0) ws_fetch(ws);          // next quarter -> the other slot, behind the first group's MFMAs
     }
+    ws.cslot ^= 1;
 }
 
 // acc[ob][r] = bias of row 32ob + crow(r, half), from the LDS table

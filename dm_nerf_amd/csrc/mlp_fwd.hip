@@ -87,10 +87,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
     WStream ws;
     ws.gsrc = reinterpret_cast<const char*>(blob) + lane * 16 + wave * 1024;
-    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(L.stream * 4); ws.fslot = 0; ws.cslot = 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // inputs + table landed: the counters below start clean
-    ws_fetch(ws);                                                         // quarter 0: mlps.0
-    ws_fetch(ws);                                                         // quarter 1: first quarter of stage 0
+    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(L.stream * 4); ws.cslot = 0;
+    ws_fetch_first(ws);                                                   // quarter 0: mlps.0
     if constexpr (!EMBEDDED) {                                            // full-range sin/cos under the DMA flight
         encode<POS_L, 2>(pt, pe, half);
         encode<DIR_L, 1>(vd, de, half);
@@ -106,8 +104,6 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         bits_rs = uniform_rsrc(a.save + SL.bits, (int64_t)srows * (BITS_WORDS_PER_BLOCK / 32) * MP);
         bits_voff = (int)((blk * BITS_WORDS_PER_BLOCK + lane * 4) * 4);
     }
-    constexpr int Y0 = DMA_PER_QUARTER;            // younger VMEM ops at an acquire whose preceding boundary stored nothing
-    constexpr int YS = SAVE ? DMA_PER_QUARTER + 43 : DMA_PER_QUARTER;   // ... preceded by a 43-store batch
 
     f32x16 h[8], acc[8];
     auto save_mask8 = [&](int layer) {
@@ -117,16 +113,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(v, bits_rs, bits_voff + layer * 1024, 0, 0);
     };
     // ---- mlps.0 : 63 -> 256 (quarter 0)
-    ws_acquire<Y0>();
-    if constexpr (SAVE) {                          // issued after the acquire: 90 stores with a whole quarter to retire
+    ws_begin();
+    if constexpr (SAVE) {                          // 90 stores with a whole quarter to retire
         store_encoded_rows<POS_L, 2>(a.save + SL.pe, srows * MP, blk, lane, pe);
         store_encoded_rows<DIR_L, 1>(a.save + SL.de, srows * MP, blk, lane, de);
     }
     init_bias_lds<8>(tab + L.b0, acc, half);
-    gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, pe, acc, lane);
-    ws.cslot ^= 1;
-    ws_release_barrier();
-    ws_fetch(ws);
+    gemm_quarter<0, 8, 8>(ws, pe, acc, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
     if constexpr (SAVE) save_mask8(0);
@@ -141,30 +134,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     auto stage = [&](int st) {
         RowIO hio;
         if constexpr (SAVE) hio = make_rowio(a.save + SL.h + (int64_t)(st < 8 ? st : 7) * 256 * MP, 256, (st < 8 ? srows : 0) * MP, blk, lane);
-        ws_acquire<Y0>();
+        ws_begin();
         init_bias_lds<8>(tab + L.b_stage + st * (int)bias_floats(8), acc, half);
-        gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<0, 8, 8>(ws, h, acc, lane);
+        ws_begin();
         if constexpr (SAVE) store_rows_part<0, 43>(hio, h);
-        ws_fetch(ws);
-        ws_acquire<YS>();
-        gemm_quarter<8, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<8, 8, 8>(ws, h, acc, lane);
+        ws_begin();
         if constexpr (SAVE) store_rows_part<43, 43>(hio, h);
-        ws_fetch(ws);
-        ws_acquire<YS>();
-        gemm_quarter<16, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<16, 8, 8>(ws, h, acc, lane);
+        ws_begin();
         if constexpr (SAVE) store_rows_part<86, 42>(hio, h);
-        ws_fetch(ws);
-        ws_acquire<SAVE ? DMA_PER_QUARTER + 42 : DMA_PER_QUARTER>();
-        gemm_quarter<24, 8, 8>(lds + ws.cslot * SLOT_FLOATS, h, acc, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        ws_fetch(ws);
+        gemm_quarter<24, 8, 8>(ws, h, acc, lane);
     };
 
     // ---- trunk: mlps.1 .. mlps.7
@@ -172,11 +153,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     for (int st = 0; st < 7; ++st) {
         stage(st);
         if (st == 4) {                                                    // skip: cat[h, pts] (dm_nerf.py:87)
-            ws_acquire<Y0>();
-            gemm_quarter<0, 8, 8>(lds + ws.cslot * SLOT_FLOATS, pe, acc, lane);
-            ws.cslot ^= 1;
-            ws_release_barrier();
-            ws_fetch(ws);
+            ws_begin();
+            gemm_quarter<0, 8, 8>(ws, pe, acc, lane);
         }
 #pragma unroll
         for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
@@ -204,28 +182,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         RowIO fio;
         if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
         f32x16 hid[4];
-        ws_acquire<Y0>();
+        ws_begin();
         init_bias_lds<4>(tab + L.b_rgbh, hid, half);
-        gemm_quarter<0, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<0, 16, 4>(ws, acc, hid, lane);
+        ws_begin();
         if constexpr (SAVE) store_rows_part<0, 43>(fio, acc);
-        ws_fetch(ws);
-        ws_acquire<YS>();
-        gemm_quarter<16, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<16, 16, 4>(ws, acc, hid, lane);
+        ws_begin();
         if constexpr (SAVE) store_rows_part<43, 43>(fio, acc);
-        ws_fetch(ws);
-        ws_acquire<YS>();
-        gemm_quarter<0, 4, 4>(lds + ws.cslot * SLOT_FLOATS, de, hid, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        if constexpr (SAVE) store_rows_part<86, 42>(fio, acc);
-        ws_fetch(ws);
+        gemm_quarter<0, 4, 4>(ws, de, hid, lane);
+        if constexpr (SAVE) store_rows_part<86, 42>(fio, acc);      // (with the g1 burst below: younger than the DMA in flight)
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-        // (these 64 stores are younger than the DMA above: stage 8's first acquire over-waits once per block)
         if constexpr (SAVE) {
             store_rows<4>(make_rowio(a.save + SL.g1, 128, srows * MP, blk, lane), hid);
             unsigned m[2];
@@ -257,24 +225,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         RowIO qio;
         if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);
         f32x16 hid[4];
-        ws_acquire<Y0>();
+        ws_begin();
         init_bias_lds<4>(tab + L.b_insh, hid, half);
-        gemm_quarter<0, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
+        gemm_quarter<0, 16, 4>(ws, acc, hid, lane);
+        ws_begin();
         if constexpr (SAVE) store_rows_part<0, 43>(qio, acc);
-        ws_fetch(ws);                                                 // (runs into the zero-filled landing zone)
-        ws_acquire<YS>();
-        gemm_quarter<16, 16, 4>(lds + ws.cslot * SLOT_FLOATS, acc, hid, lane);
-        ws.cslot ^= 1;
-        ws_release_barrier();
-        if constexpr (SAVE) store_rows_part<43, 43>(qio, acc);
-        ws_fetch(ws);
+        gemm_quarter<16, 16, 4>(ws, acc, hid, lane);                  // (its fetch runs into the zero-filled landing zone)
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-        ws_acquire<YS>();
+        ws_begin();
         if constexpr (SAVE) {
-            store_rows_part<86, 42>(qio, acc);
+            store_rows_part<43, 85>(qio, acc);
             store_rows<4>(make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane), hid);
             unsigned m[2];
             pack_mask<4>(hid, m);
@@ -283,7 +244,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         }
         f32x16 io[OBI];
         init_bias_lds<OBI>(tab + L.b_inso, io, half);
-        gemm_quarter<0, 16, OBI>(lds + ws.cslot * SLOT_FLOATS, hid, io, lane);     // ins_linear (:103)
+        gemm_quarter<0, 16, OBI>(ws, hid, io, lane);                  // ins_linear (:103)
         if (valid) {
 #pragma unroll
             for (int b = 0; b < OBI; ++b) {
