@@ -23,9 +23,35 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     return r;
 }
 
+// sin / cos of v * 2^k for k = 0..L-1 with ONE shared range reduction in double precision:
+//   t = v / (2 pi) (double: |error| <= |t| 2^-53), and for each k the angle in revolutions is t * 2^k, an
+//   exact scaling; g = frac-to-nearest(t 2^k + q/4) in [-1/2, 1/2] is exact as well (q = 0: sin, q = 1: cos,
+//   cos x = sin(x + pi/2)); fold to [-1/4, 1/4] and evaluate sin(2 pi g) by its degree-15 Taylor polynomial in
+//   double (truncation 6e-12 at pi/2), round once to float.  Arguments reach 2^9 |x| ~ 7700 rad: the result is
+//   within 1/2 ulp + 2e-12 of the true value of the SAME float argument the reference feeds to sin / cos
+//   (x * freq is exact for power-of-two freq, dm_nerf.py:25,31), cheaper and tighter than a full-range sincosf.
+__device__ __forceinline__ double rev_of(float v) { return (double)v * 0.15915494309189535; }      // 1 / (2 pi)
+
+__device__ __forceinline__ float sin_rev(double t, int k, int quarter) {
+    double g = t * (double)(1 << k) + 0.25 * (double)quarter;
+    g = g - __builtin_rint(g);
+    const double ag = __builtin_fabs(g);
+    const double gf = ag > 0.25 ? 0.5 - ag : ag;
+    const double x = gf * 6.283185307179586;
+    const double x2 = x * x;
+    double p = 1.0 / 1307674368000.0;                    // 1/15!
+    p = __builtin_fma(p, x2, -1.0 / 6227020800.0);       // 1/13!
+    p = __builtin_fma(p, x2, 1.0 / 39916800.0);
+    p = __builtin_fma(p, x2, -1.0 / 362880.0);
+    p = __builtin_fma(p, x2, 1.0 / 5040.0);
+    p = __builtin_fma(p, x2, -1.0 / 120.0);
+    p = __builtin_fma(p, x2, 1.0 / 6.0);
+    const double s = x - x * x2 * p;                     // x (1 - x2/6 + x4/120 - ...)
+    return (float)__builtin_copysign(s, g);
+}
+
 // Encoding of one 3-vector in the k-pair order of layout.h::pefeat: lanes 0-31 take the sin
-// slot (and x, z), lanes 32-63 the cos slot (and y, pad).  sin/cos are ocml's full-range f32
-// routines (arguments reach 2^9 * |x|: no fast-math approximations here).
+// slot (and x, z), lanes 32-63 the cos slot (and y, pad).
 template <int L, int NV>
 __device__ __forceinline__ void encode(const float (&v)[3], f32x16 (&out)[NV], int half) {
     static_assert(NV * 16 >= 2 + 3 * L, "encoding registers too small");
@@ -33,15 +59,13 @@ __device__ __forceinline__ void encode(const float (&v)[3], f32x16 (&out)[NV], i
     for (int i = 0; i < NV; ++i) out[i] = (f32x16)(0.f);
     out[0][0] = half ? v[1] : v[0];
     out[0][1] = half ? 0.f : v[2];
+    const double t[3] = {rev_of(v[0]), rev_of(v[1]), rev_of(v[2])};
 #pragma unroll
     for (int k = 0; k < L; ++k) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int p = 2 + 3 * k + c;
-            const float arg = v[c] * (float)(1 << k);   // exact: power of two (dm_nerf.py:25,31)
-            float s, co;
-            sincosf(arg, &s, &co);
-            out[p >> 4][p & 15] = half ? co : s;
+            out[p >> 4][p & 15] = sin_rev(t[c], k, half);
         }
     }
 }

@@ -79,11 +79,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         load_encoded<POS_L, 2>(xr, pe, half);
         load_encoded<DIR_L, 1>(xr + POS_CH, de, half);
     }
-    {   // biases + VALU heads -> LDS table
+    // biases + VALU heads: global -> registers now, registers -> LDS table after the encoding below, so
+    // that neither this load nor the first weight DMA exposes its latency
+    f32x4 tabv[TAB_FLOATS / 1024];
+    {
         const f32x4* src = reinterpret_cast<const f32x4*>(blob) + threadIdx.x;
-        f32x4* dst = reinterpret_cast<f32x4*>(tab) + threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < TAB_FLOATS / 1024; ++k) dst[k * 256] = src[k * 256];
+        for (int k = 0; k < TAB_FLOATS / 1024; ++k) tabv[k] = src[k * 256];
     }
     WStream ws;
     ws.gsrc = reinterpret_cast<const char*>(blob) + lane * 16 + wave * 1024;
@@ -92,6 +94,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     if constexpr (!EMBEDDED) {                                            // full-range sin/cos under the DMA flight
         encode<POS_L, 2>(pt, pe, half);
         encode<DIR_L, 1>(vd, de, half);
+    }
+    {
+        f32x4* dst = reinterpret_cast<f32x4*>(tab) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < TAB_FLOATS / 1024; ++k) dst[k * 256] = tabv[k];
     }
 
     const SaveLayout SL = make_save_layout(a.M);

@@ -11,6 +11,7 @@
 
 #include "../../include/dmnerf_hip.h"
 #include "common.h"
+#include "mlp_common.h"
 
 namespace {
 
@@ -147,11 +148,10 @@ __global__ void embed_kernel(const float* __restrict__ x, int64_t M, int L, floa
     const float v = x[idx];
     float* o = out + m * od;
     o[c] = v;
+    const double t = dmn::rev_of(v);                 // same shared range reduction as the fused kernel
     for (int k = 0; k < L; ++k) {
-        float s, co;
-        sincosf(v * (float)(1 << k), &s, &co);
-        o[3 + 6 * k + c] = s;
-        o[3 + 6 * k + 3 + c] = co;
+        o[3 + 6 * k + c] = dmn::sin_rev(t, k, 0);
+        o[3 + 6 * k + 3 + c] = dmn::sin_rev(t, k, 1);
     }
 }
 
