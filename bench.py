@@ -137,14 +137,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # (DMNERF_BENCH_ONE_DEVICE=1 + DMNERF_BENCH_BACKEND=gloo: exercise the multi-rank code path on a 1-GPU box)
+    if os.environ.get("DMNERF_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("DMNERF_BENCH_BACKEND", "nccl")                      # "nccl" is RCCL on ROCm
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from dm_nerf_amd import _lib
+    from dm_nerf_amd import _lib, distributed as D
     from dm_nerf_amd.networks import helpers as H, render as R
     from oracle.ref_cpu import dmsr_intrinsics, pose_spherical   # synthetic camera definition only (host numpy)
 
@@ -160,7 +166,6 @@ def main():
     args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None)
     mc.blob(); mf.blob()                                        # packed weights resident
     tile = torch.empty(N_RAYS, 3 + INS_NUM + 1, device=dev)
-    gathered = torch.empty(world * N_RAYS, 3 + INS_NUM + 1, device=dev) if world > 1 else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
     def step(i, events=None):
@@ -169,7 +174,7 @@ def main():
         out = R.dm_nerf(rays, pe, ve, mc, mf, z, args, _events=events)
         if world > 1:                                           # all-gather of the rendered tile (rgb | ins | depth)
             tile[:, :3] = out['rgb_fine']; tile[:, 3:3 + INS_NUM] = out['ins_fine']; tile[:, -1] = out['depth_fine']
-            dist.all_gather_into_tensor(gathered, tile)
+            D.all_gather_cat(tile)
         return out
 
     def barrier():

@@ -63,7 +63,12 @@ def all_gather_cat(t, sizes=None):
     t = t.contiguous()
     if sizes is None or len(set(sizes)) == 1:
         out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t)
+        try:
+            dist.all_gather_into_tensor(out, t)          # one RCCL all-gather
+        except (RuntimeError, NotImplementedError):      # backends without the tensor form (gloo on device tensors)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            out = torch.cat(parts, 0)
         return out
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -89,6 +94,17 @@ def allreduce_grads(models, average=False):
         p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
     return flat.numel() * flat.element_size()
+
+
+def data_parallel_backward(loss_local, models, n_local, n_global):
+    """Ray-sharded training step: every rank rendered ``n_local`` of the ``n_global`` rays of the SAME
+    batch and formed ``loss_local`` as a SUM over its rays of per-ray terms (e.g. ``((rgb - target)**2).sum()``).
+    Scales it so that the all-reduced gradients equal those of the mean over the global batch, runs backward and
+    sums the gradients over ranks in one bucket.  Batch-global losses (Hungarian cost, penalizer normalisers) need
+    ``all_gather_cat`` of the small per-ray outputs first -- they are not a sum of per-ray terms."""
+    del n_local
+    (loss_local / float(n_global)).backward()
+    return allreduce_grads(models)
 
 
 def _default_raygen(H, W, K, c2w, row0, nrows):

@@ -64,6 +64,17 @@ def _worker(rank, world, port, q):
                 p.grad = torch.full_like(p, float(rank + 1))
         nbytes = D.allreduce_grads(lin)
         g_ok = all(bool((p.grad == 3.0).all()) for m in lin for p in m.parameters())
+        # ray-sharded training step == single-process gradients (mean-squared error over the global batch)
+        torch.manual_seed(0)
+        lin2 = torch.nn.Linear(3, 3)
+        g = torch.Generator().manual_seed(5)
+        xs, ys = torch.randn(10, 3, generator=g), torch.randn(10, 3, generator=g)
+        s0, cnt = D.ray_slice(10, rank, world)
+        D.data_parallel_backward(((lin2(xs[s0:s0 + cnt]) - ys[s0:s0 + cnt]) ** 2).sum(), [lin2], cnt, 10)
+        ref = torch.nn.Linear(3, 3)
+        ref.load_state_dict(lin2.state_dict())
+        (((ref(xs) - ys) ** 2).sum() / 10).backward()
+        g_ok = g_ok and all(torch.allclose(p.grad, q.grad, atol=1e-6) for p, q in zip(lin2.parameters(), ref.parameters()))
         # uneven all_gather_cat
         t = torch.arange(rank + 2, dtype=torch.float32)[:, None] + 10 * rank
         cat = D.all_gather_cat(t, sizes=[2, 3])
