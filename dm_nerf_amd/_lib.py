@@ -58,6 +58,10 @@ SIGNATURES = {
     "dmnerf_blob_t_floats": (c_i64, [c_int]),
     "dmnerf_build_pack_index_t": (c_int, [c_int, c_vp, c_i64]),
     "dmnerf_mlp_bwd_data": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dmnerf_manipulator_render": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_z_val_lerp": (c_int, [c_vp, c_float, c_float, c_i64, c_int, c_vp, c_vp]),
+    "dmnerf_sort_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "dmnerf_exchanger": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_penalizer_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp]),
     "dmnerf_penalizer_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan_sizes": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

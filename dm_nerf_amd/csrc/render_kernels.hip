@@ -160,7 +160,7 @@ __global__ void embed_kernel(const float* __restrict__ x, int64_t M, int L, floa
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
     const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int64_t N,
-    int S, int C, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map,
+    int S, int C, int n_ins, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map,
     float* __restrict__ ins_map) {
     __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -215,9 +215,10 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
         if (c < 3) {
             for (int s = 0; s < S; ++s) acc += (double)(wl[s] * sigmoidf_ref(rr[(int64_t)s * ch + c]));
             rgb_map[n * 3 + c] = (float)acc;
-        } else if (c - 4 < C - 1) {
+        } else if (c - 4 < n_ins) {
             for (int s = 0; s < S; ++s) acc += (double)(wl[s] * rr[(int64_t)s * ch + c]);
-            ins_map[n * (int64_t)(C - 1) + (c - 4)] = sigmoidf_ref((float)acc);      // sigmoid after the sum, last channel dropped
+            // sigmoid after the sum; n_ins = C-1 drops the last channel (render.py:24-26), n_ins = C keeps it (manipulator.py:101-102)
+            ins_map[n * (int64_t)n_ins + (c - 4)] = sigmoidf_ref((float)acc);
         }
     }
 }
@@ -521,6 +522,89 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void sample_kernel(const Samp
     }
 }
 
+// manipulator z grid (networks/manipulator.py:117-119): near (1 - t) + far t
+__global__ void zlerp_kernel(const float* __restrict__ t, float near_, float far_, int64_t total, int S, float* __restrict__ z) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float tv = t[idx % S];
+    z[idx] = near_ * (1.f - tv) + far_ * tv;
+}
+
+// torch.sort(x, -1) values of each row (manipulator.py:191,195): rank sort, one wave per row
+constexpr int MAX_SORT = 2048;
+__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void sort_rows_kernel(const float* __restrict__ in, int64_t N, int K, float* __restrict__ out) {
+    __shared__ float v_lds[RAYS_PER_BLOCK][MAX_SORT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (n >= N) return;
+    float* all = v_lds[wv];
+    for (int j = lane; j < K; j += WAVE) all[j] = in[n * (int64_t)K + j];
+    lds_sync_wave();
+    for (int e = lane; e < K; e += WAVE) {
+        const float v = all[e];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) {
+            const float o = all[j];
+            rank += (o < v) || (o == v && j < e);
+        }
+        out[n * (int64_t)K + rank] = v;
+    }
+}
+
+// exchanger (networks/manipulator.py:18-83): per (ray, sample) label logic + masked swaps of the raw rows
+constexpr int MAX_MOVE = 8;
+struct ExchArgs {
+    float* ori_raw;                       // [N,S,4+C], modified in place
+    const float* tar_raw[MAX_MOVE];       // T x [N,S,4+C]
+    const float* ori_acc;                 // [N,C] accumulated object map of the original rays
+    const float* tar_acc[MAX_MOVE];       // T x [N,C]
+    int labels[MAX_MOVE];
+    int T, S, C;
+    int64_t N;
+    int64_t* ori_label;                   // [N,S] out (nullable)
+    int64_t* tar_label;                   // [N,S] out: labels of the LAST target (nullable)
+};
+
+__device__ __forceinline__ int argmax_sigmoid(const float* x, int n) {
+    int best = 0;
+    float bv = sigmoidf_ref(x[0]);
+    for (int c = 1; c < n; ++c) {
+        const float v = sigmoidf_ref(x[c]);
+        if (v > bv) { bv = v; best = c; }          // first maximum wins, like torch.argmax on CPU
+    }
+    return best;
+}
+
+__global__ void exchanger_kernel(const ExchArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.N * a.S) return;
+    const int64_t n = idx / a.S;
+    const int ch = 4 + a.C;
+    float* orow = a.ori_raw + idx * ch;
+    int ori_lab = argmax_sigmoid(orow + 4, a.C);
+    const int ori_acc_lab = argmax_sigmoid(a.ori_acc + n * a.C, a.C - 1);
+    int tar_lab_last = 0;
+    for (int t = 0; t < a.T; ++t) {
+        const int L = a.labels[t];
+        const float* trow = a.tar_raw[t] + idx * ch;
+        if (ori_acc_lab != L && ori_lab == L) ori_lab = ori_acc_lab;                 // occluded: take the ray's label
+        const bool fill = ori_acc_lab == L && ori_lab != L;
+        int tar_lab = argmax_sigmoid(trow + 4, a.C);
+        const int tar_acc_lab = argmax_sigmoid(a.tar_acc[t] + n * a.C, a.C - 1);
+        if (tar_acc_lab != L && tar_lab == L) tar_lab = tar_acc_lab;
+        const int reduced = (tar_lab == L ? 1 : 0) + (ori_lab == L ? 2 : 0);          // tar_move_mask - ori_move_mask
+        const int op = reduced == 0 ? -1 : (reduced == 2 ? 0 : 1);                    // -1 keep, 0 eliminate, 1 exchange
+        if (fill || op == 1) {
+            for (int c = 0; c < ch; ++c) orow[c] = trow[c];
+        } else if (op == 0) {
+            for (int c = 0; c < ch; ++c) orow[c] = orow[c] * 0.f;
+        }
+        tar_lab_last = tar_lab;
+    }
+    if (a.ori_label) a.ori_label[idx] = ori_lab;
+    if (a.tar_label) a.tar_label[idx] = tar_lab_last;
+}
+
 __global__ void gather_kernel(const float* __restrict__ flat, const int32_t* __restrict__ idx,
                               float* __restrict__ blob, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -590,8 +674,20 @@ extern "C" int dmnerf_composite_fwd(const float* d_raw, const float* d_z, const 
     if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "composite_fwd: bad N=%lld S=%d (max %d) C=%d", (long long)N, S, MAX_S, C);
     if (N == 0) return DMNERF_OK;
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
-                       d_raw, d_z, d_rays_d, N, S, C, d_rgb_map, d_weights, d_depth_map, d_ins_map);
+                       d_raw, d_z, d_rays_d, N, S, C, C - 1, d_rgb_map, d_weights, d_depth_map, d_ins_map);
     return dmn_check_launch("composite_fwd");
+}
+
+extern "C" int dmnerf_manipulator_render(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N,
+                                         int S, int C, float* d_rgb_map, float* d_weights, float* d_depth_map,
+                                         float* d_ins_map, void* stream) {
+    if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "manipulator_render: bad N=%lld S=%d (max %d) C=%d", (long long)N, S, MAX_S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_rays_d || !d_rgb_map || !d_weights || !d_depth_map || !d_ins_map)
+        return dmn_fail(DMNERF_E_ARG, "manipulator_render: null pointer");
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+                       d_raw, d_z, d_rays_d, N, S, C, C, d_rgb_map, d_weights, d_depth_map, d_ins_map);
+    return dmn_check_launch("manipulator_render");
 }
 
 extern "C" int dmnerf_sample_pdf(const float* d_bins, const float* d_weights, const float* d_u, int64_t u_row_stride,
@@ -685,4 +781,35 @@ extern "C" int dmnerf_raygen_select(int H, int W, const float* h_intr, const flo
     a.W = W; a.row0 = 0; a.n = n; a.rays_o = d_rays_o; a.rays_d = d_rays_d;
     hipLaunchKernelGGL(raygen_select_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, d_idx);
     return dmn_check_launch("raygen_select");
+}
+
+extern "C" int dmnerf_z_val_lerp(const float* d_t, float near_, float far_, int64_t N, int S, float* d_z, void* stream) {
+    if (!d_t || !d_z || N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "z_val_lerp: bad argument");
+    if (N == 0) return DMNERF_OK;
+    hipLaunchKernelGGL(zlerp_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, (hipStream_t)stream, d_t, near_, far_, N * S, S, d_z);
+    return dmn_check_launch("z_val_lerp");
+}
+
+extern "C" int dmnerf_sort_rows(const float* d_in, int64_t N, int K, float* d_out, void* stream) {
+    if (N < 0 || K < 1 || K > MAX_SORT) return dmn_fail(DMNERF_E_ARG, "sort_rows: bad N=%lld K=%d (max %d)", (long long)N, K, MAX_SORT);
+    if (N == 0) return DMNERF_OK;
+    if (!d_in || !d_out || d_in == d_out) return dmn_fail(DMNERF_E_ARG, "sort_rows: null or aliased pointers");
+    hipLaunchKernelGGL(sort_rows_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, d_in, N, K, d_out);
+    return dmn_check_launch("sort_rows");
+}
+
+extern "C" int dmnerf_exchanger(float* d_ori_raw, const float* const* h_tar_raws, const float* d_ori_acc,
+                                const float* const* h_tar_accs, const int* h_labels, int T, int64_t N, int S, int C,
+                                int64_t* d_ori_label, int64_t* d_tar_label, void* stream) {
+    if (T < 1 || T > MAX_MOVE || N < 0 || S < 1 || C < 2) return dmn_fail(DMNERF_E_ARG, "exchanger: bad T=%d (max %d) N=%lld S=%d C=%d", T, MAX_MOVE, (long long)N, S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_ori_raw || !h_tar_raws || !d_ori_acc || !h_tar_accs || !h_labels) return dmn_fail(DMNERF_E_ARG, "exchanger: null pointer");
+    ExchArgs a{};
+    a.ori_raw = d_ori_raw; a.ori_acc = d_ori_acc; a.T = T; a.S = S; a.C = C; a.N = N; a.ori_label = d_ori_label; a.tar_label = d_tar_label;
+    for (int t = 0; t < T; ++t) {
+        if (!h_tar_raws[t] || !h_tar_accs[t]) return dmn_fail(DMNERF_E_ARG, "exchanger: null target pointer %d", t);
+        a.tar_raw[t] = h_tar_raws[t]; a.tar_acc[t] = h_tar_accs[t]; a.labels[t] = h_labels[t];
+    }
+    hipLaunchKernelGGL(exchanger_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return dmn_check_launch("exchanger");
 }

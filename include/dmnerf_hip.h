@@ -165,6 +165,22 @@ int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const floa
                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                            float* d_part, float* d_grad_flat, void* stream);
 
+/* ---- manipulator.py (scene editing at render time) -----------------------------------
+ * manipulator_render (networks/manipulator.py:86-105): render_train whose object map keeps all C channels
+ * (d_ins_map [N,C]).  z_val_lerp: the grid of manipulator_nerf (:117-119), near (1-t) + far t.
+ * sort_rows: torch.sort(x, -1).values per row (K <= 2048), exact permutation (:191,:195).
+ * exchanger (:18-83): per-sample / per-ray argmax labels and the masked swaps of raw rows, d_ori_raw modified in
+ * place; h_tar_raws / h_tar_accs: HOST arrays of T device pointers ([N,S,4+C] / [N,C]); h_labels: T moved labels;
+ * outputs (nullable): int64 labels [N,S] of the original rays and of the last target.                 */
+int dmnerf_manipulator_render(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N, int S,
+                              int C, float* d_rgb_map, float* d_weights, float* d_depth_map,
+                              float* d_ins_map, void* stream);
+int dmnerf_z_val_lerp(const float* d_t, float near_, float far_, int64_t N, int S, float* d_z, void* stream);
+int dmnerf_sort_rows(const float* d_in, int64_t N, int K, float* d_out, void* stream);
+int dmnerf_exchanger(float* d_ori_raw, const float* const* h_tar_raws, const float* d_ori_acc,
+                     const float* const* h_tar_accs, const int* h_labels, int T, int64_t N, int S, int C,
+                     int64_t* d_ori_label, int64_t* d_tar_label, void* stream);
+
 /* ---- penalizer.py (the consumer of raw / z_vals / depth) ---------------------------
  * emptiness_penalizer (networks/penalizer.py:5-55) fused: _fwd writes per-ray partial sums
  * d_partials [N,4] (double): {sum BCE*w_before, sum m_before, sum loss_middle*w_middle, sum m_middle};

@@ -309,6 +309,117 @@ def ins_penalizer(raw, z_vals, depth, rays_d, tolerance, deta_w):
 
 
 # --------------------------------------------------------------------------------------
+# manipulation render  (networks/manipulator.py:18-205) -- SURVEY 8(f)-3
+# --------------------------------------------------------------------------------------
+
+def exchanger(ori_raw, tar_raws, ori_raw_pred, tar_raw_preds, move_labels):
+    """``exchanger`` (networks/manipulator.py:18-83).  Mutates ``ori_raw`` in place, like the reference."""
+    ori_pred_label = torch.argmax(torch.sigmoid(ori_raw[..., 4:]), dim=-1)
+    ori_accum_label = torch.argmax(torch.sigmoid(ori_raw_pred[..., :-1]), dim=-1)
+    ori_accum_label = ori_accum_label[:, None].repeat(1, ori_pred_label.shape[-1])
+    tar_pred_label_temp = None
+    for idx, move_label in enumerate(move_labels):
+        tar_raw = tar_raws[idx]
+        tar_raw_pre = tar_raw_preds[idx]
+        ori_occludes = (ori_accum_label != move_label) * (ori_pred_label == move_label)
+        ori_pred_label[ori_occludes == True] = ori_accum_label[ori_occludes == True]
+        fillings = (ori_accum_label == move_label) * (ori_pred_label != move_label)
+        tar_pred_label = torch.argmax(torch.sigmoid(tar_raw[..., 4:]), dim=-1)
+        tar_pred_label_temp = tar_pred_label
+        tar_accum_label = torch.argmax(torch.sigmoid(tar_raw_pre[..., :-1]), dim=-1)
+        tar_accum_label = tar_accum_label[:, None].repeat(1, tar_pred_label.shape[-1])
+        tar_occludes = (tar_accum_label != move_label) * (tar_pred_label == move_label)
+        tar_pred_label[tar_occludes == True] = tar_accum_label[tar_occludes == True]
+        operation_mask = torch.zeros_like(ori_pred_label)
+        ori_move_mask, tar_move_mask = torch.zeros_like(ori_pred_label), torch.zeros_like(tar_pred_label)
+        ori_move_mask[ori_pred_label == move_label] = -2
+        tar_move_mask[tar_pred_label == move_label] = 1
+        reduced_mask = tar_move_mask - ori_move_mask
+        operation_mask[reduced_mask == 0] = -1
+        operation_mask[reduced_mask == 1] = 1
+        operation_mask[reduced_mask == 2] = 0
+        operation_mask[reduced_mask == 3] = 1
+        ori_raw[fillings] = tar_raw[fillings]
+        ori_raw[operation_mask == 1] = tar_raw[operation_mask == 1]
+        ori_raw[operation_mask == 0] = ori_raw[operation_mask == 0] * 0
+    return ori_raw, tar_raws, ori_pred_label, tar_pred_label_temp
+
+
+def manipulator_render(raw, z_vals, rays_d):
+    """``manipulator_render`` (networks/manipulator.py:86-105): like render_train, but the object map keeps all
+    C channels and is not detached."""
+    dev = raw.device
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.tensor([1e10], device=dev).expand(dists[..., :1].shape)], -1)
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+    rgb = torch.sigmoid(raw[..., :3])
+    alpha = 1. - torch.exp(-F.relu(raw[..., 3]) * dists)
+    weights = alpha * torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1), device=dev), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)
+    ins_map = torch.sigmoid(torch.sum(weights[..., None] * raw[..., 4:], -2))
+    depth_map = torch.sum(weights * z_vals, -1)
+    return rgb_map, weights, depth_map, ins_map
+
+
+def manipulator_z(N_rays, near, far, N_samples, device="cpu"):
+    """z grid of ``manipulator_nerf`` (:114-119): ``near (1 - t) + far t`` (rounds differently from z_val_sample)."""
+    near_, far_ = near * torch.ones(size=(N_rays, 1), device=device), far * torch.ones(size=(N_rays, 1), device=device)
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=device)
+    return (near_ * (1. - t_vals) + far_ * t_vals).expand([N_rays, N_samples])
+
+
+def manipulator_nerf(rays, sd, N_samples=None, near=None, far=None, z_vals=None):
+    """``manipulator_nerf`` (networks/manipulator.py:108-134) with the model as a state_dict."""
+    rays_o, rays_d = rays
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    if z_vals is None:
+        z_vals = manipulator_z(rays_d.shape[0], near, far, N_samples, rays_d.device)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    e = torch.cat([embed(pts.reshape(-1, 3), 10), embed(viewdirs[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1)
+    raw = mlp_forward(sd, e)
+    return torch.reshape(raw, list(pts.shape[:-1]) + [raw.shape[-1]]), z_vals
+
+
+def manipulator(sd_coarse, sd_fine, ori_rays, f_tar_rays, N_samples, N_importance, near, far, target_labels, us=None):
+    """``manipulator`` (networks/manipulator.py:137-205).  ``us``: optional list of the ``2 + T`` uniform draws
+    [N, N_importance] in the order the reference makes them (original, each target, original again)."""
+    us = list(us) if us is not None else None
+    draw = lambda: us.pop(0) if us is not None else None
+    ori_raw, ori_z = manipulator_nerf(ori_rays, sd_coarse, N_samples, near, far)
+    _, ori_w, _, _ = manipulator_render(ori_raw, ori_z, ori_rays[1])
+    ori_mid = .5 * (ori_z[..., 1:] + ori_z[..., :-1])
+    ori_zs = sample_pdf(ori_mid, ori_w[..., 1:-1], N_importance, u=draw())
+    ori_z_full, _ = torch.sort(torch.cat([ori_z, ori_zs], dim=-1), dim=-1)
+    ori_raw_full, _ = manipulator_nerf(ori_rays, sd_fine, N_samples, near, far, z_vals=ori_z_full)
+    _, _, _, ori_ins_accum = manipulator_render(ori_raw_full, ori_z_full, ori_rays[1])
+    tar_raws, f_tar_z, f_tar_zs, tar_ins_accums = [], [], [], []
+    tar_rgb = tar_ins_accum = None
+    for tar_rays in f_tar_rays:
+        tar_raw, tar_z = manipulator_nerf(tar_rays, sd_coarse, N_samples, near, far)
+        tar_raws.append(tar_raw); f_tar_z.append(tar_z)
+        tar_rgb, tar_w, _, _ = manipulator_render(tar_raw, tar_z, tar_rays[1])
+        tar_mid = .5 * (tar_z[..., 1:] + tar_z[..., :-1])
+        tar_zs = sample_pdf(tar_mid, tar_w[..., 1:-1], N_importance, u=draw())
+        tar_z_full, _ = torch.sort(torch.cat([tar_z, tar_zs], dim=-1), dim=-1)
+        tar_raw_full, _ = manipulator_nerf(tar_rays, sd_fine, z_vals=tar_z_full)
+        _, _, _, tar_ins_accum = manipulator_render(tar_raw_full, tar_z_full, tar_rays[1])
+        f_tar_zs.append(tar_zs); tar_ins_accums.append(tar_ins_accum)
+    ori_raw, _, _, _ = exchanger(ori_raw, tar_raws, ori_ins_accum, tar_ins_accums, target_labels)
+    _, ori_w, _, _ = manipulator_render(ori_raw, ori_z, ori_rays[1])
+    ori_zs = sample_pdf(.5 * (ori_z[..., 1:] + ori_z[..., :-1]), ori_w[..., 1:-1], N_importance, u=draw())
+    f_tar_zs = torch.cat(f_tar_zs, dim=-1)
+    ori_z, _ = torch.sort(torch.cat([ori_z, ori_zs, f_tar_zs], dim=-1), dim=-1)
+    for idx, tar_rays in enumerate(f_tar_rays):
+        ori_raw, ori_z = manipulator_nerf(ori_rays, sd_fine, z_vals=ori_z)
+        tar_z, _ = torch.sort(torch.cat([f_tar_z[idx], ori_zs, f_tar_zs], dim=-1), dim=-1)
+        tar_raws[idx], _ = manipulator_nerf(tar_rays, sd_fine, z_vals=tar_z)
+    ori_raw, _, _, _ = exchanger(ori_raw, tar_raws, ori_ins_accum, tar_ins_accums, target_labels)
+    final_rgb, _, _, final_ins = manipulator_render(ori_raw, ori_z, ori_rays[1])
+    return final_rgb, final_ins, tar_rgb, tar_ins_accum
+
+
+# --------------------------------------------------------------------------------------
 # synthetic scene (SURVEY.md section 8(d)); used by tests and bench
 # --------------------------------------------------------------------------------------
 

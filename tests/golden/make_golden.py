@@ -258,6 +258,85 @@ def gen_select():
     save("select", rgb=rgb, lab=lab, c2w=c2w, K=K, idx=idx, target_c=tc, target_i=ti, rays=rays, HWN=np.array([H, W, N]))
 
 
+def gen_manipulator():
+    """exchanger / manipulator_render / manipulator (networks/manipulator.py:18-205).  The module imports cv2,
+    lpips, imageio, skimage at the top for its eval drivers only: stub them (the arithmetic does not use them)."""
+    from unittest.mock import MagicMock
+    for mod in ("imageio", "lpips", "cv2", "skimage", "skimage.metrics", "open3d", "matplotlib", "matplotlib.pyplot",
+                "matplotlib.cm", "h5py", "configargparse", "trimesh"):
+        sys.modules.setdefault(mod, MagicMock())
+    import networks.manipulator as R_mani
+    out = {}
+    C = 8
+    gen = torch.Generator().manual_seed(701)
+    N, S = 40, 24
+    ori_raw = torch.randn(N, S, 4 + C, generator=gen) * 2
+    tar_raws = [torch.randn(N, S, 4 + C, generator=gen) * 2 for _ in range(2)]
+    ori_acc = torch.rand(N, C, generator=gen)
+    tar_accs = [torch.rand(N, C, generator=gen) for _ in range(2)]
+    labels = [2, 5]
+    # make the moved labels frequent so every branch of the mask logic is hit
+    for t in [ori_raw] + tar_raws:
+        t[:, ::3, 4 + 2] += 4.0
+        t[:, 1::4, 4 + 5] += 4.0
+    ori_acc[::2, 2] = 2.0; ori_acc[1::4, 5] = 2.0
+    for t in tar_accs:
+        t[::3, 2] = 2.0; t[1::3, 5] = 2.0
+    r_in = [ori_raw.clone(), [t.clone() for t in tar_raws]]
+    ro, rt, rl, rtl = R_mani.exchanger(r_in[0], r_in[1], ori_acc, tar_accs, labels)
+    o_in = [ori_raw.clone(), [t.clone() for t in tar_raws]]
+    oo, ot, ol, otl = O.exchanger(o_in[0], o_in[1], ori_acc, tar_accs, labels)
+    beq(oo, ro, "exchanger raw"); beq(ol, rl, "exchanger ori labels"); beq(otl, rtl, "exchanger tar labels")
+    out.update(ex_ori_raw=ori_raw, ex_tar_raw0=tar_raws[0], ex_tar_raw1=tar_raws[1], ex_ori_acc=ori_acc,
+               ex_tar_acc0=tar_accs[0], ex_tar_acc1=tar_accs[1], ex_labels=np.array(labels),
+               ex_out_raw=ro, ex_out_ori_label=rl, ex_out_tar_label=rtl)
+    # manipulator_render
+    raw = torch.randn(5, 64, 4 + C, generator=gen) * 2
+    z = torch.sort(torch.rand(5, 64, generator=gen) * 4, -1)[0]
+    d = torch.randn(5, 3, generator=gen)
+    rr = R_mani.manipulator_render(raw, z, d)
+    oo_ = O.manipulator_render(raw, z, d)
+    for a_, b_, n_ in zip(oo_, rr, ("rgb", "w", "depth", "ins")):
+        beq(a_, b_, f"manipulator_render {n_}")
+    out.update(mr_raw=raw, mr_z=z, mr_d=d, mr_rgb=rr[0], mr_w=rr[1], mr_depth=rr[2], mr_ins=rr[3])
+    # the manipulator z grid: near (1-t) + far t
+    zz = R_mani.manipulator_nerf  # noqa: F841
+    out["mz"] = O.manipulator_z(2, 0.0, 4.7, 64).contiguous()
+    # full manipulator, T = 1 and T = 2
+    ins_num = C - 1
+    sd_c = O.make_weights(711, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(712, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = ref_model(sd_c, ins_num), ref_model(sd_f, ins_num)
+    pe, _ = R_model.get_embedder(10, 0); ve, _ = R_model.get_embedder(4, 0)
+    Nr = 12
+    K = O.dmsr_intrinsics(480, 640)
+    c2w = O.pose_spherical(37.0, -65.0, 7.0)
+    ro_, rd_ = R_helpers.get_rays_k(480, 640, K, c2w)
+    sel = torch.from_numpy(np.random.RandomState(9).choice(480 * 640, Nr, replace=False))
+    ori_rays = torch.stack([ro_.reshape(-1, 3)[sel], rd_.reshape(-1, 3)[sel]], 0)
+    tars = []
+    for k in range(2):
+        tr = ori_rays.clone()
+        tr[0] = tr[0] + torch.tensor([0.3 * (k + 1), -0.2, 0.1])
+        tars.append(tr)
+    out.update(m_ori_rays=ori_rays, m_tar_rays0=tars[0], m_tar_rays1=tars[1], m_seed_c=np.int64(711), m_seed_f=np.int64(712),
+               m_ins_num=np.int64(ins_num))
+    for T in (1, 2):
+        a = types.SimpleNamespace(N_samples=64, N_importance=128, near=4.0, far=15.0, target_labels=labels[:T])
+        with torch.no_grad():
+            torch.manual_seed(720 + T)
+            ref = R_mani.manipulator(pe, ve, mc, mf, ori_rays, tars[:T], a)
+            torch.manual_seed(720 + T)
+            us = [torch.rand(Nr, 128) for _ in range(2 + T)]
+            ora = O.manipulator(sd_c, sd_f, ori_rays, tars[:T], 64, 128, 4.0, 15.0, labels[:T], us=us)
+        for a_, b_, n_ in zip(ora, ref, ("final_rgb", "final_ins", "tar_rgb", "tar_ins_accum")):
+            beq(a_, b_, f"manipulator T={T} {n_}")
+            out[f"m{T}_{n_}"] = b_
+        for i, u_ in enumerate(us):
+            out[f"m{T}_u{i}"] = u_
+    save("manipulator", **out)
+
+
 def gen_penalizer():
     """``ins_penalizer`` (penalizer.py:58-62) value and its gradient w.r.t. raw, tolerance/deta_w of the configs."""
     out = {}
@@ -295,4 +374,5 @@ if __name__ == "__main__":
     gen_dm_nerf()
     gen_penalizer()
     gen_select()
+    gen_manipulator()
     print("all oracle == reference checks passed (bit-exact)")
