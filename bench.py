@@ -152,7 +152,7 @@ def main():
 
     from dm_nerf_amd import _lib, distributed as D
     from dm_nerf_amd.networks import helpers as H, render as R
-    from oracle.ref_cpu import dmsr_intrinsics, pose_spherical   # synthetic camera definition only (host numpy)
+    from dm_nerf_amd.synthetic import dmsr_intrinsics, pose_spherical
 
     pe, ve, mc, mf = build_models(dev)
     K = dmsr_intrinsics(H_IMG, W_IMG)
