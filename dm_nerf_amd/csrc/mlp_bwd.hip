@@ -121,14 +121,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     {
         // ---- ins branch: dg2 = relu'(g2) . (W_io^T g_ins);  dq = W_ih^T dg2 ----------------------
         f32x16 t4[4], d4[4];
-        zero<4>(t4);
         ws_begin();
-        gemm_quarter<0, 4 * OBI, 4>(ws, gi, t4, lane);
+        gemm_quarter<0, 4 * OBI, 4, true>(ws, gi, t4, lane);
         apply_mask<4>(d4, g2bits, t4);
         store_rows<4>(make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane), d4);     // burst (once per block)
-        zero<8>(acc);
         ws_begin();
-        gemm_quarter<0, 8, 8>(ws, d4, acc, lane);
+        gemm_quarter<0, 8, 8, true>(ws, d4, acc, lane);
         ws_begin();
         gemm_quarter<8, 8, 8>(ws, d4, acc, lane);
         store_rows<8>(make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane), acc);      // dq (ins_feature has no activation)
@@ -150,9 +148,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         }
         apply_mask<4>(d4, g1bits, t4);
         store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);
-        zero<8>(acc);
         ws_begin();
-        gemm_quarter<0, 8, 8>(ws, d4, acc, lane);
+        gemm_quarter<0, 8, 8, true>(ws, d4, acc, lane);
         ws_begin();
         gemm_quarter<8, 8, 8>(ws, d4, acc, lane);
 #pragma unroll
@@ -164,9 +161,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
 #pragma nounroll
     for (int st = 0; st < NSTAGE_T; ++st) {
         const RowIO dio = make_rowio(st == 0 ? a.dsave + SL.f : a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
-        zero<8>(acc);
         ws_begin();
-        gemm_quarter<0, 8, 8>(ws, d, acc, lane);
+        gemm_quarter<0, 8, 8, true>(ws, d, acc, lane);
         ws_begin();
         store_rows_part<0, 43>(dio, d);
         gemm_quarter<8, 8, 8>(ws, d, acc, lane);

@@ -221,7 +221,7 @@ __device__ __forceinline__ void ws_begin() {
 
 // One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
 // operands from the LDS slot (group-local index), B from registers (accumulator layout).
-template <int G0, int NG, int OB, int NB>
+template <int G0, int NG, int OB, bool ZERO = false, int NB>
 __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
     static_assert(NB * 16 >= (G0 + NG) * 4, "B operand too small");
     static_assert(NG * OB <= 64, "more than one quarter");
@@ -235,7 +235,11 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
         for (int kk = 0; kk < 4; ++kk) {
             const int p = (G0 + gl) * 4 + kk;
 #pragma unroll
-            for (int ob = 0; ob < OB; ++ob) acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
+            for (int ob = 0; ob < OB; ++ob) {
+                // ZERO: this quarter starts the GEMM -- C = 0 is an inline constant of the MFMA, no accumulator clear
+                if (ZERO && G0 + gl == 0 && kk == 0) acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], (f32x16)(0.f));
+                else acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
+            }
         }
         if (gl == 0) ws_fetch(ws);          // next quarter -> the other slot, behind the first group's MFMAs
     }
@@ -275,7 +279,11 @@ __device__ __forceinline__ void pack_mask(const f32x16 (&h)[NB], unsigned (&m)[N
 template <int NB>
 __device__ __forceinline__ void apply_mask(f32x16 (&d)[NB], const unsigned (&m)[NB / 2], const f32x16 (&g)[NB]) {
 #pragma unroll
-    for (int p = 0; p < NB * 16; ++p) d[p >> 4][p & 15] = ((m[p >> 5] >> (p & 31)) & 1u) ? g[p >> 4][p & 15] : 0.f;
+    for (int p = 0; p < NB * 16; ++p) {
+        // sign-extended 1-bit field = 0 or ~0: two VALU ops per register (bfe + and)
+        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)m[p >> 5], p & 31, 1);
+        d[p >> 4][p & 15] = __uint_as_float(__float_as_uint(g[p >> 4][p & 15]) & keep);
+    }
 }
 
 // Stores registers [P0, P0 + NP) (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
