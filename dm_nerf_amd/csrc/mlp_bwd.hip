@@ -113,8 +113,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
             }
     }
     WStream ws;
-    ws.gsrc = reinterpret_cast<const char*>(a.blobT) + lane * 16 + wave * 1024;
-    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(LT.stream * 4); ws.cslot = 0;
+    ws_init(ws, a.blobT, LT.total, lds, lane, wave, LT.stream);
     ws_fetch_first(ws);                                                   // quarter 0: ins_linear^T
 
     f32x16 d[8], acc[8];

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "layout.h"
 
 namespace dmn {
@@ -16,10 +19,16 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// relu as ONE integer max on the bit pattern (negative floats are negative ints; -0 -> +0): fmaxf costs a
+// second v_max_f32 (sNaN quieting), and every VALU instruction is paid for in MFMA time.
+__device__ __forceinline__ float relu1(float x) {
+    const int xi = (int)__float_as_uint(x);
+    return __uint_as_float((unsigned)(xi > 0 ? xi : 0));
+}
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     f32x16 r;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = fmaxf(v[i], 0.f);
+    for (int i = 0; i < 16; ++i) r[i] = relu1(v[i]);
     return r;
 }
 
@@ -190,19 +199,35 @@ constexpr int DMA_PER_QUARTER = 16;                        // LDS-DMA instructio
 #define DMN_LAS __attribute__((address_space(3)))
 
 struct WStream {
-    const char* gsrc;     // blob + lane*16 + wave*1024 (per-lane global source of piece 0)
+    rsrc_t rs;            // the whole blob as a raw buffer (uniform)
+    unsigned voff;        // lane*16 + wave*1024: this lane's bytes of piece 0 of a quarter
     float* ring;          // LDS ring base
     int wave;             // wave id in the workgroup (uniform)
-    unsigned off;         // byte offset from the blob start of the next quarter to fetch
+    unsigned off;         // byte offset from the blob start of the next quarter to fetch (uniform)
     int cslot;            // ring slot of the next quarter to consume
 };
 
+__device__ __forceinline__ void ws_init(WStream& ws, const float* blob, int64_t blob_floats, float* ring, int lane, int wave,
+                                        int64_t stream_float_off) {
+    ws.rs = uniform_rsrc(blob, blob_floats);
+    ws.wave = __builtin_amdgcn_readfirstlane(wave);
+    ws.voff = (unsigned)(lane * 16 + ws.wave * 1024);
+    ws.ring = ring;
+    ws.off = __builtin_amdgcn_readfirstlane((unsigned)(stream_float_off * 4));
+    ws.cslot = 0;
+}
+
+// One 1-KiB piece (i = 0..15) of the next quarter: wave w fetches pieces 4 i + w.  MUBUF form (descriptor +
+// one constant 32-bit VGPR offset + SGPR offset): NO per-piece vector ALU -- any VALU instruction of the
+// wave takes its cycles from the MFMA stream (measured: 16 pieces addressed through 64-bit VGPR pointers
+// cost ~900 cycles per quarter, this form ~0; scripts/micro/mfma_mix.hip).
+__device__ __forceinline__ void ws_fetch_piece(const WStream& ws, int i) {
+    float* dst = ws.ring + (ws.cslot ^ 1) * SLOT_FLOATS + ws.wave * 256 + i * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ws.rs, (DMN_LAS void*)dst, 16, (int)ws.voff, (int)(ws.off + i * 4096), 0, 0);
+}
 __device__ __forceinline__ void ws_fetch(WStream& ws) {
-    const char* g = ws.gsrc + ws.off;
-    float* dst = ws.ring + (ws.cslot ^ 1) * SLOT_FLOATS + ws.wave * 256;
 #pragma unroll
-    for (int i = 0; i < DMA_PER_QUARTER; ++i)     // piece p = 4 i + wave: 1 KiB each
-        __builtin_amdgcn_global_load_lds((DMN_GAS void*)(g + i * 4096), (DMN_LAS void*)(dst + i * 1024), 16, 0, 0);
+    for (int i = 0; i < DMA_PER_QUARTER; ++i) ws_fetch_piece(ws, i);
     ws.off += QUARTER_FLOATS * 4;
 }
 
@@ -219,30 +244,75 @@ __device__ __forceinline__ void ws_begin() {
     asm volatile("" ::: "memory");
 }
 
+// ---- hand-scheduled LDS operand reads --------------------------------------------------------------
+// With one wave per SIMD nothing hides a stall of that wave, and the compiler's own placement of the
+// A-operand reads (right before their s_waitcnt) and of the LDS-DMA burst (16 in 5 MFMA gaps) cost ~10 %
+// of the MFMA rate.  The reads are therefore issued through inline asm (invisible to the compiler's
+// waitcnt insertion), waited for by hand, and every MFMA is pinned in place by a sched_barrier.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(DMN_LAS const void*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16_async(f32x4& v, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) -- the
+// index is a constant expression inside f (literal instruction offsets; no address arithmetic for the
+// compiler to hoist out of the layer loop and spill)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// wait until at most N LDS operations are outstanding, then hand the registers back to the compiler
+template <int N, int NV>
+__device__ __forceinline__ void lds_wait(f32x4 (&v)[NV]) {
+    __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));           // lgkmcnt(N) only (gfx9 encoding)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 // One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
 // operands from the LDS slot (group-local index), B from registers (accumulator layout).
+// Schedule per k-group (4 OB MFMAs, k-major): the OB reads of the NEXT group ride in the first OB MFMA
+// gaps (register double buffer), the 16 DMA pieces of the next quarter are spread over the first half of
+// the quarter, one per gap.
 template <int G0, int NG, int OB, bool ZERO = false, int NB>
 __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
     static_assert(NB * 16 >= (G0 + NG) * 4, "B operand too small");
     static_assert(NG * OB <= 64, "more than one quarter");
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(ws.ring + ws.cslot * SLOT_FLOATS) + lane;
-#pragma unroll
-    for (int gl = 0; gl < NG; ++gl) {
-        f32x4 a[OB];
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) a[ob] = s4[(gl * OB + ob) * 64];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int p = (G0 + gl) * 4 + kk;
-#pragma unroll
-            for (int ob = 0; ob < OB; ++ob) {
-                // ZERO: this quarter starts the GEMM -- C = 0 is an inline constant of the MFMA, no accumulator clear
-                if (ZERO && G0 + gl == 0 && kk == 0) acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], (f32x16)(0.f));
-                else acc[ob] = mfma32(a[ob][kk], B[p >> 4][p & 15], acc[ob]);
-            }
-        }
-        if (gl == 0) ws_fetch(ws);          // next quarter -> the other slot, behind the first group's MFMAs
-    }
+    constexpr int GM = 4 * OB;                       // MFMAs per k-group
+    constexpr int Q = NG * GM;                       // MFMAs in this call
+    constexpr int P = (Q / 2) / DMA_PER_QUARTER > 0 ? (Q / 2) / DMA_PER_QUARTER : 1;   // gaps between DMA pieces
+    static_assert(OB + (DMA_PER_QUARTER - 1) * P < Q, "DMA pieces do not fit");
+    const unsigned s0 = lds_addr(ws.ring + ws.cslot * SLOT_FLOATS) + lane * 16;
+    f32x4 a[2][OB];
+    static_for<OB>([&](auto ic) {
+        constexpr int ob = decltype(ic)::value;
+        lds_read16_async<ob * 1024>(a[0][ob], s0);
+    });
+    static_for<NG>([&](auto gc) {
+        constexpr int gl = decltype(gc)::value;
+        lds_wait<0>(a[gl & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<GM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int kk = i / OB, ob = i % OB, M = gl * GM + i;
+            constexpr int p = (G0 + gl) * 4 + kk;
+            if constexpr (gl + 1 < NG && i < OB)
+                lds_read16_async<((gl + 1) * OB + i) * 1024>(a[(gl + 1) & 1][i], s0);           // group gl + 1, out-block i
+            if constexpr (M >= OB && (M - OB) % P == 0 && (M - OB) / P < DMA_PER_QUARTER) ws_fetch_piece(ws, (M - OB) / P);
+            // ZERO: this quarter starts the GEMM -- C = 0 is an inline constant of the MFMA, no accumulator clear
+            if constexpr (ZERO && G0 + gl == 0 && kk == 0) acc[ob] = mfma32(a[gl & 1][ob][kk], B[p >> 4][p & 15], (f32x16)(0.f));
+            else acc[ob] = mfma32(a[gl & 1][ob][kk], B[p >> 4][p & 15], acc[ob]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    ws.off += QUARTER_FLOATS * 4;
     ws.cslot ^= 1;
 }
 

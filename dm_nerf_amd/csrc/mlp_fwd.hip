@@ -88,8 +88,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         for (int k = 0; k < TAB_FLOATS / 1024; ++k) tabv[k] = src[k * 256];
     }
     WStream ws;
-    ws.gsrc = reinterpret_cast<const char*>(blob) + lane * 16 + wave * 1024;
-    ws.ring = lds; ws.wave = wave; ws.off = (unsigned)(L.stream * 4); ws.cslot = 0;
+    ws_init(ws, blob, L.total, lds, lane, wave, L.stream);
     ws_fetch_first(ws);                                                   // quarter 0: mlps.0
     if constexpr (!EMBEDDED) {                                            // full-range sin/cos under the DMA flight
         encode<POS_L, 2>(pt, pe, half);

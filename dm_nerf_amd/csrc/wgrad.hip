@@ -62,6 +62,7 @@ struct WgArgs {
     float* part;
     const WgJob* jobs;
     int64_t Mp;
+    long long* trace;     // diagnostic: per-workgroup {start, end} of the 100 MHz wall clock, or null
 };
 
 template <int NBA, int NBB>
@@ -96,7 +97,13 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
     // pieces i < NBA come from the A tile, the rest from the B tile; inside a tile piece e*4 floats
     const int prow = tid >> 3, pcol = (tid & 7) * 4;
     f32x4 stage[NL];
+#ifndef WG_EXP
+#define WG_EXP 0
+#endif
     auto load_chunk = [&](int c) {
+#if WG_EXP == 1
+        c &= 1;
+#endif
         const float* ta = A + (int64_t)(jb.chunk0 + c) * strideA + tid * 4;
         const float* tb = B + (int64_t)(jb.chunk0 + c) * strideB + tid * 4;
 #pragma unroll
@@ -125,7 +132,9 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
     for (int c = 0; c < jb.nchunk; ++c) {
         const float* cur = lds + (c & 1) * BUF;
         const bool more = c + 1 < jb.nchunk;
+#if WG_EXP != 4
         if (more) load_chunk(c + 1);                    // global loads in flight under the MFMAs below
+#endif
         // lane (i = li, kh = half) reads row (blk*32 + i), columns 4t + 2kh, +1 :
         //   MFMA u uses sample 4t + u from lanes 0-31 (k = 0) and sample 4t + 2 + u from lanes 32-63 (k = 1)
         const float* arow[SP::SAn];
@@ -134,28 +143,38 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
         for (int k = 0; k < SP::SAn; ++k) arow[k] = cur + (SP::sa(w, k) * 32 + li) * LDS_STRIDE + 2 * half;
 #pragma unroll
         for (int k = 0; k < SP::SBn; ++k) brow[k] = cur + ((NBA + SP::sb(w, k)) * 32 + li) * LDS_STRIDE + 2 * half;
+        // operands of step t + 1 are read from LDS before the MFMAs of step t issue (register double buffer):
+        // with one wave per SIMD nothing else hides the ds_read latency
+        float2 av[2][SP::SAn], bv[2][SP::SBn];
+        auto read_ops = [&](int t) {
+#pragma unroll
+            for (int k = 0; k < SP::SAn; ++k) av[t & 1][k] = *reinterpret_cast<const float2*>(arow[k] + 4 * t);
+#pragma unroll
+            for (int k = 0; k < SP::SBn; ++k) bv[t & 1][k] = *reinterpret_cast<const float2*>(brow[k] + 4 * t);
+        };
+        read_ops(0);
 #pragma unroll
         for (int t = 0; t < KT / 4; ++t) {
+            if (t + 1 < KT / 4) read_ops(t + 1);
             // half-way through the chunk the next tile (in flight since the top of the loop) is written to
             // the other ring slot, so the ds_writes issue in the shadow of the remaining MFMAs
+#if WG_EXP != 2 && WG_EXP != 4
             if (t == KT / 8 && more) write_chunk(lds + ((c + 1) & 1) * BUF);
-            float2 av[SP::SAn], bv[SP::SBn];
-#pragma unroll
-            for (int k = 0; k < SP::SAn; ++k) av[k] = *reinterpret_cast<const float2*>(arow[k] + 4 * t);
-#pragma unroll
-            for (int k = 0; k < SP::SBn; ++k) bv[k] = *reinterpret_cast<const float2*>(brow[k] + 4 * t);
+#endif
 #pragma unroll
             for (int ia = 0; ia < SP::SAn; ++ia) {
                 if (NBA * 32 > 0 && SP::sa(w, ia) >= NBA) continue;        // wave has fewer blocks than SAn (wave-uniform)
 #pragma unroll
                 for (int ib = 0; ib < SP::SBn; ++ib) {
-                    acc[ia * SP::SBn + ib] = mfma32(av[ia].x, bv[ib].x, acc[ia * SP::SBn + ib]);
-                    acc[ia * SP::SBn + ib] = mfma32(av[ia].y, bv[ib].y, acc[ia * SP::SBn + ib]);
+                    acc[ia * SP::SBn + ib] = mfma32(av[t & 1][ia].x, bv[t & 1][ib].x, acc[ia * SP::SBn + ib]);
+                    acc[ia * SP::SBn + ib] = mfma32(av[t & 1][ia].y, bv[t & 1][ib].y, acc[ia * SP::SBn + ib]);
                 }
-                if (do_bias) bsum[ia] += av[ia].x + av[ia].y;
+                if (do_bias) bsum[ia] += av[t & 1][ia].x + av[t & 1][ia].y;
             }
         }
+#if WG_EXP != 3
         __syncthreads();
+#endif
     }
 
     // epilogue: partial tile [NBA*32][NBB*32], C layout: lane holds column j = li, rows crow(r, half)
@@ -189,6 +208,7 @@ constexpr int CLS_NBB[N_CLASSES] = {8, 8, 2, 1, 8, 4, 4, 4, 4};
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WgJob jb = a.jobs[blockIdx.x];
+    if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = (long long)wall_clock64();
     switch (jb.cls) {                                  // workgroup-uniform
         case C_8_8: run_job<8, 8>(a, jb, lds); break;
         case C_4_8: run_job<4, 8>(a, jb, lds); break;
@@ -201,6 +221,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
         case C_4_4: run_job<4, 4>(a, jb, lds); break;
         default: break;
     }
+    if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = (long long)wall_clock64();
 }
 
 // Adds the per-slice partials in slice order into the flat gradient vector.
@@ -343,6 +364,12 @@ extern "C" int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jo
     return DMNERF_OK;
 }
 
+static long long* g_wgrad_trace = nullptr;
+extern "C" int dmnerf_wgrad_set_trace(int64_t* d_ticks) {
+    g_wgrad_trace = (long long*)d_ticks;
+    return DMNERF_OK;
+}
+
 extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                                       const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                                       float* d_part, float* d_grad_flat, void* stream) {
@@ -350,7 +377,7 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
         return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights: bad argument");
     WgArgs a{};
     a.src[0] = d_save; a.src[1] = d_dsave; a.src[2] = d_graw_t;
-    a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M);
+    a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_wgrad_trace;
     const size_t lds_bytes = 2 * (size_t)MAX_ROWS * LDS_STRIDE * sizeof(float);      // 139 264 B
     static bool attr_set = false;
     if (!attr_set) {

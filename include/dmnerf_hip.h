@@ -164,6 +164,10 @@ int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t
 int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                            float* d_part, float* d_grad_flat, void* stream);
+/* Diagnostic: when d_ticks != NULL every workgroup of the following dmnerf_mlp_bwd_weights launches writes its
+ * {start, end} 100 MHz wall-clock ticks to d_ticks[2*wg], d_ticks[2*wg+1] (n_jobs pairs); NULL turns it off.
+ * Used by scripts/diag_wgrad.py to fit the split-K cost model. */
+int dmnerf_wgrad_set_trace(int64_t* d_ticks);
 
 /* ---- manipulator.py (scene editing at render time) -----------------------------------
  * manipulator_render (networks/manipulator.py:86-105): render_train whose object map keeps all C channels
