@@ -120,14 +120,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     {
         // ---- ins branch: dg2 = relu'(g2) . (W_io^T g_ins);  dq = W_ih^T dg2 ----------------------
         f32x16 t4[4], d4[4];
-        ws_begin();
-        gemm_quarter<0, 4 * OBI, 4, true>(ws, gi, t4, lane);
+        ws_prime<4>(ws, lane);
+        gemm_quarter<0, 4 * OBI, 4, 8, true>(ws, gi, t4, lane);
         apply_mask<4>(d4, g2bits, t4);
         store_rows<4>(make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane), d4);     // burst (once per block)
-        ws_begin();
-        gemm_quarter<0, 8, 8, true>(ws, d4, acc, lane);
-        ws_begin();
-        gemm_quarter<8, 8, 8>(ws, d4, acc, lane);
+        gemm_quarter<0, 8, 8, 8, true>(ws, d4, acc, lane);
+        gemm_quarter<8, 8, 8, 8>(ws, d4, acc, lane);
         store_rows<8>(make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane), acc);      // dq (ins_feature has no activation)
 
         // ---- rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU;  df = (W_rh^T dg1)[:256] ----
@@ -147,10 +145,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         }
         apply_mask<4>(d4, g1bits, t4);
         store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);
-        ws_begin();
-        gemm_quarter<0, 8, 8, true>(ws, d4, acc, lane);
-        ws_begin();
-        gemm_quarter<8, 8, 8>(ws, d4, acc, lane);
+        gemm_quarter<0, 8, 8, 8, true>(ws, d4, acc, lane);
+        gemm_quarter<8, 8, 8, 8>(ws, d4, acc, lane);
 #pragma unroll
         for (int b = 0; b < 8; ++b) d[b] = acc[b];                        // df (rgb_feature has no activation)
     }
@@ -160,17 +156,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
 #pragma nounroll
     for (int st = 0; st < NSTAGE_T; ++st) {
         const RowIO dio = make_rowio(st == 0 ? a.dsave + SL.f : a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
-        ws_begin();
-        gemm_quarter<0, 8, 8, true>(ws, d, acc, lane);
-        ws_begin();
+        gemm_quarter<0, 8, 8, 8, true>(ws, d, acc, lane);
         store_rows_part<0, 43>(dio, d);
-        gemm_quarter<8, 8, 8>(ws, d, acc, lane);
-        ws_begin();
+        gemm_quarter<8, 8, 8, 8>(ws, d, acc, lane);
         store_rows_part<43, 43>(dio, d);
-        gemm_quarter<16, 8, 8>(ws, d, acc, lane);
-        ws_begin();
+        gemm_quarter<16, 8, 8, 8>(ws, d, acc, lane);
         store_rows_part<86, 42>(dio, d);
-        gemm_quarter<24, 8, 8>(ws, d, acc, lane);
+        gemm_quarter<24, 8, 8, 8>(ws, d, acc, lane);                     // (the last stage prefetches from the landing zone)
         if (st == 0) {
             // density_linear (dm_nerf.py:101): dh_7 += w_d * g_sigma
             const f32x4* wd = reinterpret_cast<const f32x4*>(tab + LT.w_den + half * 128);

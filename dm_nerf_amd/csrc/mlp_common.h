@@ -205,6 +205,7 @@ struct WStream {
     int wave;             // wave id in the workgroup (uniform)
     unsigned off;         // byte offset from the blob start of the next quarter to fetch (uniform)
     int cslot;            // ring slot of the next quarter to consume
+    f32x4 pre[8];         // A operands of the next quarter's first k-group (read during this quarter's last group)
 };
 
 __device__ __forceinline__ void ws_init(WStream& ws, const float* blob, int64_t blob_floats, float* ring, int lane, int wave,
@@ -236,12 +237,6 @@ __device__ __forceinline__ void ws_fetch_first(WStream& ws) {
     ws.cslot = 1;
     ws_fetch(ws);
     ws.cslot = 0;
-}
-
-__device__ __forceinline__ void ws_begin() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 }
 
 // ---- hand-scheduled LDS operand reads --------------------------------------------------------------
@@ -276,28 +271,55 @@ __device__ __forceinline__ void lds_wait(f32x4 (&v)[NV]) {
     for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
 }
 
+// Quarter hand-over.  Quarter q + 1 is complete in the other ring slot once every wave has seen its own
+// DMA pieces land (vmcnt(0)) and passed the barrier; the barrier also releases quarter q's slot for the DMA
+// of q + 2, because a wave only arrives after its last LDS read of q has returned.  It sits at the START of
+// quarter q's last k-group (whose operands are already in registers), so the first operands of q + 1 are
+// read under that group's MFMAs and no LDS latency is exposed at the quarter boundary.
+__device__ __forceinline__ void ws_handover() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Very first quarter of the kernel: wait for it (and for the LDS table), then read its first operands.
+template <int OB>
+__device__ __forceinline__ void ws_prime(WStream& ws, int lane) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned s0 = lds_addr(ws.ring + ws.cslot * SLOT_FLOATS) + lane * 16;
+    static_for<OB>([&](auto ic) {
+        constexpr int ob = decltype(ic)::value;
+        lds_read16_async<ob * 1024>(ws.pre[ob], s0);
+    });
+}
+
 // One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
-// operands from the LDS slot (group-local index), B from registers (accumulator layout).
+// operands from the LDS slot (group-local index), B from registers (accumulator layout).  NEXT_OB = out-
+// blocks of the quarter that follows in the stream (0: this is the kernel's last quarter).
 // Schedule per k-group (4 OB MFMAs, k-major): the OB reads of the NEXT group ride in the first OB MFMA
-// gaps (register double buffer), the 16 DMA pieces of the next quarter are spread over the first half of
-// the quarter, one per gap.
-template <int G0, int NG, int OB, bool ZERO = false, int NB>
+// gaps (register double buffer), the 16 DMA pieces of the next quarter are spread over the first fourth of
+// the quarter, one per gap; the last group starts with the hand-over and reads the next quarter's first
+// operands into ws.pre.
+template <int G0, int NG, int OB, int NEXT_OB, bool ZERO = false, int NB>
 __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
     static_assert(NB * 16 >= (G0 + NG) * 4, "B operand too small");
     static_assert(NG * OB <= 64, "more than one quarter");
     constexpr int GM = 4 * OB;                       // MFMAs per k-group
     constexpr int Q = NG * GM;                       // MFMAs in this call
-    constexpr int P = (Q / 2) / DMA_PER_QUARTER > 0 ? (Q / 2) / DMA_PER_QUARTER : 1;   // gaps between DMA pieces
-    static_assert(OB + (DMA_PER_QUARTER - 1) * P < Q, "DMA pieces do not fit");
+    constexpr int P = (Q / 4) / DMA_PER_QUARTER > 0 ? (Q / 4) / DMA_PER_QUARTER : 1;   // gaps between DMA pieces (first quarter of the call)
+    static_assert(OB + (DMA_PER_QUARTER - 1) * P < Q - GM, "DMA pieces must be issued before the last group");
+    static_assert(NG >= 2 && NEXT_OB <= GM && NEXT_OB <= 8, "hand-over does not fit the last group");
     const unsigned s0 = lds_addr(ws.ring + ws.cslot * SLOT_FLOATS) + lane * 16;
+    const unsigned s1 = lds_addr(ws.ring + (ws.cslot ^ 1) * SLOT_FLOATS) + lane * 16;
     f32x4 a[2][OB];
-    static_for<OB>([&](auto ic) {
-        constexpr int ob = decltype(ic)::value;
-        lds_read16_async<ob * 1024>(a[0][ob], s0);
-    });
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) a[0][ob] = ws.pre[ob];
     static_for<NG>([&](auto gc) {
         constexpr int gl = decltype(gc)::value;
         lds_wait<0>(a[gl & 1]);
+        if constexpr (gl == NG - 1 && NEXT_OB > 0) ws_handover();
         __builtin_amdgcn_sched_barrier(0);
         static_for<GM>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -305,6 +327,7 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
             constexpr int p = (G0 + gl) * 4 + kk;
             if constexpr (gl + 1 < NG && i < OB)
                 lds_read16_async<((gl + 1) * OB + i) * 1024>(a[(gl + 1) & 1][i], s0);           // group gl + 1, out-block i
+            if constexpr (gl == NG - 1 && i < NEXT_OB) lds_read16_async<i * 1024>(ws.pre[i], s1);  // next quarter, group 0
             if constexpr (M >= OB && (M - OB) % P == 0 && (M - OB) / P < DMA_PER_QUARTER) ws_fetch_piece(ws, (M - OB) / P);
             // ZERO: this quarter starts the GEMM -- C = 0 is an inline constant of the MFMA, no accumulator clear
             if constexpr (ZERO && G0 + gl == 0 && kk == 0) acc[ob] = mfma32(a[gl & 1][ob][kk], B[p >> 4][p & 15], (f32x16)(0.f));

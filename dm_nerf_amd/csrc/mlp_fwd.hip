@@ -35,12 +35,23 @@ struct MlpArgs {
     float* save;           // training: activation workspace, SAVE_ROWS x M floats (layout.h::SaveLayout)
     int64_t M;             // total samples
     int S;                 // samples per ray (rays variant)
+#ifdef DMN_FWD_TRACE
+    long long* trace;      // diagnostic builds only (make diag): per-workgroup cycle stamps, see scripts/diag_fwd.py
+#endif
 };
+#ifdef DMN_FWD_TRACE
+static long long* g_fwd_trace = nullptr;
+extern "C" int dmnerf_debug_fwd_trace(long long* p) { g_fwd_trace = p; return 0; }
+#define DMN_STAMP(k) do { if (a.trace && threadIdx.x == 0) { a.trace[8 * blockIdx.x + (k)] = (long long)clock64(); if ((k) == 0) a.trace[8 * blockIdx.x + 7] = (long long)wall_clock64(); } } while (0)
+#else
+#define DMN_STAMP(k) do {} while (0)
+#endif
 
 template <int OBI, bool EMBEDDED, bool SAVE>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 16 KiB]
     float* const tab = lds + RING_FLOATS;
+    DMN_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,6 +122,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         bits_voff = (int)((blk * BITS_WORDS_PER_BLOCK + lane * 4) * 4);
     }
 
+    DMN_STAMP(1);
     f32x16 h[8], acc[8];
     auto save_mask8 = [&](int layer) {
         unsigned m[4];
@@ -119,17 +131,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(v, bits_rs, bits_voff + layer * 1024, 0, 0);
     };
     // ---- mlps.0 : 63 -> 256 (quarter 0)
-    ws_begin();
+    ws_prime<8>(ws, lane);
     if constexpr (SAVE) {                          // 90 stores with a whole quarter to retire
         store_encoded_rows<POS_L, 2>(a.save + SL.pe, srows * MP, blk, lane, pe);
         store_encoded_rows<DIR_L, 1>(a.save + SL.de, srows * MP, blk, lane, de);
     }
     init_bias_lds<8>(tab + L.b0, acc, half);
-    gemm_quarter<0, 8, 8>(ws, pe, acc, lane);
+    gemm_quarter<0, 8, 8, 8>(ws, pe, acc, lane);
 #pragma unroll
     for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
     if constexpr (SAVE) save_mask8(0);
 
+    DMN_STAMP(2);
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
 
@@ -137,30 +150,28 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     // saves it in three batches at the quarter boundaries, BEFORE the next DMA is issued, so that DMA
     // stays older than them (see mlp_common.h).  The body is instantiated three times (trunk loop,
     // rgb_feature, ins_feature) to keep the register live ranges of the two heads out of the loop.
-    auto stage = [&](int st) {
+    auto stage = [&](int st, auto next_ob) {           // next_ob: out-blocks of the quarter after the stage
+        constexpr int NEXT = decltype(next_ob)::value;
         RowIO hio;
         if constexpr (SAVE) hio = make_rowio(a.save + SL.h + (int64_t)(st < 8 ? st : 7) * 256 * MP, 256, (st < 8 ? srows : 0) * MP, blk, lane);
-        ws_begin();
         init_bias_lds<8>(tab + L.b_stage + st * (int)bias_floats(8), acc, half);
-        gemm_quarter<0, 8, 8>(ws, h, acc, lane);
-        ws_begin();
+        gemm_quarter<0, 8, 8, 8>(ws, h, acc, lane);
         if constexpr (SAVE) store_rows_part<0, 43>(hio, h);
-        gemm_quarter<8, 8, 8>(ws, h, acc, lane);
-        ws_begin();
+        gemm_quarter<8, 8, 8, 8>(ws, h, acc, lane);
         if constexpr (SAVE) store_rows_part<43, 43>(hio, h);
-        gemm_quarter<16, 8, 8>(ws, h, acc, lane);
-        ws_begin();
+        gemm_quarter<16, 8, 8, 8>(ws, h, acc, lane);
         if constexpr (SAVE) store_rows_part<86, 42>(hio, h);
-        gemm_quarter<24, 8, 8>(ws, h, acc, lane);
+        gemm_quarter<24, 8, 8, NEXT>(ws, h, acc, lane);
     };
+    typedef std::integral_constant<int, 8> Next8;
+    typedef std::integral_constant<int, 4> Next4;
 
     // ---- trunk: mlps.1 .. mlps.7
 #pragma nounroll
     for (int st = 0; st < 7; ++st) {
-        stage(st);
+        stage(st, Next8{});
         if (st == 4) {                                                    // skip: cat[h, pts] (dm_nerf.py:87)
-            ws_begin();
-            gemm_quarter<0, 8, 8>(ws, pe, acc, lane);
+            gemm_quarter<0, 8, 8, 8>(ws, pe, acc, lane);
         }
 #pragma unroll
         for (int b = 0; b < 8; ++b) h[b] = relu16(acc[b]);
@@ -182,21 +193,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         sigma = part + __shfl_xor(part, 32) + tab[L.b_den];
     }
 
+    DMN_STAMP(3);
     // ---- rgb branch: acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
-    stage(7);
+    stage(7, Next4{});
     {
         RowIO fio;
         if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
         f32x16 hid[4];
-        ws_begin();
         init_bias_lds<4>(tab + L.b_rgbh, hid, half);
-        gemm_quarter<0, 16, 4>(ws, acc, hid, lane);
-        ws_begin();
+        gemm_quarter<0, 16, 4, 4>(ws, acc, hid, lane);
         if constexpr (SAVE) store_rows_part<0, 43>(fio, acc);
-        gemm_quarter<16, 16, 4>(ws, acc, hid, lane);
-        ws_begin();
+        gemm_quarter<16, 16, 4, 4>(ws, acc, hid, lane);
         if constexpr (SAVE) store_rows_part<43, 43>(fio, acc);
-        gemm_quarter<0, 4, 4>(ws, de, hid, lane);
+        gemm_quarter<0, 4, 4, 8>(ws, de, hid, lane);
         if constexpr (SAVE) store_rows_part<86, 42>(fio, acc);      // (with the g1 burst below: younger than the DMA in flight)
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
@@ -226,20 +235,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
 
     // ---- ins branch: acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
-    stage(8);
+    stage(8, Next4{});
     {
         RowIO qio;
         if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);
         f32x16 hid[4];
-        ws_begin();
         init_bias_lds<4>(tab + L.b_insh, hid, half);
-        gemm_quarter<0, 16, 4>(ws, acc, hid, lane);
-        ws_begin();
+        gemm_quarter<0, 16, 4, 4>(ws, acc, hid, lane);
         if constexpr (SAVE) store_rows_part<0, 43>(qio, acc);
-        gemm_quarter<16, 16, 4>(ws, acc, hid, lane);                  // (its fetch runs into the zero-filled landing zone)
+        gemm_quarter<16, 16, 4, OBI>(ws, acc, hid, lane);
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
-        ws_begin();
         if constexpr (SAVE) {
             store_rows_part<43, 85>(qio, acc);
             store_rows<4>(make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane), hid);
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         }
         f32x16 io[OBI];
         init_bias_lds<OBI>(tab + L.b_inso, io, half);
-        gemm_quarter<0, 16, OBI>(ws, hid, io, lane);                  // ins_linear (:103)
+        gemm_quarter<0, 16, OBI, 0>(ws, hid, io, lane);               // ins_linear (:103); its fetch runs into the zero-filled landing zone
         if (valid) {
 #pragma unroll
             for (int b = 0; b < OBI; ++b) {
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         }
     }
+    DMN_STAMP(4);
     // cat[rgb, density, ins]  (dm_nerf.py:105)
     if (valid && half == 0) {
         out_row[0] = rgb_out[0];
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         out_row[2] = rgb_out[2];
         out_row[3] = sigma;
     }
+    DMN_STAMP(5);
 }
 
 template <bool EMBEDDED, bool SAVE>
@@ -326,6 +334,9 @@ extern "C" int dmnerf_mlp_fwd_rays(const float* d_blob, int ins_num, const float
     MlpArgs a{};
     a.blob = d_blob; a.L = make_layout(ins_num); a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z;
     a.raw = d_raw; a.M = N * S; a.S = S;
+#ifdef DMN_FWD_TRACE
+    a.trace = g_fwd_trace;
+#endif
     return launch<false, false>(a, (hipStream_t)stream);
 }
 
