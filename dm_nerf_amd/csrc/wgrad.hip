@@ -5,14 +5,20 @@
 // GEMM over K = samples (up to ~10^6) whose output is at most 256 x 256, and the operands of one
 // 32-sample chunk are two CONTIGUOUS tiles of rows*128 bytes:
 //   * split-K: the samples are cut into slices, one workgroup per (job, slice); slice counts are
-//     proportional to the job's FLOPs so that ~one wave of workgroups (<= 256 CUs, one per CU) is
-//     balanced; per-slice partials go to a workspace and a second kernel adds them in fixed order
+//     proportional to the job's measured chunk time so that one wave of workgroups (<= 256 CUs, one per
+//     CU) is balanced; per-slice partials go to a workspace and a second kernel adds them in fixed order
 //     (deterministic, no float atomics);
-//   * per 32-sample chunk a workgroup stages dy[<=256][32] and x[<=256][32] in LDS through
-//     registers (coalesced 128-byte row segments; row stride 34 floats => conflict-free
-//     ds_read_b64) with a 2-deep ring, and its 4 waves run v_mfma_f32_32x32x2_f32 with
-//     A[i][k] = dy[row i][sample k], B[k][j] = x[row j][sample k];
-//   * bias gradients (row sums of dy) ride along in the VALU shadow of wave 0.
+//   * a chunk's two tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction)
+//     into a D-deep ring (D = 2 for the 256 x 256 jobs, up to 6 for the skinny ones, whose chunks are
+//     shorter than the HBM latency), rows of 128 bytes with their 16-byte units XOR-swizzled by
+//     (row >> 1) & 7 so that the ds_read_b128 of 32 different rows is bank-conflict free;
+//   * the 4 waves run v_mfma_f32_32x32x2_f32 with A[i][k] = dy[row i][sample k], B[k][j] = x[row j][sample k];
+//     a lane reads 4 consecutive samples of its row per ds_read_b128 (k = 0 / 1 <-> lane halves);
+//   * the inner loop is hand-scheduled like the MLP kernels (mlp_common.h): operand reads one round
+//     ahead through inline asm, one per MFMA gap; the ring hand-over (vmcnt + barrier) at the start of a
+//     chunk's last round; no vector-ALU work besides the bias sums (every VALU instruction of a
+//     one-wave-per-SIMD kernel is paid for in MFMA time): row sums of dy as 2 v_pk_add_f32 per A block
+//     and round, the rounds dealt out over the waves that hold the same A blocks.
 // Exact f32 (fmaf-chain MFMA), no vendor BLAS.  Roofline: ~equal parts MFMA (2 x MAC x M FLOP) and
 // HBM (each dy / x row is read once per job: ~23 KB per sample and model).
 #include <hip/hip_runtime.h>
@@ -29,9 +35,9 @@ using namespace dmn;
 
 namespace {
 
-constexpr int KT = 32;            // samples per chunk
-constexpr int LDS_STRIDE = 34;    // floats per staged row (32 + 2): banks 34*i mod 64 distinct for i < 32
-constexpr int MAX_ROWS = 512;     // A rows + B rows staged per chunk
+constexpr int KT = 32;                      // samples per chunk
+constexpr int WG_LDS_BYTES = 147456;        // ring budget (of the CU's 160 KiB)
+constexpr int MAX_DEPTH = 6;                // ring slots (the chunk loop is unrolled by the depth)
 
 // One workgroup's work (device table, offsets only => reusable across steps).
 struct WgJob {
@@ -51,10 +57,10 @@ static_assert(sizeof(WgJob) % 8 == 0, "WgJob layout");
 // One output tensor slice (weight columns [col_off, col_off + rowsB) of a parameter, plus its bias).
 struct WgOut {
     int64_t part_off, slice_stride;   // first partial, distance between slices
-    int64_t bias_part_off, bias_slice_stride;
+    int64_t bias_part_off, bias_slice_stride;   // per slice: bias_sub partial vectors of NBA*32 floats each
     int64_t out_off, bias_out_off;    // float offsets into the flat gradient vector (reference order); bias -1 = none
     int n_slices, rowsA, rowsB, ldp;  // ldp = NBB*32
-    int ld_out, col_off, pad0, pad1;
+    int ld_out, col_off, bias_sub, ldb;        // bias_sub shares per slice, ldb = NBA*32 apart
 };
 
 struct WgArgs {
@@ -66,136 +72,162 @@ struct WgArgs {
 };
 
 template <int NBA, int NBB>
-struct Split {   // which (A block, B block) pairs a wave owns: a rectangle SA x SB
+struct Split {   // which (A block, B block) pairs a wave owns: a rectangle SAn x SBn; block = literal + wave part
     static constexpr int SBn = NBB >= 4 ? NBB / 4 : 1;
-    static constexpr int SAn = NBB >= 4 ? NBA : (NBB == 2 ? (NBA + 1) / 2 : (NBA + 3) / 4);
-    __device__ static int sa(int w, int k) { return NBB >= 4 ? k : (NBB == 2 ? (w >> 1) + 2 * k : w + 4 * k); }
-    __device__ static int sb(int w, int k) { return NBB >= 4 ? w + 4 * k : (NBB == 2 ? (w & 1) : 0); }
+    static constexpr int SAn = NBB >= 4 ? NBA : (NBB == 2 ? NBA / 2 : NBA / 4);
+    static constexpr int NSHARE = NBB >= 4 ? 4 : (NBB == 2 ? 2 : 1);        // waves that hold the same A blocks
+    static_assert(NBB >= 4 || (NBB == 2 && NBA % 2 == 0) || (NBB == 1 && NBA % 4 == 0), "unsupported shape class");
+    // A block of (wave w, k) = a_lit(k) + a_wave(w); B block = b_lit(k) + b_wave(w)
+    __device__ static constexpr int a_lit(int k) { return NBB >= 4 ? k : (NBB == 2 ? 2 * k : 4 * k); }
+    __device__ static int a_wave(int w) { return NBB >= 4 ? 0 : (NBB == 2 ? (w >> 1) : w); }
+    __device__ static constexpr int b_lit(int k) { return NBB >= 4 ? 4 * k : 0; }
+    __device__ static int b_wave(int w) { return NBB >= 4 ? w : (NBB == 2 ? (w & 1) : 0); }
+    __device__ static int share_rank(int w) { return NBB >= 4 ? w : (NBB == 2 ? (w & 1) : 0); }
+};
+
+template <int NBA, int NBB>
+struct Ring {
+    static constexpr int BUF = (NBA + NBB) * 4096;                                    // bytes per chunk: rows * 128
+    static constexpr int D = WG_LDS_BYTES / BUF < MAX_DEPTH ? WG_LDS_BYTES / BUF : MAX_DEPTH;
+    static_assert(D >= 2, "ring needs two slots");
 };
 
 template <int NBA, int NBB>
 __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float* lds) {
     typedef Split<NBA, NBB> SP;
-    constexpr int ROWS = (NBA + NBB) * 32;
-    constexpr int NL = NBA + NBB;                  // 16-byte pieces per thread per chunk (ROWS*8/256)
-    constexpr int BUF = ROWS * LDS_STRIDE;         // floats per ring slot
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, li = lane & 31;
-    // tile of chunk c: rows [row0, row0 + rows) of block (chunk0 + c): contiguous rows*32 floats
+    typedef Ring<NBA, NBB> RG;
+    constexpr int SAn = SP::SAn, SBn = SP::SBn, NPAIR = SAn * SBn;
+    constexpr int NL = NBA + NBB;                  // DMA pieces per wave per chunk (1 KiB each)
+    constexpr int NR = SAn + SBn;                  // operand reads per round
+    constexpr int NGAP = 4 * NPAIR;                // MFMAs per round
+    constexpr int D = RG::D, BUF = RG::BUF;
+    static_assert((D - 1) * NL <= 63, "vmcnt range");
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = lds_addr(lds);
+
+    // ---- DMA geometry: wave w owns the 1-KiB pieces q = w + 4 j of a tile (rows 8 q .. 8 q + 7); lane l lands
+    // at LDS row 8 q + (l >> 3), unit l & 7, so it must FETCH unit (l & 7) ^ ((row >> 1) & 7) of that row
+    const int drow = 8 * w + (lane >> 3);
+    const int dvoff = drow * 128 + (((lane & 7) ^ ((drow >> 1) & 7)) << 4);            // + 4096 j (soffset)
     const float* __restrict__ A = a.src[jb.a_src] + jb.a_off + (int64_t)jb.a_row0 * 32;
     const float* __restrict__ B = a.src[jb.b_src] + jb.b_off + (int64_t)jb.b_row0 * 32;
-    const int64_t strideA = (int64_t)jb.a_R * 32, strideB = (int64_t)jb.b_R * 32;       // floats per block
-
-    f32x16 acc[SP::SAn * SP::SBn];
-#pragma unroll
-    for (int i = 0; i < SP::SAn * SP::SBn; ++i) acc[i] = (f32x16)(0.f);
-    float bsum[SP::SAn];
-#pragma unroll
-    for (int i = 0; i < SP::SAn; ++i) bsum[i] = 0.f;
-    const bool do_bias = jb.bias_off >= 0 && (NBB >= 4 ? w == 0 : (NBB == 2 ? (w & 1) == 0 : true));
-
-    // per-thread staging geometry: piece e = tid + 256 i -> (row = e >> 3, 16-byte piece = e & 7)
-    // pieces i < NBA come from the A tile, the rest from the B tile; inside a tile piece e*4 floats
-    const int prow = tid >> 3, pcol = (tid & 7) * 4;
-    f32x4 stage[NL];
-#ifndef WG_EXP
-#define WG_EXP 0
-#endif
-    auto load_chunk = [&](int c) {
-#if WG_EXP == 1
-        c &= 1;
-#endif
-        const float* ta = A + (int64_t)(jb.chunk0 + c) * strideA + tid * 4;
-        const float* tb = B + (int64_t)(jb.chunk0 + c) * strideB + tid * 4;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const bool isA = i < NBA;
-            const int r = prow + 32 * (isA ? i : i - NBA);
-            const bool ok = r < (isA ? jb.rowsA : jb.rowsB);
-            const float* p = (isA ? ta : tb) + 1024 * (isA ? i : i - NBA);
-            stage[i] = ok ? *reinterpret_cast<const f32x4*>(p) : (f32x4)(0.f);
-        }
-    };
-    auto write_chunk = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            float2* d = reinterpret_cast<float2*>(buf + (prow + 32 * i) * LDS_STRIDE + pcol);   // 8-byte aligned (stride 34, piece*4)
-            d[0] = make_float2(stage[i][0], stage[i][1]);
-            d[1] = make_float2(stage[i][2], stage[i][3]);
-        }
+    const int64_t strideA = (int64_t)jb.a_R * 32, strideB = (int64_t)jb.b_R * 32;     // floats per 32-sample block
+    const int nchunk = jb.nchunk;
+    // rows beyond rowsA / rowsB are out of range of the tile descriptor: never fetched (what the LDS holds there
+    // only reaches outputs the reduction ignores)
+    auto dma_chunk_piece = [&](int c, unsigned slot_byte, int i) {      // piece i of NL for chunk c (clamped) into a ring slot
+        const int cc = c < nchunk ? c : nchunk - 1;
+        const bool isA = i < NBA;
+        const int j = isA ? i : i - NBA;
+        const float* base = isA ? A + (int64_t)(jb.chunk0 + cc) * strideA : B + (int64_t)(jb.chunk0 + cc) * strideB;
+        const rsrc_t rs = uniform_rsrc(base, (int64_t)(isA ? jb.rowsA : jb.rowsB) * 32);
+        float* dst = lds + (slot_byte + i * 4096 + w * 1024) / 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (DMN_LAS void*)dst, 16, dvoff, j * 4096, 0, 0);
     };
 
-    if (jb.nchunk > 0) {
-        load_chunk(0);
-        write_chunk(lds);
+    // ---- read geometry: lane (li, half) reads row 32 blk + li, unit (2 t + half) ^ ((li >> 1) & 7) in round t
+    // (slot 0 addresses; the chunk loop adds the ring slot's byte offset: 10 VALU adds per 256+ MFMAs)
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned o = lds0 + li * 128 + ((((2 * t + half) ^ ((li >> 1) & 7))) << 4);
+        offA[t] = o + SP::a_wave(w) * 4096;
+        offB[t] = o + (NBA + SP::b_wave(w)) * 4096;
     }
-    __syncthreads();
-    for (int c = 0; c < jb.nchunk; ++c) {
-        const float* cur = lds + (c & 1) * BUF;
-        const bool more = c + 1 < jb.nchunk;
-#if WG_EXP != 4
-        if (more) load_chunk(c + 1);                    // global loads in flight under the MFMAs below
-#endif
-        // lane (i = li, kh = half) reads row (blk*32 + i), columns 4t + 2kh, +1 :
-        //   MFMA u uses sample 4t + u from lanes 0-31 (k = 0) and sample 4t + 2 + u from lanes 32-63 (k = 1)
-        const float* arow[SP::SAn];
-        const float* brow[SP::SBn];
+
+    f32x16 acc[NPAIR];
 #pragma unroll
-        for (int k = 0; k < SP::SAn; ++k) arow[k] = cur + (SP::sa(w, k) * 32 + li) * LDS_STRIDE + 2 * half;
+    for (int i = 0; i < NPAIR; ++i) acc[i] = (f32x16)(0.f);
+    f32x4 bs[SAn];
 #pragma unroll
-        for (int k = 0; k < SP::SBn; ++k) brow[k] = cur + ((NBA + SP::sb(w, k)) * 32 + li) * LDS_STRIDE + 2 * half;
-        // operands of step t + 1 are read from LDS before the MFMAs of step t issue (register double buffer):
-        // with one wave per SIMD nothing else hides the ds_read latency
-        float2 av[2][SP::SAn], bv[2][SP::SBn];
-        auto read_ops = [&](int t) {
+    for (int i = 0; i < SAn; ++i) bs[i] = (f32x4)(0.f);
+    const bool want_bias = jb.bias_off >= 0;
+    const int my_rank = SP::share_rank(w);
+
+    f32x4 av[2][SAn], bv[2][SBn];
+    auto read_ops_one = [&](auto gc, int buf, unsigned addrA, unsigned addrB) {     // operand g of a round
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < SAn) lds_read16_async<SP::a_lit(g) * 4096>(av[buf][g], addrA);
+        else lds_read16_async<SP::b_lit(g - SAn) * 4096>(bv[buf][g - SAn], addrB);
+    };
+
+    // ---- prologue: D chunks in flight, chunk 0 landed, its round-0 operands on their way
 #pragma unroll
-            for (int k = 0; k < SP::SAn; ++k) av[t & 1][k] = *reinterpret_cast<const float2*>(arow[k] + 4 * t);
+    for (int sl = 0; sl < D; ++sl)
 #pragma unroll
-            for (int k = 0; k < SP::SBn; ++k) bv[t & 1][k] = *reinterpret_cast<const float2*>(brow[k] + 4 * t);
-        };
-        read_ops(0);
+        for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));     // vmcnt((D-1) NL) only
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
+
+    unsigned sb = 0;                                    // byte offset of the ring slot of chunk c (uniform)
+#pragma nounroll
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned nb = sb + BUF == (unsigned)(D * BUF) ? 0u : sb + BUF;
+        unsigned cA[4], cB[4];
 #pragma unroll
-        for (int t = 0; t < KT / 4; ++t) {
-            if (t + 1 < KT / 4) read_ops(t + 1);
-            // half-way through the chunk the next tile (in flight since the top of the loop) is written to
-            // the other ring slot, so the ds_writes issue in the shadow of the remaining MFMAs
-#if WG_EXP != 2 && WG_EXP != 4
-            if (t == KT / 8 && more) write_chunk(lds + ((c + 1) & 1) * BUF);
-#endif
+        for (int t = 1; t < 4; ++t) { cA[t] = offA[t] + sb; cB[t] = offB[t] + sb; }
+        cA[0] = offA[0] + nb; cB[0] = offB[0] + nb;     // round 0 of the NEXT chunk (read in this chunk's round 3)
+        static_for<4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            lds_wait<0>(av[r & 1]);
 #pragma unroll
-            for (int ia = 0; ia < SP::SAn; ++ia) {
-                if (NBA * 32 > 0 && SP::sa(w, ia) >= NBA) continue;        // wave has fewer blocks than SAn (wave-uniform)
-#pragma unroll
-                for (int ib = 0; ib < SP::SBn; ++ib) {
-                    acc[ia * SP::SBn + ib] = mfma32(av[t & 1][ia].x, bv[t & 1][ib].x, acc[ia * SP::SBn + ib]);
-                    acc[ia * SP::SBn + ib] = mfma32(av[t & 1][ia].y, bv[t & 1][ib].y, acc[ia * SP::SBn + ib]);
-                }
-                if (do_bias) bsum[ia] += av[t & 1][ia].x + av[t & 1][ia].y;
+            for (int k = 0; k < SBn; ++k) asm volatile("" : "+v"(bv[r & 1][k]));
+            if constexpr (r == 3) {
+                // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
-        }
-#if WG_EXP != 3
-        __syncthreads();
-#endif
+            if (want_bias && (r % SP::NSHARE) == my_rank) {            // wave-uniform
+                asm volatile("");                                       // (keeps this a branch: no if-conversion into selects)
+#pragma unroll
+                for (int ia = 0; ia < SAn; ++ia) bs[ia] += av[r & 1][ia];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NGAP>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int u = g / NPAIR, pr = g % NPAIR, ia = pr / SBn, ib = pr % SBn;
+                if constexpr (g < NR) read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
+                if constexpr (r == 3) {                                 // refill the released slot with chunk c + D
+                    constexpr int G0 = NR < NGAP ? NR : NGAP - 1;
+                    constexpr int PD = (NGAP - G0) / NL > 0 ? (NGAP - G0) / NL : 1;
+                    static_for<NL>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int at = G0 + i * PD < NGAP ? G0 + i * PD : NGAP - 1;
+                        if constexpr (at == g) dma_chunk_piece(c + D, sb, i);
+                    });
+                }
+                acc[pr] = mfma32(av[r & 1][ia][u], bv[r & 1][ib][u], acc[pr]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        sb = nb;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the ring's last (clamped) refills
 
     // epilogue: partial tile [NBA*32][NBB*32], C layout: lane holds column j = li, rows crow(r, half)
     float* __restrict__ P = a.part + jb.part_off;
     constexpr int LDP = NBB * 32;
 #pragma unroll
-    for (int ia = 0; ia < SP::SAn; ++ia) {
-        const int ba = SP::sa(w, ia);
-        if (ba >= NBA) continue;
+    for (int ia = 0; ia < SAn; ++ia) {
+        const int ba = SP::a_lit(ia) + SP::a_wave(w);
 #pragma unroll
-        for (int ib = 0; ib < SP::SBn; ++ib) {
-            const int bb = SP::sb(w, ib);
+        for (int ib = 0; ib < SBn; ++ib) {
+            const int bb = SP::b_lit(ib) + SP::b_wave(w);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = ba * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                P[(int64_t)row * LDP + bb * 32 + li] = acc[ia * SP::SBn + ib][r];
+                P[(int64_t)row * LDP + bb * 32 + li] = acc[ia * SBn + ib][r];
             }
         }
-        if (do_bias) {
-            const float s = bsum[ia] + __shfl_xor(bsum[ia], 32);            // the two k-halves of the row
-            if (half == 0) a.part[jb.bias_off + ba * 32 + li] = s;
+        if (want_bias) {
+            // this wave's share of the row sums (its rounds, both k halves); the reduction adds the NSHARE shares
+            float sum = (bs[ia][0] + bs[ia][1]) + (bs[ia][2] + bs[ia][3]);
+            sum += __shfl_xor(sum, 32);
+            if (half == 0) a.part[jb.bias_off + (int64_t)my_rank * (NBA * 32) + ba * 32 + li] = sum;
         }
     }
 }
@@ -240,7 +272,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const WgOut*
         } else {
             const int r = (int)(e - n_w);
             const float* p = part + o.bias_part_off + r;
-            for (int k = 0; k < o.n_slices; ++k) s += p[k * o.bias_slice_stride];
+            for (int k = 0; k < o.n_slices; ++k)
+                for (int q = 0; q < o.bias_sub; ++q) s += p[k * o.bias_slice_stride + (int64_t)q * o.ldb];
             grad[o.bias_out_off + r] = s;
         }
     }
@@ -303,26 +336,44 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
     d.push_back({2, 0, GT, 3, 0, R_h + 7 * W, W, 0, 1, W, 0, w_d, W, 0, b_d});                                  // density_linear
     d.push_back({2, 0, GT, 4, 0, R_g2, HW, 0, C, HW, 0, w_io, HW, 0, b_io});                                   // ins_linear
     d.push_back({2, 0, GT, 0, 0, R_g1, HW, 0, 3, HW, 0, w_ro, HW, 0, b_ro});                                   // rgb_linear
-    // Cost of one 32-sample chunk for a workgroup: its MFMA time (NBA*NBB blocks * 16 MFMAs * 64 cycles
-    // over 4 SIMDs = 256 cycles per block pair) but never less than the fixed per-chunk latency of the
-    // load -> LDS -> barrier pipeline (measured ~2.5 us: the skinny jobs were the long pole when slices
-    // were allotted by FLOPs alone).
-    auto chunk_cost = [](int cls) { const double c = 256.0 * CLS_NBA[cls] * CLS_NBB[cls]; return c < 6000.0 ? 6000.0 : c; };
-    double total = 0;
-    for (auto& j : d) { j.cls = class_for(j.rowsA, j.rowsB); total += chunk_cost(j.cls); }
+    // Cost of one 32-sample chunk for a workgroup = its measured time in ns (scripts/diag_wgrad.py on MI355X,
+    // r01): the MFMA time 256 * NBA * NBB cycles at ~2.4 GHz plus ~3 % for the fat classes; the skinny
+    // classes are bound by the per-chunk hand-over (barrier + DMA issue), ~0.5 us.
+    auto chunk_cost = [](int cls) {
+        static const double ns[N_CLASSES] = {/*8,8*/ 7025, /*4,8*/ 3530, /*8,2*/ 1858, /*4,1*/ 538, /*1,8*/ 984,
+                                             /*1,4*/ 540, /*2,4*/ 1000, /*3,4*/ 1400, /*4,4*/ 1800};
+        return ns[cls];
+    };
+    // Slices per job: minimise the longest workgroup (chunks per slice x chunk cost) under sum(slices) <= max_wgs:
+    // start from one slice each and keep giving a slice to the job whose workgroups are the longest.
+    for (auto& j : d) j.cls = class_for(j.rowsA, j.rowsB);
+    std::vector<int> n_slices(d.size(), 1);
+    {
+        auto wg_time = [&](size_t k) { return chunk_cost(d[k].cls) * (double)((nchunks + n_slices[k] - 1) / n_slices[k]); };
+        int used = (int)d.size();
+        while (used < max_wgs) {
+            size_t worst = 0;
+            for (size_t k = 1; k < d.size(); ++k)
+                if (wg_time(k) > wg_time(worst)) worst = k;
+            if (n_slices[worst] >= nchunks) break;
+            ++n_slices[worst];
+            ++used;
+        }
+    }
 
     Plan P;
-    for (auto& j : d) {
+    for (size_t jk = 0; jk < d.size(); ++jk) {
+        auto& j = d[jk];
         const int nba = CLS_NBA[j.cls], nbb = CLS_NBB[j.cls];
-        int ns = (int)((double)max_wgs * chunk_cost(j.cls) / total);   // floor => sum <= max_wgs
-        if (ns < 1) ns = 1;
-        if (ns > nchunks) ns = nchunks;
-        const int64_t tile = (int64_t)nba * 32 * nbb * 32, brow = (int64_t)nba * 32;
+        const int ns = n_slices[jk];
+        const int nshare = nbb >= 4 ? 4 : (nbb == 2 ? 2 : 1);               // Split<>::NSHARE
+        const int64_t tile = (int64_t)nba * 32 * nbb * 32, brow = (int64_t)nba * 32 * nshare;
         WgOut o{};
         o.part_off = P.part_floats; o.slice_stride = tile + brow;
         o.bias_part_off = P.part_floats + tile; o.bias_slice_stride = tile + brow;
         o.out_off = j.out_off; o.bias_out_off = j.bias_out_off;
         o.n_slices = ns; o.rowsA = j.rowsA; o.rowsB = j.rowsB; o.ldp = nbb * 32; o.ld_out = j.ld_out; o.col_off = j.col_off;
+        o.bias_sub = nshare; o.ldb = nba * 32;
         P.outs.push_back(o);
         for (int s = 0; s < ns; ++s) {
             WgJob g{};
@@ -378,7 +429,7 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
     WgArgs a{};
     a.src[0] = d_save; a.src[1] = d_dsave; a.src[2] = d_graw_t;
     a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_wgrad_trace;
-    const size_t lds_bytes = 2 * (size_t)MAX_ROWS * LDS_STRIDE * sizeof(float);      // 139 264 B
+    const size_t lds_bytes = WG_LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
