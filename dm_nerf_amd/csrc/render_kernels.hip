@@ -207,8 +207,31 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS writes above are read below by other lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // channel sums: lane <-> channel, samples in order; products in f32 (as the reference forms
-    // weights[..., None] * rgb), accumulated in double
+    // channel sums: products in f32 (as the reference forms weights[..., None] * rgb), accumulated in double.
+    // lane = (sample group g, channel c): NG = 64 / ch groups take the samples s = g, g + NG, ... of their
+    // channel, and the NG partial sums are added in group order (the double accumulator makes the result
+    // independent of the order to far below one f32 ulp).
+    if (ch <= 32) {
+        const int NG = WAVE / ch;
+        const int g = lane / ch, c = lane - g * ch;
+        const bool act = g < NG && c != 3 && (c < 3 || c - 4 < n_ins);
+        double acc = 0.0;
+        if (act) {
+            if (c < 3) {
+                for (int s = g; s < S; s += NG) acc += (double)(wl[s] * sigmoidf_ref(rr[(int64_t)s * ch + c]));
+            } else {
+                for (int s = g; s < S; s += NG) acc += (double)(wl[s] * rr[(int64_t)s * ch + c]);
+            }
+        }
+        double tot = 0.0;
+        for (int q = 0; q < NG; ++q) tot += shfl_d(acc, q * ch + (lane < ch ? lane : 0));
+        if (lane < ch && lane != 3) {
+            if (lane < 3) rgb_map[n * 3 + lane] = (float)tot;
+            // sigmoid after the sum; n_ins = C-1 drops the last channel (render.py:24-26), n_ins = C keeps it (manipulator.py:101-102)
+            else if (lane - 4 < n_ins) ins_map[n * (int64_t)n_ins + (lane - 4)] = sigmoidf_ref((float)tot);
+        }
+        return;
+    }
     for (int c = lane; c < ch; c += WAVE) {
         if (c == 3) continue;
         double acc = 0.0;

@@ -87,7 +87,9 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
         'rgb_fine': torch.empty(N, 3, **f), 'ins_fine': torch.empty(N, C - 1, **f),
         'z_vals_fine': torch.empty(N, SF, **f), 'raw_fine': torch.empty(N, SF, 4 + C, **f),
         'raw_coarse': torch.empty(N, S, 4 + C, **f), 'rgb_coarse': torch.empty(N, 3, **f),
-        'ins_coarse': torch.empty(N, C - 1, **f), 'z_vals_coarse': torch.empty(N, S, **f),
+        'ins_coarse': torch.empty(N, C - 1, **f),
+        # without jitter the reference hands its input grid back (render.py:40-47 is skipped): alias, no copy
+        'z_vals_coarse': torch.empty(N, S, **f) if t_rand is not None else z_in,
         'depth_fine': torch.empty(N, **f), 'depth_coarse': torch.empty(N, **f),
     }
     ws = torch.empty(N, SF, **f)

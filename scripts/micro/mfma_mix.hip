@@ -26,15 +26,18 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
     f32x4 a[2][8];
     for (int i = 0; i < 8; ++i) { a[0][i] = (f32x4)(1e-3f * tid); a[1][i] = (f32x4)(2e-3f * tid); }
     float b = blockIdx.x * 1e-3f + 1.f, vv = tid;
+    float w8[8]; int i8[8];
+    for (int i = 0; i < 8; ++i) { w8[i] = tid * 0.1f + i; i8[i] = tid * 7 + i; }
     const unsigned s0 = (unsigned)(unsigned long long)(LAS const void*)lds + lane * 16;
     const char* g = (const char*)src + lane * 16 + w * 1024;
     // DFORM 1: SGPR base + 32-bit VGPR offset (no per-piece VALU), M0 from SALU
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const unsigned voff = lane * 16;
     const unsigned long long gb = (unsigned long long)src + wu * 1024;
-    const unsigned long long ub = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(gb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)gb);
+    const unsigned ub_lo = __builtin_amdgcn_readfirstlane((unsigned)gb), ub_hi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+    const unsigned long long ub = ((unsigned long long)ub_hi << 32) | ub_lo;
     const unsigned ul = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(LAS const void*)lds + 65536 + wu * 1024);
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, 1 << 20, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, 1 << 28, 0x00020000);
     for (int it = 0; it < iters; ++it) {
         if (WAITV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
@@ -58,12 +61,32 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LAS void*)(lds + 16384 + wu * 256 + (M / 8) * 1024), 16, voff, (M / 8) * 4096, 0, 0);
                 }
                 for (int v = 0; v < VALU; ++v) vv = fmaxf(vv * 1.0001f, 0.5f);
+                if constexpr (DFORM == 10 && M % 2 == 0)       // 128 dword stores per body (distinct rows, 128 B apart)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[gl & 1][i & 7][0]), rs, (int)voff / 4 + (M / 2) * 128, it * 16384, 0);
+                if constexpr (DFORM == 11 && M % 8 == 0) {     // 32 dwordx4 stores per body
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 q = {__float_as_uint(a[gl & 1][i & 7][0]), __float_as_uint(a[gl & 1][i & 7][1]), __float_as_uint(a[gl & 1][i & 7][2]), __float_as_uint(a[gl & 1][i & 7][3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)voff + (M / 8) * 1024, it * 32768, 0);
+                }
+                if constexpr (DFORM >= 20 && DFORM < 30) {       // (DFORM - 20) independent fma per gap over 8 registers
+                    for (int v = 0; v < DFORM - 20; ++v) { const int q = (M * (DFORM - 20) + v) & 7; w8[q] = fmaf(w8[q], 1.0001f, 0.5f); }
+                }
+                if constexpr (DFORM >= 30 && DFORM < 40) {       // (DFORM - 30) independent integer max per gap (non-idempotent: +1 first)
+                    for (int v = 0; v < DFORM - 30; ++v) { const int q = (M * (DFORM - 30) + v) & 7; i8[q] = (i8[q] ^ (int)(M + v)) > 3 ? (i8[q] ^ (int)(M + v)) : 3; }
+                }
+                if constexpr (DFORM == 12 && M % 2 == 0) {     // 128 independent 1-op VALU (integer max on distinct registers)
+                    const int q = (M / 2) & 31;
+                    unsigned x = __float_as_uint(a[(gl + 1) & 1][q >> 2 & 7][q & 3]);
+                    x = (int)x > 0 ? x : 0u;
+                    a[(gl + 1) & 1][q >> 2 & 7][q & 3] = __uint_as_float(x);
+                }
                 acc[i & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gl & 1][i & 7][i >> 3 & 3], b, acc[i & 15], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
     }
     float s = vv;
+    for (int i = 0; i < 8; ++i) s += w8[i] + (float)i8[i];
     for (int i = 0; i < 16; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
@@ -73,7 +96,7 @@ void run(const char* name) {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     int grid = p.multiProcessorCount, iters = 2000;
     float *out, *src;
-    (void)hipMalloc(&out, grid * 256 * 4); (void)hipMalloc(&src, 1 << 20); (void)hipMemset(src, 0, 1 << 20);
+    (void)hipMalloc(&out, grid * 256 * 4); (void)hipMalloc(&src, 1 << 28); (void)hipMemset(src, 0, 1 << 20);
     auto k = mix<READS, DMAS, BARRIER, VALU, WAITV, DFORM>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -85,11 +108,27 @@ void run(const char* name) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double flop = (double)grid * 4 * iters * 256.0 * 4096.0;
     double cyc = ms * 1e-3 * 2.4e9 / iters;     // cycles per 256-MFMA body at 2.4 GHz (ideal 16384)
+    fflush(stdout);
     printf("%-34s %.3f ms  %6.1f TFLOP/s  %7.0f cycles per 256 MFMAs (+%5.0f)\n", name, ms, flop / ms * 1e-9, cyc, cyc - 16384);
+    fflush(stdout);
     (void)hipFree(out); (void)hipFree(src);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int only_new = argc > 1;
+    if (only_new) {
+        run<0, 0, 0, 0, 0>("mfma only (warm-up)");
+        run<0, 0, 0, 0, 0>("mfma only");
+        run<0, 0, 0, 0, 0, 21>("+ 1 independent fma per gap");
+        run<0, 0, 0, 0, 0, 22>("+ 2 independent fma per gap");
+        run<0, 0, 0, 0, 0, 24>("+ 4 independent fma per gap");
+        run<0, 0, 0, 0, 0, 28>("+ 8 independent fma per gap");
+        run<0, 0, 0, 0, 0, 32>("+ 2 int (xor,max) pairs per gap");
+        run<0, 0, 0, 1, 0>("+ 1 dependent (mul,max) per gap");
+        run<0, 0, 0, 0, 0, 11>("+ 32 buffer_store_dwordx4");
+        run<0, 0, 0, 0, 0, 10>("+ 128 buffer_store_dword");
+        return 0;
+    }
     run<0, 0, 0, 0, 0>("mfma only");
     run<1, 0, 0, 0, 0>("+ 64 ds_read_b128");
     run<1, 0, 1, 0, 0>("+ reads + barrier");
@@ -101,6 +140,9 @@ int main() {
     run<0, 16, 0, 0, 0, 2>("+ 16 DMA (buffer_load lds)");
     run<1, 16, 1, 0, 1, 1>("reads + 16 DMA saddr + vmcnt + bar");
     run<1, 16, 1, 0, 1, 2>("reads + 16 DMA buffer + vmcnt + bar");
+    run<0, 0, 0, 0, 0, 10>("+ 128 buffer_store_dword");
+    run<0, 0, 0, 0, 0, 11>("+ 32 buffer_store_dwordx4");
+    run<0, 0, 0, 0, 0, 12>("+ 128 independent v_max_i32");
     run<0, 0, 0, 1, 0>("+ 1 VALU per gap");
     run<0, 0, 0, 2, 0>("+ 2 VALU per gap");
     run<0, 0, 0, 4, 0>("+ 4 VALU per gap");
