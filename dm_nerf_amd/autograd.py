@@ -28,14 +28,21 @@ def _row_len(M):
 def _views(buf, M):
     """Feature-major [rows, row_len] COPIES of the tensors of a SaveLayout workspace (csrc/layout.h) --
     diagnostics / tests only.  On the device every tensor is block-major [block][rows][32 samples];
-    padding columns hold duplicates of the last sample (activations) or exact zeros (gradients)."""
+    padding columns hold duplicates of the last sample (activations) or exact zeros (gradients).  The
+    accumulator-layout tensors (everything but the encodings) keep the memory row order 0,4,1,5,2,6,3,7
+    inside each group of 8 features (csrc/layout.h::row_feature); the copies are in feature order."""
     Mp = _row_len(M)
     o = 0
     out = {}
     for name, rows, n in (("pe", 63, 1), ("de", 27, 1), ("h", W, 8), ("f", W, 1), ("q", W, 1), ("g1", HW, 1), ("g2", HW, 1)):
         ts = []
         for _ in range(n):
-            ts.append(buf[o:o + rows * Mp].view(Mp // 32, rows, 32).permute(1, 0, 2).reshape(rows, Mp))
+            t = buf[o:o + rows * Mp].view(Mp // 32, rows, 32).permute(1, 0, 2).reshape(rows, Mp)
+            if name not in ("pe", "de"):
+                rho = torch.arange(rows, device=buf.device)
+                feat = (rho & ~7) | ((rho & 7) >> 1) | ((rho & 1) << 2)
+                t = t[torch.argsort(feat)]
+            ts.append(t)
             o += rows * Mp
         out[name] = ts[0] if n == 1 else torch.stack(ts)
     return out

@@ -165,6 +165,10 @@ struct SaveLayout {
 };
 // Row length: M rounded up to a multiple of 32 so that a wave's 32-sample block never straddles
 // the end of a row (tail lanes store into / read from the padding columns).
+// Accumulator-layout training tensors keep, inside every group of 8 features, the memory row order
+// 0,4,1,5,2,6,3,7 (mlp_common.h: TID-addressed stores).  Feature held by memory row rho:
+DMN_HD constexpr int row_feature(int rho) { return (rho & ~7) | ((rho & 7) >> 1) | ((rho & 1) << 2); }
+
 DMN_HD constexpr int64_t save_row_len(int64_t M) { return (M + 31) & ~(int64_t)31; }
 
 DMN_HD inline SaveLayout make_save_layout(int64_t M_samples) {

@@ -55,14 +55,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     const bool wave_active = blk_raw < nblk;
     const int64_t blk = wave_active ? blk_raw : nblk - 1;
     const int64_t m_raw = blk * 32 + (lane & 31);
-    const bool valid = wave_active && m_raw < a.M;
+    const bool valid = m_raw < a.M;          // (a wave beyond the batch duplicates the last block exactly)
     const int64_t m = m_raw < a.M ? m_raw : a.M - 1;
 
     const BlobLayout& L = a.L;
     const BlobTLayout& LT = a.LT;
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);
-    const int srows = wave_active ? 1 : 0;           // inactive waves: empty descriptors, stores become no-ops
+    const int srows = 1;
 
     // ---- oldest VMEM ops: incoming gradient, ReLU bit masks, table --------------------------------
     const float* __restrict__ gr = a.graw + m * (4 + L.C);
@@ -156,13 +156,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
 #pragma nounroll
     for (int st = 0; st < NSTAGE_T; ++st) {
         const RowIO dio = make_rowio(st == 0 ? a.dsave + SL.f : a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
+        // dy is saved while it is consumed: 43 + 43 + 42 TID-addressed stores in the MFMA gaps of quarters 1..3
+        auto st_d = [&](int k0) { return [&, k0](int k) { store_row_one(dio, d, k0 + k); }; };
         gemm_quarter<0, 8, 8, 8, true>(ws, d, acc, lane);
-        store_rows_part<0, 43>(dio, d);
-        gemm_quarter<8, 8, 8, 8>(ws, d, acc, lane);
-        store_rows_part<43, 43>(dio, d);
-        gemm_quarter<16, 8, 8, 8>(ws, d, acc, lane);
-        store_rows_part<86, 42>(dio, d);
-        gemm_quarter<24, 8, 8, 8>(ws, d, acc, lane);                     // (the last stage prefetches from the landing zone)
+        gemm_quarter<8, 8, 8, 8, false, 43>(ws, d, acc, lane, st_d(0));
+        gemm_quarter<16, 8, 8, 8, false, 43>(ws, d, acc, lane, st_d(43));
+        gemm_quarter<24, 8, 8, 8, false, 42>(ws, d, acc, lane, st_d(86));   // (the last stage prefetches from the landing zone)
         if (st == 0) {
             // density_linear (dm_nerf.py:101): dh_7 += w_d * g_sigma
             const f32x4* wd = reinterpret_cast<const f32x4*>(tab + LT.w_den + half * 128);

@@ -109,9 +109,19 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16
 #ifndef DMN_STORE_AUX
 #define DMN_STORE_AUX 0   /* cache policy bits of the activation stores (2 = nt) */
 #endif
+// Accumulator-layout tensors (h, f, q, g1, g2 and their gradients) are stored with TID-ADDRESSED stores:
+// the descriptor has stride 4 + ADD_TID_ENABLE, so lane l of a `buffer_store_dword v, off, rsrc, soffset
+// offset:imm` writes base + soffset + imm + 4 l -- one contiguous 256-byte run per instruction and NO
+// address VGPR.  A store with an address VGPR costs ~27 cycles of a one-wave MFMA stream, this form none
+// (scripts/micro/mfma_mix.hip), and a 256 -> 256 layer saves 128 of them.  For that, the two features a
+// register holds (f in lanes 0-31, f + 4 in lanes 32-63) must be adjacent 128-byte rows, so inside every
+// group of 8 features the MEMORY row order is 0,4,1,5,2,6,3,7:
+//     mem_row(f) = (f & ~7) + 2 (f & 3) + ((f >> 2) & 1),    feature(mem_row) = layout.h::row_feature()
+// (the weight-gradient kernel maps its output rows/columns back; nothing else reads these tensors).
 struct RowIO {
-    rsrc_t rs;
-    int voff;        // ((blk*R + 4*half) * 32 + j) * 4 bytes
+    rsrc_t rs;        // stride 4, ADD_TID_ENABLE, 64 records (the record count does not bound the lanes: a wave
+                      // beyond the end of the batch is an exact duplicate of the last block's wave instead)
+    unsigned soff;    // byte offset of this wave's 32-sample block: blk * R * 128 (uniform)
 };
 
 // NOTE: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0
@@ -129,23 +139,32 @@ __device__ __forceinline__ rsrc_t uniform_rsrc(const float* base, int64_t n_floa
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)nb, 0x00020000);
 }
 
-// base: tensor start; R: its row count; Mp: padded sample count (multiple of 32); blk: this wave's block.
+// base: tensor start; R: its row count; blk: this wave's block (Mp is unused: kept for the call sites' symmetry).
 __device__ __forceinline__ RowIO make_rowio(const float* base, int R, int64_t Mp, int64_t blk, int lane) {
     RowIO io;
-    io.rs = uniform_rsrc(base, (int64_t)R * Mp);
-    io.voff = (int)(((blk * R + 4 * (lane >> 5)) * 32 + (lane & 31)) * 4);
+    const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    float* q = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    // with ADD_TID_ENABLE the DATA_FORMAT bits of word 3 are stride[17:14]: they stay 0
+    io.rs = __builtin_amdgcn_make_buffer_rsrc(q, 4, 64, 1 << 23);
+    (void)Mp;
+    io.soff = __builtin_amdgcn_readfirstlane((unsigned)(blk * R * 128));
+    (void)lane;
     return io;
 }
+
+// register r of out-block b -> byte offset of its 256-byte run inside the block (lanes 0-31: feature
+// 32 b + (r & 3) + 8 (r >> 2), lanes 32-63: that + 4)
+__device__ __forceinline__ constexpr int run_off(int b, int r) { return (32 * b + 8 * (r >> 2) + 2 * (r & 3)) * 128; }
 
 template <int NB>
 __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB]) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * b + (r & 3) + 8 * (r >> 2);
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, DMN_STORE_AUX);
-        }
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, run_off(0, r), (int)(io.soff + b * 4096), DMN_STORE_AUX);
     }
 }
 
@@ -176,20 +195,13 @@ __device__ __forceinline__ void store_encoded_rows(const float* base, int64_t Mp
 // ==========================================================================================
 // LDS = [ring: 2 slots x 64 KiB][table: 16 KiB].  The weight stream (layout.h) is consumed one
 // 64 KiB quarter at a time; quarter q lives in slot q & 1.  All four waves of the workgroup issue
-// the LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, 16 per wave and quarter) for
-// quarter q+2 the moment quarter q has been released, i.e. one full quarter (256 MFMAs per wave,
-// ~6.8 us) before it is needed, and read their A operands with ds_read_b128 (lgkmcnt), so
-//   * no VMEM load is ever issued inside the MFMA stream, and every DMA is OLDER than the activation
-//     stores issued after it: waiting for a DMA (vmcnt retires in order) never waits for a store ack;
+// the LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, 16 per wave and quarter) for
+// quarter q+1 during the first fourth of quarter q, and read their A operands with ds_read_b128, so
+//   * no VMEM load result is ever waited for inside the MFMA stream, and every DMA is OLDER than the
+//     activation stores issued after it;
 //   * the L2 -> CU weight traffic drops 4x (one copy per workgroup instead of one per wave).
-// Protocol per quarter q (slot q & 1):
-//   ws_begin()   = s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier   -- ONE barrier: every wave's DMA pieces of quarter q
-//                  have landed AND every wave is done reading the other slot (quarter q-1)
-//   [training: this boundary's batch of activation stores]
-//   first k-group (8 ds_read_b128 + 32 MFMAs), then ws_fetch(): DMA of quarter q+1 into the other slot, issued
-//                  in the shadow of the MFMA stream, then the remaining k-groups.
-// vmcnt(0) at a boundary only ever waits for operations issued a full quarter earlier (the DMA and the store
-// batch in front of it), except after the two small once-per-block bursts of the heads.
+// The hand-over of a quarter (vmcnt(0) + s_barrier) happens at the start of the previous quarter's last
+// k-group: see gemm_quarter / ws_handover below.
 constexpr int SLOT_FLOATS = QUARTER_FLOATS;
 constexpr int RING_FLOATS = 2 * SLOT_FLOATS;
 constexpr int LDS_FLOATS = RING_FLOATS + TAB_FLOATS;       // 147 456 bytes
@@ -276,11 +288,19 @@ __device__ __forceinline__ void lds_wait(f32x4 (&v)[NV]) {
 // of q + 2, because a wave only arrives after its last LDS read of q has returned.  It sits at the START of
 // quarter q's last k-group (whose operands are already in registers), so the first operands of q + 1 are
 // read under that group's MFMAs and no LDS latency is exposed at the quarter boundary.
+template <int NYOUNGER = 0>
 __device__ __forceinline__ void ws_handover() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt retires in order: "at most NYOUNGER outstanding" = everything older than the NYOUNGER activation
+    // stores issued after this quarter's DMA pieces has landed
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (NYOUNGER & 15) | ((NYOUNGER >> 4) << 14));
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+
+struct NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
 
 // Very first quarter of the kernel: wait for it (and for the LDS table), then read its first operands.
 template <int OB>
@@ -301,9 +321,11 @@ __device__ __forceinline__ void ws_prime(WStream& ws, int lane) {
 // Schedule per k-group (4 OB MFMAs, k-major): the OB reads of the NEXT group ride in the first OB MFMA
 // gaps (register double buffer), the 16 DMA pieces of the next quarter are spread over the first fourth of
 // the quarter, one per gap; the last group starts with the hand-over and reads the next quarter's first
-// operands into ws.pre.
-template <int G0, int NG, int OB, int NEXT_OB, bool ZERO = false, int NB>
-__device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane) {
+// operands into ws.pre.  NSIDE "side" operations side(0) .. side(NSIDE-1) (training: TID-addressed activation
+// stores, which cost nothing when they are SPREAD over the MFMA stream but stall it when issued as a burst)
+// ride in every third gap between the DMA pieces and the last group.
+template <int G0, int NG, int OB, int NEXT_OB, bool ZERO = false, int NSIDE = 0, int NB, class Side = NoSide>
+__device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB], f32x16 (&acc)[OB], int lane, Side&& side = Side()) {
     static_assert(NB * 16 >= (G0 + NG) * 4, "B operand too small");
     static_assert(NG * OB <= 64, "more than one quarter");
     constexpr int GM = 4 * OB;                       // MFMAs per k-group
@@ -311,6 +333,9 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
     constexpr int P = (Q / 4) / DMA_PER_QUARTER > 0 ? (Q / 4) / DMA_PER_QUARTER : 1;   // gaps between DMA pieces (first quarter of the call)
     static_assert(OB + (DMA_PER_QUARTER - 1) * P < Q - GM, "DMA pieces must be issued before the last group");
     static_assert(NG >= 2 && NEXT_OB <= GM && NEXT_OB <= 8, "hand-over does not fit the last group");
+    constexpr int S0 = OB + DMA_PER_QUARTER * P;      // first gap of the side operations
+    constexpr int SP = NSIDE > 0 ? ((Q - GM - S0) / NSIDE >= 3 ? 3 : ((Q - GM - S0) / NSIDE >= 1 ? (Q - GM - S0) / NSIDE : 1)) : 1;
+    static_assert(NSIDE == 0 || (S0 + (NSIDE - 1) * SP < Q - GM && NSIDE <= 63), "side operations do not fit before the last group");
     const unsigned s0 = lds_addr(ws.ring + ws.cslot * SLOT_FLOATS) + lane * 16;
     const unsigned s1 = lds_addr(ws.ring + (ws.cslot ^ 1) * SLOT_FLOATS) + lane * 16;
     f32x4 a[2][OB];
@@ -319,7 +344,7 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
     static_for<NG>([&](auto gc) {
         constexpr int gl = decltype(gc)::value;
         lds_wait<0>(a[gl & 1]);
-        if constexpr (gl == NG - 1 && NEXT_OB > 0) ws_handover();
+        if constexpr (gl == NG - 1 && NEXT_OB > 0) ws_handover<NSIDE>();
         __builtin_amdgcn_sched_barrier(0);
         static_for<GM>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -329,6 +354,7 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
                 lds_read16_async<((gl + 1) * OB + i) * 1024>(a[(gl + 1) & 1][i], s0);           // group gl + 1, out-block i
             if constexpr (gl == NG - 1 && i < NEXT_OB) lds_read16_async<i * 1024>(ws.pre[i], s1);  // next quarter, group 0
             if constexpr (M >= OB && (M - OB) % P == 0 && (M - OB) / P < DMA_PER_QUARTER) ws_fetch_piece(ws, (M - OB) / P);
+            if constexpr (NSIDE > 0 && M >= S0 && (M - S0) % SP == 0 && (M - S0) / SP < NSIDE) side((M - S0) / SP);
             // ZERO: this quarter starts the GEMM -- C = 0 is an inline constant of the MFMA, no accumulator clear
             if constexpr (ZERO && G0 + gl == 0 && kk == 0) acc[ob] = mfma32(a[gl & 1][ob][kk], B[p >> 4][p & 15], (f32x16)(0.f));
             else acc[ob] = mfma32(a[gl & 1][ob][kk], B[p >> 4][p & 15], acc[ob]);
@@ -355,17 +381,21 @@ __device__ __forceinline__ void init_bias_lds(const float* tab_seg, f32x16 (&acc
 }
 
 // ---- 1-bit ReLU masks (layout.h::BITS_WORDS_PER_BLOCK) ---------------------------------------------
+// Element p = 32 w + i of the tensor is bit (31 - i) of word w: each element costs a compare and an
+// add-with-carry (m = 2 m + [h > 0]); the NB/2 words are advanced round-robin so that consecutive VALU
+// instructions are independent.
 template <int NB>
 __device__ __forceinline__ void pack_mask(const f32x16 (&h)[NB], unsigned (&m)[NB / 2]) {
 #pragma unroll
-    for (int w = 0; w < NB / 2; ++w) {
-        unsigned v = 0;
+    for (int w = 0; w < NB / 2; ++w) m[w] = 0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < 32; ++i) {
+#pragma unroll
+        for (int w = 0; w < NB / 2; ++w) {
             const int p = 32 * w + i;
-            v |= (h[p >> 4][p & 15] > 0.f ? 1u : 0u) << i;          // relu backward: grad * (result > 0)
+            const float x = h[p >> 4][p & 15];                          // relu backward: grad * (result > 0)
+            asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m[w]) : "v"(x) : "vcc");
         }
-        m[w] = v;
     }
 }
 
@@ -374,19 +404,23 @@ __device__ __forceinline__ void apply_mask(f32x16 (&d)[NB], const unsigned (&m)[
 #pragma unroll
     for (int p = 0; p < NB * 16; ++p) {
         // sign-extended 1-bit field = 0 or ~0: two VALU ops per register (bfe + and)
-        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)m[p >> 5], p & 31, 1);
+        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)m[p >> 5], 31 - (p & 31), 1);
         d[p >> 4][p & 15] = __uint_as_float(__float_as_uint(g[p >> 4][p & 15]) & keep);
     }
+}
+
+// One register (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
+template <int NB>
+__device__ __forceinline__ void store_row_one(const RowIO& io, const f32x16 (&v)[NB], int p) {
+    __builtin_amdgcn_raw_buffer_store_b32(f2u(v[p >> 4][p & 15]), io.rs, run_off(0, p & 15), (int)(io.soff + (p >> 4) * 4096), DMN_STORE_AUX);
 }
 
 // Stores registers [P0, P0 + NP) (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
 template <int P0, int NP, int NB>
 __device__ __forceinline__ void store_rows_part(const RowIO& io, const f32x16 (&v)[NB]) {
 #pragma unroll
-    for (int p = P0; p < P0 + NP; ++p) {
-        const int row = 32 * (p >> 4) + ((p & 15) & 3) + 8 * ((p & 15) >> 2);
-        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[p >> 4][p & 15]), io.rs, io.voff + (row * 128) % 4096, (row * 128) / 4096 * 4096, DMN_STORE_AUX);
-    }
+    for (int p = P0; p < P0 + NP; ++p)
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[p >> 4][p & 15]), io.rs, run_off(0, p & 15), (int)(io.soff + (p >> 4) * 4096), DMN_STORE_AUX);
 }
 
 }  // namespace dmn

@@ -56,13 +56,14 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Every wave of the workgroup takes part in the DMA + barrier protocol; a wave beyond the end of
-    // the batch (only in the last workgroup) recomputes the last block and stores nothing.
+    // the batch (only in the last workgroup) is an exact duplicate of the last block's wave: it computes and
+    // stores the same values to the same addresses.
     const int64_t nblk = (a.M + 31) / 32;
     const int64_t blk_raw = (int64_t)blockIdx.x * 4 + wave;
     const bool wave_active = blk_raw < nblk;
     const int64_t blk = wave_active ? blk_raw : nblk - 1;
     const int64_t m_raw = blk * 32 + (lane & 31);
-    const bool valid = wave_active && m_raw < a.M;
+    const bool valid = m_raw < a.M;
     const int64_t m = m_raw < a.M ? m_raw : a.M - 1;                      // tail lanes recompute the last sample
 
     const float* __restrict__ blob = a.blob;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);          // padded row length of the training workspace
-    const int srows = wave_active ? 1 : 0;         // an inactive wave gets empty descriptors: its stores are bounds-checked no-ops
+    const int srows = 1;
     // ReLU bit masks for the backward pass (one 16-byte store per lane and layer instead of 128 row loads there)
     rsrc_t bits_rs;
     int bits_voff = 0;
@@ -150,18 +151,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     // saves it in three batches at the quarter boundaries, BEFORE the next DMA is issued, so that DMA
     // stays older than them (see mlp_common.h).  The body is instantiated three times (trunk loop,
     // rgb_feature, ins_feature) to keep the register live ranges of the two heads out of the loop.
-    auto stage = [&](int st, auto next_ob) {           // next_ob: out-blocks of the quarter after the stage
+    auto stage = [&](int st, auto next_ob, auto save_h) {   // next_ob: out-blocks of the quarter after the stage; save_h: store its input
         constexpr int NEXT = decltype(next_ob)::value;
+        constexpr bool SAVE_H = SAVE && decltype(save_h)::value;
         RowIO hio;
         if constexpr (SAVE) hio = make_rowio(a.save + SL.h + (int64_t)(st < 8 ? st : 7) * 256 * MP, 256, (st < 8 ? srows : 0) * MP, blk, lane);
         init_bias_lds<8>(tab + L.b_stage + st * (int)bias_floats(8), acc, half);
+        // training: the stage's input h is saved while it is consumed, 43 + 43 + 42 TID-addressed stores riding in
+        // the MFMA gaps of quarters 1..3 (a burst of stores stalls the one wave; spread out they cost nothing)
+        constexpr int NS = SAVE_H ? 43 : 0;
+        auto st_h = [&](int k0) { return [&, k0](int k) { store_row_one(hio, h, k0 + k); }; };
         gemm_quarter<0, 8, 8, 8>(ws, h, acc, lane);
-        if constexpr (SAVE) store_rows_part<0, 43>(hio, h);
-        gemm_quarter<8, 8, 8, 8>(ws, h, acc, lane);
-        if constexpr (SAVE) store_rows_part<43, 43>(hio, h);
-        gemm_quarter<16, 8, 8, 8>(ws, h, acc, lane);
-        if constexpr (SAVE) store_rows_part<86, 42>(hio, h);
-        gemm_quarter<24, 8, 8, NEXT>(ws, h, acc, lane);
+        gemm_quarter<8, 8, 8, 8, false, NS>(ws, h, acc, lane, st_h(0));
+        gemm_quarter<16, 8, 8, 8, false, NS>(ws, h, acc, lane, st_h(43));
+        gemm_quarter<24, 8, 8, NEXT, false, SAVE_H ? 42 : 0>(ws, h, acc, lane, st_h(86));
     };
     typedef std::integral_constant<int, 8> Next8;
     typedef std::integral_constant<int, 4> Next4;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     // ---- trunk: mlps.1 .. mlps.7
 #pragma nounroll
     for (int st = 0; st < 7; ++st) {
-        stage(st, Next8{});
+        stage(st, Next8{}, std::true_type{});
         if (st == 4) {                                                    // skip: cat[h, pts] (dm_nerf.py:87)
             gemm_quarter<0, 8, 8, 8>(ws, pe, acc, lane);
         }
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 
     DMN_STAMP(3);
     // ---- rgb branch: acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
-    stage(7, Next4{});
+    stage(7, Next4{}, std::true_type{});
     {
         RowIO fio;
         if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
 
     // ---- ins branch: acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
-    stage(8, Next4{});
+    stage(8, Next4{}, std::false_type{});          // re-reads h_7: already saved
     {
         RowIO qio;
         if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);

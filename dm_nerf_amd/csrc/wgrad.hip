@@ -61,6 +61,7 @@ struct WgOut {
     int64_t out_off, bias_out_off;    // float offsets into the flat gradient vector (reference order); bias -1 = none
     int n_slices, rowsA, rowsB, ldp;  // ldp = NBB*32
     int ld_out, col_off, bias_sub, ldb;        // bias_sub shares per slice, ldb = NBA*32 apart
+    int perm_a, perm_b, pad0, pad1;            // operand rows are in the accumulator-layout memory order (layout.h::row_feature)
 };
 
 struct WgArgs {
@@ -268,13 +269,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const WgOut*
             const int r = (int)(e / o.rowsB), c = (int)(e % o.rowsB);
             const float* p = part + o.part_off + (int64_t)r * o.ldp + c;
             for (int k = 0; k < o.n_slices; ++k) s += p[k * o.slice_stride];
-            grad[o.out_off + (int64_t)r * o.ld_out + o.col_off + c] = s;
+            const int ro = o.perm_a ? row_feature(r) : r, co = o.perm_b ? row_feature(c) : c;
+            grad[o.out_off + (int64_t)ro * o.ld_out + o.col_off + co] = s;
         } else {
             const int r = (int)(e - n_w);
             const float* p = part + o.bias_part_off + r;
             for (int k = 0; k < o.n_slices; ++k)
                 for (int q = 0; q < o.bias_sub; ++q) s += p[k * o.bias_slice_stride + (int64_t)q * o.ldb];
-            grad[o.bias_out_off + r] = s;
+            grad[o.bias_out_off + (o.perm_a ? row_feature(r) : r)] = s;
         }
     }
 }
@@ -374,6 +376,8 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
         o.out_off = j.out_off; o.bias_out_off = j.bias_out_off;
         o.n_slices = ns; o.rowsA = j.rowsA; o.rowsB = j.rowsB; o.ldp = nbb * 32; o.ld_out = j.ld_out; o.col_off = j.col_off;
         o.bias_sub = nshare; o.ldb = nba * 32;
+        o.perm_a = j.a_src == 1;                                            // dy tensors of the dgrad pass
+        o.perm_b = !(j.b_base == R_pe || j.b_base == R_de);                 // saved h / f / q / g1 / g2 (not the encodings)
         P.outs.push_back(o);
         for (int s = 0; s < ns; ++s) {
             WgJob g{};

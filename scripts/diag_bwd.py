@@ -7,7 +7,8 @@ from dm_nerf_amd import autograd as G, _lib
 from dm_nerf_amd.networks import dm_nerf as M
 
 torch.manual_seed(0)
-N, S, ins_num, seed = 8, 64, 13, 5
+import os
+N, S, ins_num, seed = int(os.environ.get("DN", 8)), int(os.environ.get("DS", 64)), 13, 5
 sd = O.make_weights(seed, ins_num, gain=1.7)
 g = torch.Generator().manual_seed(seed)
 rays_o = torch.randn(N, 3, generator=g); rays_d = torch.randn(N, 3, generator=g)

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
     const unsigned long long ub = ((unsigned long long)ub_hi << 32) | ub_lo;
     const unsigned ul = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(LAS const void*)lds + 65536 + wu * 1024);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, 1 << 28, 0x00020000);
+    __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 4, 64, (1 << 23));   // stride 4, 64 records, ADD_TID_ENABLE (DATA_FORMAT bits are stride[17:14] then: keep them 0)
     for (int it = 0; it < iters; ++it) {
         if (WAITV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
@@ -63,6 +64,16 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
                 for (int v = 0; v < VALU; ++v) vv = fmaxf(vv * 1.0001f, 0.5f);
                 if constexpr (DFORM == 10 && M % 2 == 0)       // 128 dword stores per body (distinct rows, 128 B apart)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[gl & 1][i & 7][0]), rs, (int)voff / 4 + (M / 2) * 128, it * 16384, 0);
+                if constexpr (DFORM == 13 && M % 2 == 0)       // 128 dword stores, no VGPR address (all lanes one address: issue cost only)
+                    asm volatile("buffer_store_dword %0, off, %1, %2 offset:%3" :: "v"(a[gl & 1][i & 7][0]), "s"(rs), "s"(it * 16384), "n"((M / 2) * 16) : "memory");
+                if constexpr (DFORM == 14 && M % 2 == 0) {     // 128 dword stores through a descriptor with ADD_TID_ENABLE (lane l -> +4 l bytes)
+                    asm volatile("buffer_store_dword %0, off, %1, %2 offset:%3" :: "v"(a[gl & 1][i & 7][0]), "s"(rst), "s"(it * 32768 + (M / 2) * 256), "n"(0) : "memory");
+                }
+                if constexpr (DFORM == 15 && M % 4 == 0) {     // 64 dwordx2 stores
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    u2 q = {__float_as_uint(a[gl & 1][i & 7][0]), __float_as_uint(a[gl & 1][i & 7][1])};
+                    __builtin_amdgcn_raw_buffer_store_b64(q, rs, (int)voff / 2 + (M / 4) * 512, it * 32768, 0);
+                }
                 if constexpr (DFORM == 11 && M % 8 == 0) {     // 32 dwordx4 stores per body
                     typedef unsigned u4 __attribute__((ext_vector_type(4)));
                     u4 q = {__float_as_uint(a[gl & 1][i & 7][0]), __float_as_uint(a[gl & 1][i & 7][1]), __float_as_uint(a[gl & 1][i & 7][2]), __float_as_uint(a[gl & 1][i & 7][3])};
@@ -114,19 +125,32 @@ void run(const char* name) {
     (void)hipFree(out); (void)hipFree(src);
 }
 
+__global__ void tid_probe(float* buf) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 4, 64, (1 << 23));
+    float v = 100.f + threadIdx.x;
+    asm volatile("buffer_store_dword %0, off, %1, %2 offset:128" :: "v"(v), "s"(r), "s"(1024) : "memory");
+}
+static void probe() {
+    float* d; (void)hipMalloc(&d, 1 << 16); (void)hipMemset(d, 0, 1 << 16);
+    tid_probe<<<1, 64>>>(d);
+    float h[16384]; (void)hipMemcpy(h, d, 1 << 16, hipMemcpyDeviceToHost);
+    int first = -1, cnt = 0, ok = 1;
+    for (int i = 0; i < 16384; ++i) if (h[i] != 0.f) { if (first < 0) first = i; ++cnt; }
+    for (int l = 0; l < 64; ++l) if (first >= 0 && h[first + l] != 100.f + l) ok = 0;
+    printf("add_tid probe: first nonzero float index %d (expect (1024+128)/4 = 288), %d nonzero, contiguous-in-lane-order %d\n", first, cnt, ok);
+    fflush(stdout);
+}
 int main(int argc, char** argv) {
     const int only_new = argc > 1;
     if (only_new) {
+        probe();
         run<0, 0, 0, 0, 0>("mfma only (warm-up)");
         run<0, 0, 0, 0, 0>("mfma only");
-        run<0, 0, 0, 0, 0, 21>("+ 1 independent fma per gap");
-        run<0, 0, 0, 0, 0, 22>("+ 2 independent fma per gap");
-        run<0, 0, 0, 0, 0, 24>("+ 4 independent fma per gap");
-        run<0, 0, 0, 0, 0, 28>("+ 8 independent fma per gap");
-        run<0, 0, 0, 0, 0, 32>("+ 2 int (xor,max) pairs per gap");
-        run<0, 0, 0, 1, 0>("+ 1 dependent (mul,max) per gap");
         run<0, 0, 0, 0, 0, 11>("+ 32 buffer_store_dwordx4");
         run<0, 0, 0, 0, 0, 10>("+ 128 buffer_store_dword");
+        run<0, 0, 0, 0, 0, 13>("+ 128 buffer_store_dword off (no vaddr)");
+        run<0, 0, 0, 0, 0, 14>("+ 128 buffer_store_dword add_tid");
+        run<0, 0, 0, 0, 0, 15>("+ 64 buffer_store_dwordx2");
         return 0;
     }
     run<0, 0, 0, 0, 0>("mfma only");
