@@ -71,6 +71,36 @@ def get_select_full(rgb, pose, K, ins_target, N_train):
     return target_c, target_i, rays
 
 
+def get_select_crop(rgb, pose, K, ins_target, ins_index, crop_mask, N_train):
+    """``get_select_crop`` (networks/helpers.py:64-95, the ScanNet batch): 30 % of the batch from the labelled
+    pixels ``ins_index`` (flat indices, numpy), the rest from the central crop ``crop_mask`` (numpy, 1 = inside).
+
+    The host RNG stream is the reference's: ``choice(len(ins_index), N_ins)`` then
+    ``choice(|crop \\ labelled|, N_rgb)`` -- and, like the reference (:82-84), the second draw indexes the crop
+    pixel list itself, not the set difference.  Only the selected rays are generated.
+    Returns ``target_c [N_train,3], target_i [N_ins], batch_rays [2,N_train,3], N_ins``; unlabelled rays first.
+    """
+    H, W, _ = rgb.shape
+    _lib.require_gpu(rgb.contiguous())
+    ins_index = np.asarray(ins_index)
+    N_ins = min(int(N_train * 0.3), len(ins_index))
+    N_rgb = N_train - N_ins
+    crop_indices = np.where(np.asarray(crop_mask).reshape(-1) == 1)[0]
+    labeled_idx = ins_index[np.random.choice(ins_index.shape[0], size=[N_ins], replace=False)]
+    n_unlabeled = len(set(crop_indices.tolist()) - set(labeled_idx.tolist()))
+    unlabeled_idx = crop_indices[np.random.choice(n_unlabeled, size=[N_rgb], replace=False)]
+    flat = np.concatenate([unlabeled_idx, labeled_idx]).astype(np.int64)
+    idx = torch.from_numpy(flat).to(rgb.device)
+    intr, c = _camera(K, pose)
+    rays = torch.empty(2, N_train, 3, dtype=torch.float32, device=rgb.device)
+    _lib.check(_lib.load().dmnerf_raygen_select(int(H), int(W), intr.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p),
+                                                _lib.ptr(idx), int(N_train), _lib.ptr(rays[0]), _lib.ptr(rays[1]), _lib.stream()),
+               "dmnerf_raygen_select")
+    target_c = rgb.reshape(-1, rgb.shape[-1])[idx]
+    target_i = ins_target.reshape(-1)[idx[N_rgb:]]
+    return target_c, target_i, rays, N_ins
+
+
 def z_val_sample(N_rays, near, far, N_samples, device=None):
     """``z_val_sample`` (networks/helpers.py:114-119): ``near + linspace(0,1,S) * (far - near)`` -> [N, S]."""
     dev = _device(device)

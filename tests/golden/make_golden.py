@@ -258,6 +258,30 @@ def gen_select():
     save("select", rgb=rgb, lab=lab, c2w=c2w, K=K, idx=idx, target_c=tc, target_i=ti, rays=rays, HWN=np.array([H, W, N]))
 
 
+def gen_select_crop():
+    """``get_select_crop`` under np.random.seed(3) (helpers.py:64-95, the ScanNet batch): crop mask as built by
+    loader_scannet.py:24-29, labelled pixels = a subset of the crop.  Two cases: more labelled pixels than the 30 %
+    quota, and fewer (the N_ins clamp at :67-68)."""
+    H, W = 12, 16
+    K = O.dmsr_intrinsics(H, W)
+    c2w = O.pose_spherical(11.0, -40.0, 5.0)
+    gen = torch.Generator().manual_seed(602)
+    rgb = torch.rand(H, W, 3, generator=gen)
+    lab = torch.randint(0, 13, (H, W), generator=gen).to(torch.int16)
+    crop = np.zeros((H, W)); crop[2:H - 2, 3:W - 3] = 1; crop = crop.astype(np.int8)
+    inside = np.where(crop.reshape(-1) == 1)[0]
+    out = dict(rgb=rgb, lab=lab, c2w=c2w, K=K, crop=crop, HW=np.array([H, W]))
+    for name, n_lab, N in (("many", 45, 40), ("few", 5, 40)):
+        rs = np.random.RandomState(7 + n_lab)
+        ins_index = np.sort(rs.choice(inside, size=n_lab, replace=False))
+        np.random.seed(3)
+        tc, ti, rays, n_ins = R_helpers.get_select_crop(rgb, c2w[:3, :4], K, lab, ins_index, crop, N)
+        nxt = np.random.rand()
+        out.update({f"{name}_ins_index": ins_index, f"{name}_N": np.array([N, n_ins]), f"{name}_target_c": tc, f"{name}_target_i": ti,
+                    f"{name}_rays": rays, f"{name}_next_rand": np.float64(nxt)})
+    save("select_crop", **out)
+
+
 def gen_manipulator():
     """exchanger / manipulator_render / manipulator (networks/manipulator.py:18-205).  The module imports cv2,
     lpips, imageio, skimage at the top for its eval drivers only: stub them (the arithmetic does not use them)."""
@@ -366,6 +390,10 @@ def gen_penalizer():
 
 if __name__ == "__main__":
     print("reference:", REF, "| torch", torch.__version__)
+    if len(sys.argv) > 1:                       # regenerate single fixtures: python make_golden.py select_crop ...
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_embed()
     gen_mlp()
     gen_render_train()

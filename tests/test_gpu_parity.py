@@ -335,3 +335,20 @@ def test_get_select_full_same_rng_stream_as_reference(A, golden):
     np.random.seed(0)
     A.H.get_select_full(dev(g["rgb"]), dev(g["c2w"])[:3, :4], g["K"].numpy(), dev(g["lab"]), N)
     assert np.random.rand() == want_next
+
+
+def test_get_select_crop_same_rng_stream_as_reference(A, golden):
+    """ScanNet batch (helpers.py:64-95): identical numpy stream => identical pixels, targets, rays and N_ins;
+    both the 30 % quota case and the clamp to the number of labelled pixels."""
+    g = golden("select_crop")
+    crop = g["crop"].numpy()
+    for name in ("many", "few"):
+        N, n_ins_want = [int(v) for v in g[f"{name}_N"]]
+        np.random.seed(3)
+        tc, ti, rays, n_ins = A.H.get_select_crop(dev(g["rgb"]), dev(g["c2w"])[:3, :4], g["K"].numpy(), dev(g["lab"]),
+                                                  g[f"{name}_ins_index"].numpy(), crop, N)
+        assert np.random.rand() == float(g[f"{name}_next_rand"])         # host RNG advanced exactly as in the reference
+        assert n_ins == n_ins_want and rays.shape == (2, N, 3) and ti.shape == (n_ins,)
+        assert torch.equal(cpu(tc), g[f"{name}_target_c"]) and torch.equal(cpu(ti), g[f"{name}_target_i"])
+        assert torch.equal(cpu(rays[0]), g[f"{name}_rays"][0])
+        assert torch.allclose(cpu(rays[1]), g[f"{name}_rays"][1], rtol=3e-7, atol=1e-7)
