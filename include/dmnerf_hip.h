@@ -135,7 +135,11 @@ int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const float* d_ra
  * d_save (dmnerf_train_save_floats(M) floats, M = N*S, Mp = M rounded up to 32).  Each tensor with R
  * rows is stored block-major: addr(sample m, row) = ((m/32 * R + row) * 32 + m%32); tensors in order:
  *   embed(pts) R=63 | embed(dirs) R=27 | h_0..h_7 8 x R=256 | rgb_feature 256 | ins_feature 256 |
- *   rgb hidden 128 | ins hidden 128, each R*Mp floats.   M <= DMNERF_MAX_TRAIN_SAMPLES.          */
+ *   rgb hidden 128 | ins hidden 128, each R*Mp floats, then the 1-bit ReLU masks.
+ * In the 256- and 128-row tensors (not the two encodings) memory row rho holds feature
+ * (rho & ~7) | ((rho & 7) >> 1) | ((rho & 1) << 2), i.e. inside each group of 8 features the rows are
+ * 0,4,1,5,2,6,3,7 (the kernels' TID-addressed stores; only dmnerf_mlp_bwd_* read these buffers, and the
+ * gradients they return are in the reference's parameter order).   M <= DMNERF_MAX_TRAIN_SAMPLES.       */
 int64_t dmnerf_train_save_floats(int64_t M);
 int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_rays_o,
                               const float* d_rays_d, const float* d_z, int64_t N, int S,
