@@ -71,10 +71,10 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
     """Secondary measurement: rays/s of one full optimisation step on a 4096-ray batch (64+128 samples,
     perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
     levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
-    configs/dmsr/train/study.txt), an object-code loss, backward (composite_bwd, dgrad, wgrad kernels),
-    Adam(lr 5e-4).  The reference's object-code loss is a Hungarian-matched CE + soft-IoU solved by scipy on
-    the host (out of scope); a dense MSE on the same [N, ins_num] probabilities stands in for it
-    (identical gradient sparsity: only the ins head receives it)."""
+    configs/dmsr/train/study.txt), the Hungarian-matched object-code loss ins_criterion on both levels (device
+    kernels: the reference solves the assignment with scipy on the host), backward (composite_bwd,
+    dgrad, wgrad kernels), Adam(lr 5e-4).  Labels: a synthetic 9-object segmentation of the chunk."""
+    from dm_nerf_amd.networks import evaluator as E
     from dm_nerf_amd.networks import penalizer as P
     from dm_nerf_amd.networks import render as R
     mc.train(); mf.train()
@@ -83,13 +83,13 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
     args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, tolerance=0.05, deta_w=0.05)
     g = torch.Generator(device=dev).manual_seed(0)
     target = torch.rand(N_RAYS, 3, device=dev, generator=g)
-    tgt_ins = torch.rand(N_RAYS, INS_NUM, device=dev, generator=g)
+    labels = torch.randint(0, 9, (N_RAYS,), device=dev, generator=g)
     rays = torch.stack([ro[:N_RAYS], rd[:N_RAYS]])
 
     def one():
         out = R.dm_nerf(rays, None, None, mc, mf, z, args)
-        loss = ((out['rgb_fine'] - target) ** 2).mean() + ((out['rgb_coarse'] - target) ** 2).mean() \
-            + ((out['ins_fine'] - tgt_ins) ** 2).mean() + ((out['ins_coarse'] - tgt_ins) ** 2).mean() \
+        loss = E.img2mse(out['rgb_fine'], target) + E.img2mse(out['rgb_coarse'], target) \
+            + E.ins_criterion(out['ins_fine'], labels, INS_NUM)[0] + E.ins_criterion(out['ins_coarse'], labels, INS_NUM)[0] \
             + P.ins_penalizer(out['raw_fine'], out['z_vals_fine'], out['depth_fine'], rays[1], args).sum() \
             + P.ins_penalizer(out['raw_coarse'], out['z_vals_coarse'], out['depth_coarse'], rays[1], args).sum()
         opt.zero_grad(set_to_none=True)
@@ -107,7 +107,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
     flop = 2.0 * (2 * MAC_PER_SAMPLE + (MAC_PER_SAMPLE - 101248)) * (2 * S_COARSE + N_IMP) * N_RAYS
     return {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "tflops": flop / dt / 1e12,
             "frac_of_f32_mfma_peak": flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "final_loss": float(loss.detach()),
-            "batch_rays": N_RAYS, "note": "fwd + img2mse + fused emptiness penalizer + object-code MSE (stand-in for the host-side Hungarian loss) + bwd + Adam, perturb=1"}
+            "batch_rays": N_RAYS, "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"}
 
 
 def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):

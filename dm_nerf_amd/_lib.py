@@ -68,6 +68,9 @@ SIGNATURES = {
     "dmnerf_wgrad_plan": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_set_trace": (c_int, [c_vp]),
+    "dmnerf_ins_criterion_work_bytes": (c_i64, [c_i64, c_int]),
+    "dmnerf_ins_criterion_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "dmnerf_ins_criterion_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

@@ -1,0 +1,59 @@
+"""Mirror of the loss side of ``networks/evaluator.py`` that sits in the training step of the reference
+(train_dmsr.py:33-47): ``img2mse``, ``mse2psnr`` and the Hungarian-matched object-code loss ``ins_criterion``.
+
+``ins_criterion`` runs entirely on the GPU stream (csrc/criterion.hip): the reference moves the cost matrix to the
+host for ``scipy.optimize.linear_sum_assignment`` and syncs twice per step.  The metrics half of
+the file (``calculate_ap``, ``ins_eval``) is evaluation tooling and stays with the reference.
+"""
+import torch
+
+from .. import _lib
+
+img2mse = lambda x, y: torch.mean((x - y) ** 2)                                             # evaluator.py:11
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))  # evaluator.py:15
+
+
+class _InsCriterion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, labels, ins_num):
+        lib = _lib.load()
+        N = pred.shape[0]
+        nbytes = lib.dmnerf_ins_criterion_work_bytes(N, ins_num)
+        if nbytes < 0:
+            raise ValueError(f"ins_criterion: unsupported N={N} ins_num={ins_num} (ins_num <= 128)")
+        work = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+        out = torch.empty(4, dtype=torch.float32, device=pred.device)
+        _lib.check(lib.dmnerf_ins_criterion_fwd(_lib.ptr(pred), _lib.ptr(labels), N, ins_num, _lib.ptr(work), nbytes, _lib.ptr(out),
+                                                _lib.stream()), "dmnerf_ins_criterion_fwd")
+        ctx.save_for_backward(pred, labels, work)
+        ctx.ins_num = ins_num
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        pred, labels, work = ctx.saved_tensors
+        grad = torch.empty_like(pred)
+        g = _lib.f32(g_out)
+        _lib.check(_lib.load().dmnerf_ins_criterion_bwd(_lib.ptr(pred), _lib.ptr(labels), pred.shape[0], ctx.ins_num, _lib.ptr(work),
+                                                        _lib.ptr(g), _lib.ptr(grad), _lib.stream()), "dmnerf_ins_criterion_bwd")
+        return grad, None, None
+
+
+def ins_criterion(pred_ins, gt_labels, ins_num):
+    """``ins_criterion`` (networks/evaluator.py:19-37): ``pred_ins [N, ins_num]``, ``gt_labels [N]`` ->
+    ``(ins_loss_sum, valid_ce, invalid_ce, valid_siou)`` as 0-dim tensors, differentiable w.r.t. ``pred_ins``.
+
+    Same definition as the reference: rows of the cost matrices are the labels that occur (ascending), matched to
+    channels by a minimum-cost assignment of ``cost_ce + cost_siou``; ``invalid_ce`` is the mean prediction of the
+    unmatched channels (0 when every channel is matched, where the reference returns ``tensor([0])``).
+    No host synchronisation.
+    """
+    pred = _lib.f32(pred_ins)
+    _lib.require_gpu(pred)
+    if pred.dim() != 2 or pred.shape[1] != int(ins_num):
+        raise ValueError("ins_criterion: pred_ins must be [N, ins_num]")
+    labels = gt_labels.reshape(-1).to(device=pred.device, dtype=torch.int32).contiguous()
+    if labels.shape[0] != pred.shape[0]:
+        raise ValueError("ins_criterion: one label per ray")
+    out = _InsCriterion.apply(pred, labels, int(ins_num))
+    return out[0], out[1], out[2], out[3]

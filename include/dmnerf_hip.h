@@ -173,6 +173,20 @@ int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const floa
  * Used by scripts/diag_wgrad.py to fit the split-K cost model. */
 int dmnerf_wgrad_set_trace(int64_t* d_ticks);
 
+/* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
+ * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
+ * (int32, values 0..ins_num; other values are ignored) -> out4 = {ins_loss_sum, valid_ce, invalid_ce,
+ * valid_siou}.  The cost matrices (:57-69), the label -> channel assignment that the reference delegates to
+ * scipy.optimize.linear_sum_assignment (:43-54; same optimum, solved on the device by shortest augmenting
+ * paths) and the three means (:28-37) run on `stream`; d_work (dmnerf_ins_criterion_work_bytes) carries the
+ * assignment to _bwd, which writes d loss / d pred [N, ins_num] for upstream gradients gout4 of the four outputs.
+ * ins_num <= 128; at most ins_num distinct labels may occur (the reference's own limit, :21-26).            */
+int64_t dmnerf_ins_criterion_work_bytes(int64_t N, int ins_num);
+int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, void* d_work,
+                             int64_t work_bytes, float* d_out4, void* stream);
+int dmnerf_ins_criterion_bwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, const void* d_work,
+                             const float* d_gout4, float* d_grad_pred, void* stream);
+
 /* ---- manipulator.py (scene editing at render time) -----------------------------------
  * manipulator_render (networks/manipulator.py:86-105): render_train whose object map keeps all C channels
  * (d_ins_map [N,C]).  z_val_lerp: the grid of manipulator_nerf (:117-119), near (1-t) + far t.

@@ -309,6 +309,50 @@ def ins_penalizer(raw, z_vals, depth, rays_d, tolerance, deta_w):
 
 
 # --------------------------------------------------------------------------------------
+# object-code loss  (networks/evaluator.py:19-74) -- SURVEY 8(f)-2, the consumer of ins_coarse / ins_fine
+# --------------------------------------------------------------------------------------
+
+def ins_cost_matrices(pred_ins, gt_labels, ins_num):
+    """Cost matrices of ``hungarian`` (networks/evaluator.py:41-70): rows = the labels present in ``gt_labels``
+    in ascending order (the one-hot compaction of :21-26, rows beyond ``valid`` belong to the all-zero columns),
+    columns = predicted channels.  Returns ``cost_ce, cost_siou [ins_num, ins_num], valid``."""
+    present = torch.unique(gt_labels)
+    valid = len(present)
+    onehot = torch.zeros(gt_labels.shape[0], ins_num)
+    onehot[..., :valid] = F.one_hot(gt_labels.long())[..., present.long()]
+    P = pred_ins.permute([1, 0])[None, :, :]                     # [1, channel, ray]
+    G = onehot.permute([1, 0])[:, None, :]                       # [row, 1, ray]
+    cost_ce = torch.mean(-G * torch.log(P + 1e-8) - (1 - G) * torch.log(1 - P + 1e-8), dim=-1)
+    TP = torch.sum(P * G, dim=-1)
+    FP = torch.sum(P, dim=-1) - TP
+    FN = torch.sum(G, dim=-1) - TP
+    cost_siou = 1.0 - TP / (TP + FP + FN + 1e-6)
+    return cost_ce, cost_siou, valid
+
+
+def ins_assignment(cost_ce, cost_siou, valid, ins_num):
+    """``reorder`` (evaluator.py:43-54): scipy's rectangular assignment on the ``valid`` label rows of
+    ``cost_ce + cost_siou``; the unmatched channels follow in ``set`` order.  -> ``rows, cols`` (numpy)."""
+    from scipy.optimize import linear_sum_assignment
+    with torch.no_grad():
+        rows, cols = linear_sum_assignment((cost_ce + cost_siou)[:valid].cpu().numpy())
+    if ins_num - valid > 0:
+        cols = np.concatenate([cols, np.array(list(set(range(ins_num)) - set(cols)))])
+    return rows, cols
+
+
+def ins_criterion(pred_ins, gt_labels, ins_num):
+    """``ins_criterion`` (networks/evaluator.py:19-37) -> ``(loss, valid_ce, invalid_ce, valid_siou)``:
+    mean matched cross-entropy + mean matched soft-IoU cost + mean prediction of the unmatched channels."""
+    cost_ce, cost_siou, valid = ins_cost_matrices(pred_ins, gt_labels, ins_num)
+    rows, cols = ins_assignment(cost_ce, cost_siou, valid, ins_num)
+    valid_ce = torch.mean(cost_ce[rows, cols[:valid]])
+    invalid_ce = torch.mean(pred_ins[:, cols[valid:]]) if len(cols) != valid else torch.tensor([0])
+    valid_siou = torch.mean(cost_siou[rows, cols[:valid]])
+    return valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou
+
+
+# --------------------------------------------------------------------------------------
 # manipulation render  (networks/manipulator.py:18-205) -- SURVEY 8(f)-3
 # --------------------------------------------------------------------------------------
 

@@ -19,6 +19,7 @@ import warnings
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -282,6 +283,37 @@ def gen_select_crop():
     save("select_crop", **out)
 
 
+def gen_ins_criterion():
+    """``ins_criterion`` (networks/evaluator.py:19-74, scipy 1.15 linear_sum_assignment): loss terms and the gradient
+    w.r.t. the predictions for (a) every label present, (b) labels missing (unmatched channels -> invalid_ce),
+    (c) a wide label set (ins_num = 59)."""
+    import networks.evaluator as R_eval
+    out = {}
+    for name, N, ins_num, labels_from in (("all", 192, 13, 13), ("some", 160, 13, 6), ("wide", 256, 59, 41)):
+        gen = torch.Generator().manual_seed(900 + ins_num + labels_from)
+        pred = torch.sigmoid(1.5 * torch.randn(N, ins_num, generator=gen))
+        pool = torch.randperm(ins_num, generator=gen)[:labels_from]
+        lab = pool[torch.randint(0, labels_from, (N,), generator=gen)].to(torch.int64)
+        lab[:labels_from] = pool                                   # every label of the pool occurs
+        # make the prediction informative so that the assignment is not a coin toss
+        pred = (0.55 * pred + 0.45 * F.one_hot(lab, ins_num)[:, torch.randperm(ins_num, generator=gen)].float()).clamp(1e-4, 1 - 1e-4)
+        pr = pred.clone().requires_grad_(True)
+        ref = R_eval.ins_criterion(pr, lab, ins_num)
+        ref[0].sum().backward()
+        po = pred.clone().requires_grad_(True)
+        ora = O.ins_criterion(po, lab, ins_num)
+        ora[0].sum().backward()
+        for a, b, what in zip(ora, ref, ("loss", "valid_ce", "invalid_ce", "valid_siou")):
+            beq(a.float().reshape(-1), b.float().reshape(-1), f"ins_criterion {name} {what}")
+        beq(po.grad, pr.grad, f"ins_criterion {name} grad")
+        cc, cs, valid = O.ins_cost_matrices(pred, lab, ins_num)
+        rows, cols = O.ins_assignment(cc, cs, valid, ins_num)
+        out.update({f"{name}_pred": pred, f"{name}_lab": lab.to(torch.int32), f"{name}_ins_num": np.array(ins_num),
+                    f"{name}_out": torch.stack([t.detach().float().reshape(()) for t in ref]), f"{name}_grad": pr.grad,
+                    f"{name}_cost_ce": cc[:valid], f"{name}_cost_siou": cs[:valid], f"{name}_cols": np.asarray(cols, dtype=np.int64)})
+    save("ins_criterion", **out)
+
+
 def gen_manipulator():
     """exchanger / manipulator_render / manipulator (networks/manipulator.py:18-205).  The module imports cv2,
     lpips, imageio, skimage at the top for its eval drivers only: stub them (the arithmetic does not use them)."""
@@ -402,5 +434,7 @@ if __name__ == "__main__":
     gen_dm_nerf()
     gen_penalizer()
     gen_select()
+    gen_select_crop()
+    gen_ins_criterion()
     gen_manipulator()
     print("all oracle == reference checks passed (bit-exact)")

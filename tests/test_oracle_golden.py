@@ -108,3 +108,18 @@ def test_dm_nerf_dict(golden):
     assert out['ins_fine'].shape == (7, 13) and out['ins_coarse'].shape == (7, 13)
     for k, v in out.items():
         close(v, g[f"prt_{k}"], rtol=2e-4, atol=2e-4)
+
+
+def test_ins_criterion_golden(golden):
+    """Object-code loss (networks/evaluator.py:19-74): oracle == the reference's outputs and gradient, bit for bit."""
+    g = golden("ins_criterion")
+    for name in ("all", "some", "wide"):
+        ins_num = int(g[f"{name}_ins_num"])
+        pred = g[f"{name}_pred"].clone().requires_grad_(True)
+        out = O.ins_criterion(pred, g[f"{name}_lab"].long(), ins_num)
+        out[0].sum().backward()
+        got = torch.stack([t.detach().float().reshape(()) for t in out])
+        assert torch.equal(got, g[f"{name}_out"]), name
+        assert torch.equal(pred.grad, g[f"{name}_grad"]), name
+        cc, cs, valid = O.ins_cost_matrices(g[f"{name}_pred"], g[f"{name}_lab"].long(), ins_num)
+        assert torch.equal(cc[:valid], g[f"{name}_cost_ce"]) and torch.equal(cs[:valid], g[f"{name}_cost_siou"])
