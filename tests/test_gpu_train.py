@@ -84,7 +84,7 @@ def _oracle_mlp_grads(sd, rays_o, rays_d, z, cot):
 
 
 def test_mlp_backward_vs_autograd(A):
-    for N, S, ins_num, seed in ((8, 64, 13, 5), (3, 21, 13, 6), (4, 32, 59, 7)):
+    for N, S, ins_num, seed in ((8, 64, 13, 5), (3, 21, 13, 6), (4, 32, 59, 7), (5, 40, 93, 8)):
         sd = O.make_weights(seed, ins_num, gain=1.7)
         g = torch.Generator().manual_seed(seed)
         rays_o = torch.randn(N, 3, generator=g)
