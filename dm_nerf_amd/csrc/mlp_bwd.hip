@@ -41,8 +41,8 @@ __device__ __forceinline__ void zero(f32x16 (&v)[NB]) {
 }
 
 // Same LDS weight-streaming engine as the forward (mlp_common.h): the W^T stream is consumed one 64 KiB
-// quarter at a time, fetched one quarter ahead; the dy stores of a stage are issued in three batches
-// at the quarter boundaries of the NEXT stage (while dy is its B operand), always before the next DMA.
+// quarter at a time, fetched one quarter ahead; the dy stores of a stage ride in the MFMA gaps of quarters
+// 1..3 of the NEXT stage (while dy is its B operand), after that quarter's DMA pieces.
 template <int OBI>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 4 KiB]
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     const BlobTLayout& LT = a.LT;
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);
-    const int srows = 1;
+    const int srows = 1;                             // (every wave stores: see mlp_common.h::RowIO)
 
     // ---- oldest VMEM ops: incoming gradient, ReLU bit masks, table --------------------------------
     const float* __restrict__ gr = a.graw + m * (4 + L.C);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 
     const SaveLayout SL = make_save_layout(a.M);
     const int64_t MP = save_row_len(a.M);          // padded row length of the training workspace
-    const int srows = 1;
+    const int srows = 1;                           // (every wave stores: see mlp_common.h::RowIO)
     // ReLU bit masks for the backward pass (one 16-byte store per lane and layer instead of 128 row loads there)
     rsrc_t bits_rs;
     int bits_voff = 0;
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     float* __restrict__ out_row = a.raw + m * (4 + L.C);
 
     // One 256 -> 256 stage = 4 quarters.  Stage st consumes h_st (st = 0..7; st = 8 re-reads h_7): training
-    // saves it in three batches at the quarter boundaries, BEFORE the next DMA is issued, so that DMA
-    // stays older than them (see mlp_common.h).  The body is instantiated three times (trunk loop,
-    // rgb_feature, ins_feature) to keep the register live ranges of the two heads out of the loop.
+    // saves it with stores spread over the MFMA gaps of quarters 1..3, younger than each quarter's DMA pieces
+    // (see mlp_common.h).  The body is instantiated three times (trunk loop, rgb_feature, ins_feature) to keep
+    // the register live ranges of the two heads out of the loop.
     auto stage = [&](int st, auto next_ob, auto save_h) {   // next_ob: out-blocks of the quarter after the stage; save_h: store its input
         constexpr int NEXT = decltype(next_ob)::value;
         constexpr bool SAVE_H = SAVE && decltype(save_h)::value;
