@@ -32,7 +32,17 @@ struct BwdArgs {
     float* dsave;          // gradients, same SaveLayout (rows of pe/de unused)
     float* graw_t;         // optional: d raw in block-major form [blk][4+C][32] for the weight-gradient kernel
     int64_t M;
+#ifdef DMN_FWD_TRACE
+    long long* trace;      // diagnostic builds only (make diag): per-workgroup cycle stamps, see scripts/diag_fwd.py
+#endif
 };
+#ifdef DMN_FWD_TRACE
+static long long* g_bwd_trace = nullptr;
+extern "C" int dmnerf_debug_bwd_trace(long long* p) { g_bwd_trace = p; return 0; }
+#define DMN_STAMP(k) do { if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + (k)] = (long long)clock64(); } while (0)
+#else
+#define DMN_STAMP(k) do {} while (0)
+#endif
 
 template <int NB>
 __device__ __forceinline__ void zero(f32x16 (&v)[NB]) {
@@ -47,6 +57,7 @@ template <int OBI>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 4 KiB]
     float* const tab = lds + RING_FLOATS;
+    DMN_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     ws_init(ws, a.blobT, LT.total, lds, lane, wave, LT.stream);
     ws_fetch_first(ws);                                                   // quarter 0: ins_linear^T
 
+    DMN_STAMP(1);
     f32x16 d[8], acc[8];
     {
         // ---- ins branch: dg2 = relu'(g2) . (W_io^T g_ins);  dq = W_ih^T dg2 ----------------------
@@ -123,11 +135,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         ws_prime<4>(ws, lane);
         gemm_quarter<0, 4 * OBI, 4, 8, true>(ws, gi, t4, lane);
         apply_mask<4>(d4, g2bits, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane), d4);     // burst (once per block)
-        gemm_quarter<0, 8, 8, 8, true>(ws, d4, acc, lane);
-        gemm_quarter<8, 8, 8, 8>(ws, d4, acc, lane);
-        store_rows<8>(make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane), acc);      // dq (ins_feature has no activation)
+        // dg2 is saved while it is the B operand of the two quarters that produce dq (32 + 32 spread stores)
+        const RowIO g2io = make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane);
+        auto st_g2 = [&](int k0) { return [&, k0](int k) { store_row_one(g2io, d4, k0 + k); }; };
+        gemm_quarter<0, 8, 8, 8, true, 32>(ws, d4, acc, lane, st_g2(0));
+        gemm_quarter<8, 8, 8, 8, false, 32>(ws, d4, acc, lane, st_g2(32));
+        // acc = dq (ins_feature has no activation): saved under the rgb branch's two quarters below, which
+        // accumulate df directly into d
 
+        DMN_STAMP(2);
         // ---- rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU;  df = (W_rh^T dg1)[:256] ----
         zero<4>(t4);
 #pragma unroll
@@ -144,13 +160,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
             }
         }
         apply_mask<4>(d4, g1bits, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);
-        gemm_quarter<0, 8, 8, 8, true>(ws, d4, acc, lane);
-        gemm_quarter<8, 8, 8, 8>(ws, d4, acc, lane);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) d[b] = acc[b];                        // df (rgb_feature has no activation)
+        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);       // burst (once per block)
+        const RowIO qio = make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane);
+        auto st_q = [&](int k0) { return [&, k0](int k) { store_row_one(qio, acc, k0 + k); }; };
+        store_rows_part<126, 2>(qio, acc);
+        gemm_quarter<0, 8, 8, 8, true, 63>(ws, d4, d, lane, st_q(0));                     // df (rgb_feature has no activation)
+        gemm_quarter<8, 8, 8, 8, false, 63>(ws, d4, d, lane, st_q(63));
     }
 
+    DMN_STAMP(3);
     // ---- trunk: st = 0: dh_7 = W_rf^T df + w_d g_sigma;  st = k: dh_{7-k} = W_{8-k}^T dy_{8-k} -----
     // The stage's input d (df, then dy_7 .. dy_1) is saved while it is consumed.
 #pragma nounroll
@@ -185,7 +203,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         }
         apply_mask<8>(d, mb, acc);
     }
+    DMN_STAMP(4);
     store_rows<8>(make_rowio(a.dsave + SL.h, 256, srows * MP, blk, lane), d);             // dy_0
+    DMN_STAMP(5);
 }
 
 }  // namespace
@@ -199,6 +219,9 @@ extern "C" int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, i
     BwdArgs a{};
     a.blob = d_blob; a.blobT = d_blob_t; a.L = make_layout(ins_num); a.LT = make_layout_t(ins_num);
     a.save = d_save; a.graw = d_graw; a.dsave = d_dsave; a.graw_t = d_graw_t; a.M = M;
+#ifdef DMN_FWD_TRACE
+    a.trace = g_bwd_trace;
+#endif
     const int64_t nblk = (M + 31) / 32;
     dim3 g((unsigned)((nblk + 3) / 4)), b(256);
     constexpr size_t lds_bytes = (size_t)(RING_FLOATS + TAB_T_FLOATS) * sizeof(float);

@@ -204,12 +204,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
         f32x16 hid[4];
         init_bias_lds<4>(tab + L.b_rgbh, hid, half);
-        gemm_quarter<0, 16, 4, 4>(ws, acc, hid, lane);
-        if constexpr (SAVE) store_rows_part<0, 43>(fio, acc);
-        gemm_quarter<16, 16, 4, 4>(ws, acc, hid, lane);
-        if constexpr (SAVE) store_rows_part<43, 43>(fio, acc);
-        gemm_quarter<0, 4, 4, 8>(ws, de, hid, lane);
-        if constexpr (SAVE) store_rows_part<86, 42>(fio, acc);      // (with the g1 burst below: younger than the DMA in flight)
+        // training: rgb_feature (acc) is saved while it is this GEMM's B operand: 63 + 63 + 2 spread stores
+        auto st_f = [&](int k0) { return [&, k0](int k) { store_row_one(fio, acc, k0 + k); }; };
+        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_f(0));
+        gemm_quarter<16, 16, 4, 4, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_f(63));
+        gemm_quarter<0, 4, 4, 8, false, SAVE ? 2 : 0>(ws, de, hid, lane, st_f(126));
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
         if constexpr (SAVE) {
@@ -244,14 +243,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);
         f32x16 hid[4];
         init_bias_lds<4>(tab + L.b_insh, hid, half);
-        gemm_quarter<0, 16, 4, 4>(ws, acc, hid, lane);
-        if constexpr (SAVE) store_rows_part<0, 43>(qio, acc);
-        gemm_quarter<16, 16, 4, OBI>(ws, acc, hid, lane);
+        // training: ins_feature (acc) saved while it is the B operand (63 + 63), its last two registers and the first
+        // part of the hidden layer (g2) under the ins_linear quarter, the rest of g2 as one short burst
+        auto st_q = [&](int k0) { return [&, k0](int k) { store_row_one(qio, acc, k0 + k); }; };
+        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_q(0));
+        gemm_quarter<16, 16, 4, OBI, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_q(63));
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
+        constexpr int NS3 = SAVE ? (OBI == 1 ? 43 : 63) : 0;          // side slots of the ins_linear quarter
+        RowIO g2io;
         if constexpr (SAVE) {
-            store_rows_part<43, 85>(qio, acc);
-            store_rows<4>(make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane), hid);
+            g2io = make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane);
+            store_rows_part<NS3 - 2, 64 - (NS3 - 2)>(g2io, hid);
             unsigned m[2];
             pack_mask<4>(hid, m);
             __builtin_amdgcn_raw_buffer_store_b32(m[0], bits_rs, (int)((blk * BITS_WORDS_PER_BLOCK + 2176 + lane * 2) * 4), 0, 0);
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         }
         f32x16 io[OBI];
         init_bias_lds<OBI>(tab + L.b_inso, io, half);
-        gemm_quarter<0, 16, OBI, 0>(ws, hid, io, lane);               // ins_linear (:103); its fetch runs into the zero-filled landing zone
+        auto st_3 = [&](int k) { if (k < 2) store_row_one(qio, acc, 126 + k); else store_row_one(g2io, hid, k - 2); };
+        gemm_quarter<0, 16, OBI, 0, false, NS3>(ws, hid, io, lane, st_3);   // ins_linear (:103); its fetch runs into the zero-filled landing zone
         if (valid) {
 #pragma unroll
             for (int b = 0; b < OBI; ++b) {
@@ -355,5 +359,8 @@ extern "C" int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const
     MlpArgs a{};
     a.blob = d_blob; a.L = make_layout(ins_num); a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z;
     a.raw = d_raw; a.save = d_save; a.M = N * S; a.S = S;
+#ifdef DMN_FWD_TRACE
+    a.trace = g_fwd_trace;
+#endif
     return launch<false, true>(a, (hipStream_t)stream);
 }
