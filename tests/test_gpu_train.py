@@ -207,6 +207,55 @@ def test_adam_steps_follow_the_oracle_trajectory(A):
     assert got[2] < got[0]
 
 
+def test_full_training_recipe_follows_the_oracle(A):
+    """The complete loss of train_dmsr.py:33-64 -- img2mse + Hungarian-matched ins_criterion + ins_penalizer on both
+    levels -- for three Adam steps: device kernels vs the oracle (scipy assignment, PyTorch autograd)."""
+    from dm_nerf_amd.networks import evaluator as E
+    from dm_nerf_amd.networks import penalizer as P
+    ins_num, N = 13, 48
+    sd_c = O.make_weights(51, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(52, ins_num, gain=1.7, sigma_bias=0.3)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(40.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(5).choice(480 * 640, N, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous()
+    g = torch.Generator().manual_seed(53)
+    target = torch.rand(N, 3, generator=g)
+    labels = torch.randint(0, 6, (N,), generator=g)
+    tol, dw = 0.05, 0.05                                            # configs/dmsr/train/study.txt
+
+    def loss_dev(out, rays_d):
+        a = types.SimpleNamespace(tolerance=tol, deta_w=dw)
+        return E.img2mse(out['rgb_fine'], target.cuda()) + E.img2mse(out['rgb_coarse'], target.cuda()) \
+            + E.ins_criterion(out['ins_fine'], labels.cuda(), ins_num)[0] + E.ins_criterion(out['ins_coarse'], labels.cuda(), ins_num)[0] \
+            + P.ins_penalizer(out['raw_fine'], out['z_vals_fine'], out['depth_fine'], rays_d, a).sum() \
+            + P.ins_penalizer(out['raw_coarse'], out['z_vals_coarse'], out['depth_coarse'], rays_d, a).sum()
+
+    def loss_ora(o):
+        return ((o['rgb_fine'] - target) ** 2).mean() + ((o['rgb_coarse'] - target) ** 2).mean() \
+            + O.ins_criterion(o['ins_fine'], labels, ins_num)[0].sum() + O.ins_criterion(o['ins_coarse'], labels, ins_num)[0].sum() \
+            + O.ins_penalizer(o['raw_fine'], o['z_vals_fine'], o['depth_fine'], rays[1], tol, dw).sum() \
+            + O.ins_penalizer(o['raw_coarse'], o['z_vals_coarse'], o['depth_coarse'], rays[1], tol, dw).sum()
+
+    mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None)
+    sdc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    sdf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    opt_o = torch.optim.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4, betas=(0.9, 0.999))
+    got, want = [], []
+    for it in range(3):
+        out = A.R.dm_nerf(rays.cuda(), None, None, mc, mf, z.cuda(), args)
+        loss = loss_dev(out, rays[1].cuda())
+        opt.zero_grad(); loss.backward(); opt.step()
+        got.append(float(loss.detach()))
+        lo = loss_ora(O.dm_nerf(rays, sdc, sdf, z, perturb=0.))
+        opt_o.zero_grad(); lo.backward(); opt_o.step()
+        want.append(float(lo.detach()))
+    assert np.allclose(got, want, rtol=2e-3), (got, want)
+
+
 def test_penalizer_golden_value_and_gradient(A, golden):
     """fused emptiness penalizer vs the vectors produced by the reference's own ins_penalizer."""
     from dm_nerf_amd.networks import penalizer as P
