@@ -27,7 +27,7 @@ class RenderArgs(ctypes.Structure):
         ("d_z_coarse", c_vp), ("d_raw_coarse", c_vp), ("d_rgb_coarse", c_vp), ("d_depth_coarse", c_vp),
         ("d_ins_coarse", c_vp), ("d_z_fine", c_vp), ("d_raw_fine", c_vp), ("d_rgb_fine", c_vp),
         ("d_depth_fine", c_vp), ("d_ins_fine", c_vp), ("d_weights_ws", c_vp),
-        ("ev_fine_mlp_begin", c_vp), ("ev_fine_mlp_end", c_vp),
+        ("ev_fine_mlp_begin", c_vp), ("ev_fine_mlp_end", c_vp), ("fused_heads", c_int),
     ]
 
 
@@ -68,6 +68,9 @@ SIGNATURES = {
     "dmnerf_wgrad_plan": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_set_trace": (c_int, [c_vp]),
+    "dmnerf_blob_fused_floats": (c_i64, [c_int]),
+    "dmnerf_build_pack_index_fused": (c_int, [c_int, c_vp, c_i64]),
+    "dmnerf_mlp_fwd_rays_fused": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_ins_criterion_work_bytes": (c_i64, [c_i64, c_int]),
     "dmnerf_ins_criterion_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_ins_criterion_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -90,7 +93,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 1:
+    if lib.dmnerf_abi_version() != 2:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

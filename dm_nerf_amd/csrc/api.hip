@@ -58,14 +58,15 @@ extern "C" int dmnerf_render_rays_fwd(const dmnerf_render_args* a, void* stream)
             return dmn_check_launch("render_rays_fwd: z copy");
     }
     // coarse network + compositing (render.py:49-63)
-    if ((rc = dmnerf_mlp_fwd_rays(a->d_blob_coarse, a->ins_num, a->d_rays_o, a->d_rays_d, a->d_z_coarse, N, S, a->d_raw_coarse, stream))) return rc;
+    auto mlp = a->fused_heads ? dmnerf_mlp_fwd_rays_fused : dmnerf_mlp_fwd_rays;
+    if ((rc = mlp(a->d_blob_coarse, a->ins_num, a->d_rays_o, a->d_rays_d, a->d_z_coarse, N, S, a->d_raw_coarse, stream))) return rc;
     if ((rc = dmnerf_composite_fwd(a->d_raw_coarse, a->d_z_coarse, a->d_rays_d, N, S, C, a->d_rgb_coarse, a->d_weights_ws,
                                    a->d_depth_coarse, a->d_ins_coarse, stream))) return rc;
     // hierarchical resampling + merge (render.py:66-70)
     if ((rc = dmnerf_importance_resample(a->d_z_coarse, a->d_weights_ws, a->d_u, a->u_row_stride, N, S, a->n_imp, a->d_z_fine, nullptr, stream))) return rc;
     // fine network + compositing (render.py:71-86)
     if (a->ev_fine_mlp_begin) (void)hipEventRecord((hipEvent_t)a->ev_fine_mlp_begin, (hipStream_t)stream);
-    if ((rc = dmnerf_mlp_fwd_rays(a->d_blob_fine, a->ins_num, a->d_rays_o, a->d_rays_d, a->d_z_fine, N, SF, a->d_raw_fine, stream))) return rc;
+    if ((rc = mlp(a->d_blob_fine, a->ins_num, a->d_rays_o, a->d_rays_d, a->d_z_fine, N, SF, a->d_raw_fine, stream))) return rc;
     if (a->ev_fine_mlp_end) (void)hipEventRecord((hipEvent_t)a->ev_fine_mlp_end, (hipStream_t)stream);
     if ((rc = dmnerf_composite_fwd(a->d_raw_fine, a->d_z_fine, a->d_rays_d, N, SF, C, a->d_rgb_fine, a->d_weights_ws,
                                    a->d_depth_fine, a->d_ins_fine, stream))) return rc;

@@ -86,7 +86,9 @@ DMN_HD inline int64_t stage_off(const BlobLayout& L, int st) {
     return st < 5 ? L.w_stage_lo + st * seg_floats(32, 8) : (st < 8 ? L.w_stage_mid + (st - 5) * seg_floats(32, 8) : L.w_stage_hi);
 }
 
-DMN_HD inline BlobLayout make_layout(int ins_num) {
+// fused = the inference-only blob with rgb_feature_linear / ins_feature_linear folded into the hidden layers that
+// follow them (no activation in between, dm_nerf.py:89,96): the stream simply has no st7 / st8 quarters.
+DMN_HD inline BlobLayout make_layout(int ins_num, bool fused = false) {
     BlobLayout L;
     L.C = ins_num + 1;
     L.OBI = (L.C + 31) / 32;
@@ -105,10 +107,10 @@ DMN_HD inline BlobLayout make_layout(int ins_num) {
     L.w0 = o; o += QUARTER_FLOATS;
     L.w_stage_lo = o; o += 5 * seg_floats(32, 8);
     L.w5pe = o; o += QUARTER_FLOATS;
-    L.w_stage_mid = o; o += 3 * seg_floats(32, 8);
+    L.w_stage_mid = o; o += (fused ? 2 : 3) * seg_floats(32, 8);
     L.w_rgbh = o; o += seg_floats(32, 4);
     L.w_rgbh_dir = o; o += QUARTER_FLOATS;
-    L.w_stage_hi = o; o += seg_floats(32, 8);
+    L.w_stage_hi = o; o += fused ? 0 : seg_floats(32, 8);
     L.w_insh = o; o += seg_floats(32, 4);
     L.w_inso = o; o += QUARTER_FLOATS;
     o += 2 * QUARTER_FLOATS;            // the DMA engine always runs two quarters ahead: zero-filled landing zone

@@ -50,8 +50,9 @@ struct MlpArgs {
 #define DMN_STAMP(k) do {} while (0)
 #endif
 
-template <int OBI, bool EMBEDDED, bool SAVE>
+template <int OBI, bool EMBEDDED, bool SAVE, bool FUSED = false>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
+    static_assert(!(FUSED && SAVE), "the fused-heads blob is inference-only");
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 16 KiB]
     float* const tab = lds + RING_FLOATS;
     DMN_STAMP(0);
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 
     DMN_STAMP(3);
     // ---- rgb branch: acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
-    stage(7, Next4{}, std::true_type{});
+    // FUSED: rgb_feature_linear is folded into rgb_feature_linears.0 (blob built by the caller): h feeds the hidden layer directly
+    if constexpr (!FUSED) stage(7, Next4{}, std::true_type{});
     {
         RowIO fio;
         if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
@@ -209,8 +211,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         init_bias_lds<4>(tab + L.b_rgbh, hid, half);
         // training: rgb_feature (acc) is saved while it is this GEMM's B operand: 63 + 63 + 2 spread stores
         auto st_f = [&](int k0) { return [&, k0](int k) { store_row_one(fio, acc, k0 + k); }; };
-        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_f(0));
-        gemm_quarter<16, 16, 4, 4, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_f(63));
+        auto& fsrc = *(FUSED ? &h : &acc);                             // the hidden layer's input: rgb_feature, or h itself when fused
+        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, fsrc, hid, lane, st_f(0));
+        gemm_quarter<16, 16, 4, 4, false, SAVE ? 63 : 0>(ws, fsrc, hid, lane, st_f(63));
         gemm_quarter<0, 4, 4, 8, false, SAVE ? 2 : 0>(ws, de, hid, lane, st_f(126));
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
 
     // ---- ins branch: acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
-    stage(8, Next4{}, std::false_type{});          // re-reads h_7: already saved
+    if constexpr (!FUSED) stage(8, Next4{}, std::false_type{});          // re-reads h_7: already saved
     {
         RowIO qio;
         if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);
@@ -249,8 +252,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         // training: ins_feature (acc) saved while it is the B operand (63 + 63), its last two registers and the first
         // part of the hidden layer (g2) under the ins_linear quarter, the rest of g2 as one short burst
         auto st_q = [&](int k0) { return [&, k0](int k) { store_row_one(qio, acc, k0 + k); }; };
-        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_q(0));
-        gemm_quarter<16, 16, 4, OBI, false, SAVE ? 63 : 0>(ws, acc, hid, lane, st_q(63));
+        auto& qsrc = *(FUSED ? &h : &acc);
+        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, qsrc, hid, lane, st_q(0));
+        gemm_quarter<16, 16, 4, OBI, false, SAVE ? 63 : 0>(ws, qsrc, hid, lane, st_q(63));
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
         constexpr int NS3 = SAVE ? (OBI == 1 ? 43 : 63) : 0;          // side slots of the ins_linear quarter
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     DMN_STAMP(5);
 }
 
-template <bool EMBEDDED, bool SAVE>
+template <bool EMBEDDED, bool SAVE, bool FUSED = false>
 int launch(const MlpArgs& a, hipStream_t stream) {
     const int64_t nblk = (a.M + 31) / 32;
     const int64_t grid = (nblk + 3) / 4;
@@ -303,12 +307,12 @@ int launch(const MlpArgs& a, hipStream_t stream) {
     {                                                                                                                \
         static bool attr_done = false;                                                                               \
         if (!attr_done) {                                                                                            \
-            if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<OBI_, EMBEDDED, SAVE>,                                \
+            if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>,                                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)       \
                 return dmn_check_launch("mlp_fwd: hipFuncSetAttribute");                                             \
             attr_done = true;                                                                                        \
         }                                                                                                            \
-        hipLaunchKernelGGL((mlp_fwd_kernel<OBI_, EMBEDDED, SAVE>), g, b, lds_bytes, stream, a);                       \
+        hipLaunchKernelGGL((mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>), g, b, lds_bytes, stream, a);                       \
     }
     switch (a.L.OBI) {
         case 1: DMN_LAUNCH(1) break;

@@ -97,10 +97,10 @@ extern "C" int64_t dmnerf_blob_floats(int ins_num) {
     return make_layout(ins_num).total;
 }
 
-extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx) {
+static int build_pack_index(int ins_num, int32_t* idx, int64_t n_idx, bool fused) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS)
         return dmn_fail(DMNERF_E_ARG, "build_pack_index: ins_num %d outside [1,%d]", ins_num, DMNERF_MAX_LOGITS - 1);
-    const BlobLayout L = make_layout(ins_num);
+    const BlobLayout L = make_layout(ins_num, fused);
     if (!idx || n_idx != L.total)
         return dmn_fail(DMNERF_E_ARG, "build_pack_index: need %lld index slots, got %lld", (long long)L.total, (long long)n_idx);
     const Params P = make_params(ins_num);
@@ -109,9 +109,10 @@ extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx)
     fill_seg(idx, L.w0, P.mlps[0], 8, 8, K_POS, 0);
     fill_bias(idx, L.b0, P.mlps[0], 8);
     // the nine 256->256 stages: L1..L4, L5 (h columns 0..255), L6, L7, rgb_feature, ins_feature
+    // (fused: the last two are folded into rgb_hidden / ins_hidden by the caller and have no segment)
     const Lin* stage[NSTAGE] = {&P.mlps[1], &P.mlps[2], &P.mlps[3], &P.mlps[4], &P.mlps[5],
                                 &P.mlps[6], &P.mlps[7], &P.rgb_feature, &P.ins_feature};
-    for (int s = 0; s < NSTAGE; ++s) {
+    for (int s = 0; s < (fused ? NSTAGE - 2 : NSTAGE); ++s) {
         fill_seg(idx, stage_off(L, s), *stage[s], 32, 8, K_ACC, 0);
         fill_bias(idx, L.b_stage + s * bias_floats(8), *stage[s], 8);
     }
@@ -133,6 +134,14 @@ extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx)
     for (int c = 0; c < 3; ++c) idx[L.b_rgbo + c] = (int32_t)P.rgb_out.b(c);
     return DMNERF_OK;
 }
+
+extern "C" int dmnerf_build_pack_index(int ins_num, int32_t* idx, int64_t n_idx) { return build_pack_index(ins_num, idx, n_idx, false); }
+
+extern "C" int64_t dmnerf_blob_fused_floats(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_layout(ins_num, true).total;
+}
+extern "C" int dmnerf_build_pack_index_fused(int ins_num, int32_t* idx, int64_t n_idx) { return build_pack_index(ins_num, idx, n_idx, true); }
 
 extern "C" int64_t dmnerf_blob_t_floats(int ins_num) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;

@@ -100,6 +100,17 @@ class DM_NeRF(nn.Module):
             self._blob_key = key
         return self._blob
 
+    def blob_fused(self):
+        """Inference blob with ``rgb_feature_linear`` / ``ins_feature_linear`` folded into the hidden layers
+        (``dm_nerf(..., args)`` with ``args.fuse_heads = True``; same refresh rule as ``blob``)."""
+        self._check_supported()
+        state = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in state.values())
+        if getattr(self, "_blob_f", None) is None or key != self._blob_f_key:
+            self._blob_f = weights.pack_blob(state, self.ins_num, fused=True)
+            self._blob_f_key = key
+        return self._blob_f
+
     def blob_t(self):
         """W^T blob for the backward data-gradient kernel (same refresh rule as ``blob``)."""
         self._check_supported()

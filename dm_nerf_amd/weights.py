@@ -37,12 +37,40 @@ def pack_index_t_host(ins_num):
     return idx
 
 
-def pack_index(ins_num, device, transposed=False):
-    key = (ins_num, str(device), transposed)
+def pack_index_fused_host(ins_num):
+    """Gather index of the fused-heads inference blob."""
+    lib = _lib.load()
+    n = lib.dmnerf_blob_fused_floats(ins_num)
+    if n <= 0:
+        raise ValueError(f"unsupported ins_num={ins_num}")
+    idx = np.empty(n, dtype=np.int32)
+    _lib.check(lib.dmnerf_build_pack_index_fused(ins_num, idx.ctypes.data_as(ctypes.c_void_p), n), "dmnerf_build_pack_index_fused")
+    return idx
+
+
+def pack_index(ins_num, device, transposed=False, fused=False):
+    key = (ins_num, str(device), transposed, fused)
     if key not in _index_cache:
-        host = pack_index_t_host(ins_num) if transposed else pack_index_host(ins_num)
+        host = pack_index_t_host(ins_num) if transposed else (pack_index_fused_host(ins_num) if fused else pack_index_host(ins_num))
         _index_cache[key] = torch.from_numpy(host).to(device)
     return _index_cache[key]
+
+
+def fuse_heads(state):
+    """Fold the activation-free ``rgb_feature_linear`` / ``ins_feature_linear`` (dm_nerf.py:89,96) into the hidden
+    layers that consume them: a copy of ``state`` whose ``rgb_feature_linears.0`` / ``ins_feature_linears.0`` hold
+    ``W_hidden[:, :256] @ W_feature`` (products formed in float64, rounded once) and the matching biases.
+    Inference only: the result is the same function up to f32 re-association."""
+    st = {k: v.detach() for k, v in state.items()}
+    for feat, hid in (("rgb_feature_linear", "rgb_feature_linears.0"), ("ins_feature_linear", "ins_feature_linears.0")):
+        Wf, bf = st[feat + ".weight"].double(), st[feat + ".bias"].double()
+        Wh, bh = st[hid + ".weight"].double(), st[hid + ".bias"].double()
+        n_in = Wf.shape[0]                                         # 256 feature columns (then the 27 dir columns, rgb only)
+        Wn = Wh.clone()
+        Wn[:, :n_in] = Wh[:, :n_in] @ Wf
+        st[hid + ".weight"] = Wn.float()
+        st[hid + ".bias"] = (Wh[:, :n_in] @ bf + bh).float()
+    return st
 
 
 def flat_params(state):
@@ -50,16 +78,17 @@ def flat_params(state):
     return torch.cat([state[k].detach().reshape(-1).float() for k in PARAM_KEYS])
 
 
-def pack_blob(state, ins_num, out=None, transposed=False):
+def pack_blob(state, ins_num, out=None, transposed=False, fused=False):
     """Build (or refresh in place) the kernel blob for one DM_NeRF model (``transposed``: the W^T
-    blob of the backward data-gradient kernel)."""
+    blob of the backward data-gradient kernel; ``fused``: the inference blob with the feature linears folded
+    into the hidden layers)."""
     lib = _lib.load()
-    flat = flat_params(state)
+    flat = flat_params(fuse_heads(state) if fused else state)
     if flat.numel() != lib.dmnerf_param_count(ins_num):
         raise ValueError(f"parameter count {flat.numel()} != {lib.dmnerf_param_count(ins_num)} "
                          f"(only D=8, W=256, skips=[4], 63+27 input channels are supported)")
     _lib.require_gpu(flat)
-    idx = pack_index(ins_num, flat.device, transposed)
+    idx = pack_index(ins_num, flat.device, transposed, fused)
     n = idx.numel()
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=flat.device)

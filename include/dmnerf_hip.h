@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 1
+#define DMNERF_ABI_VERSION 2
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -173,6 +173,19 @@ int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const floa
  * Used by scripts/diag_wgrad.py to fit the split-K cost model. */
 int dmnerf_wgrad_set_trace(int64_t* d_ticks);
 
+/* ---- inference-only algebraic fusion (opt-in) -------------------------------------------
+ * rgb_feature_linear and ins_feature_linear have no activation (dm_nerf.py:89,96), so for inference they can be
+ * folded into the hidden layers that consume them: W' = W_hidden[:, :256] . W_feature, b' = W_hidden[:, :256] .
+ * b_feature + b_hidden (the caller forms them, e.g. in float64, and writes them over the rgb_feature_linears.0 /
+ * ins_feature_linears.0 slots of a copy of the flat parameter vector).  The fused blob has the same table and the
+ * same stream without the two 256x256 stages (36 quarters instead of 44: -18.9 % MACs at ins_num 13).  Results
+ * differ from the layer-by-layer evaluation by f32 re-association only (|d raw| ~ 1e-6), hence opt-in.           */
+int64_t dmnerf_blob_fused_floats(int ins_num);
+int dmnerf_build_pack_index_fused(int ins_num, int32_t* h_idx, int64_t n_idx);
+int dmnerf_mlp_fwd_rays_fused(const float* d_blob_fused, int ins_num, const float* d_rays_o,
+                              const float* d_rays_d, const float* d_z, int64_t N, int S,
+                              float* d_raw, void* stream);
+
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
  * (int32, values 0..ins_num; other values are ignored) -> out4 = {ins_loss_sum, valid_ce, invalid_ce,
@@ -250,6 +263,8 @@ typedef struct {
      * kernel), so a caller can time it live without splitting the call; NULL = not recorded */
     void* ev_fine_mlp_begin;
     void* ev_fine_mlp_end;
+    /* 1: d_blob_coarse / d_blob_fine are fused-heads blobs (dmnerf_build_pack_index_fused), see below */
+    int fused_heads;
 } dmnerf_render_args;
 int dmnerf_render_rays_fwd(const dmnerf_render_args* args, void* stream);
 
