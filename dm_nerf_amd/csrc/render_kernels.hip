@@ -217,10 +217,18 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
         const bool act = g < NG && c != 3 && (c < 3 || c - 4 < n_ins);
         double acc = 0.0;
         if (act) {
-            if (c < 3) {
-                for (int s = g; s < S; s += NG) acc += (double)(wl[s] * sigmoidf_ref(rr[(int64_t)s * ch + c]));
-            } else {
-                for (int s = g; s < S; s += NG) acc += (double)(wl[s] * rr[(int64_t)s * ch + c]);
+            // 4 samples per trip: the four loads are issued together (the loop is latency-bound otherwise)
+            for (int s = g; s < S; s += 4 * NG) {
+                float v[4], wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int su = s + u * NG;
+                    const bool in = su < S;
+                    v[u] = in ? rr[(int64_t)su * ch + c] : 0.f;
+                    wv[u] = in ? wl[su] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += (double)(wv[u] * (c < 3 ? sigmoidf_ref(v[u]) : v[u]));
             }
         }
         double tot = 0.0;
