@@ -110,12 +110,13 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
             "batch_rays": N_RAYS, "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"}
 
 
-def fused_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref):
-    """Not the headline: the same render step with the opt-in inference-only fusion of the activation-free
-    rgb_feature_linear / ins_feature_linear into the hidden layers (562 432 instead of 693 504 MAC per
-    sample, results equal up to f32 re-association)."""
+def fused_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref, split=False):
+    """Not the headline: the same render step with an opt-in inference mode.  split=False: the activation-free
+    rgb_feature_linear / ins_feature_linear folded into the hidden layers (562 432 instead of 693 504
+    MAC per sample, results equal up to f32 re-association).  split=True: additionally the GEMMs on the bf16 MFMA with
+    every f32 operand split into three bf16 planes and six products per term (f32-class accuracy, csrc/mlp_split.hip)."""
     from dm_nerf_amd.networks import render as R
-    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, fuse_heads=True)
+    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, fuse_heads=True, mfma_split=split)
     n_chunks = ro.shape[0] // N_RAYS
     with torch.no_grad():
         for i in range(2):
@@ -129,7 +130,9 @@ def fused_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref):
         dt = (time.perf_counter() - t0) / steps
     d = float((out['rgb_fine'] - rgb_ref).abs().max())          # same last chunk as the headline loop
     return {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "mac_per_sample": 562432,
-            "max_abs_rgb_diff_vs_layerwise": d, "note": "opt-in (args.fuse_heads), not the headline metric"}
+            "max_abs_rgb_diff_vs_layerwise": d,
+            "note": ("opt-in (args.mfma_split): fused heads + split-bf16 MFMA, six bf16 products per f32 product" if split
+                     else "opt-in (args.fuse_heads)") + ", not the headline metric"}
 
 
 def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
@@ -246,6 +249,7 @@ def main():
             res["speedup_vs_cpu"] = rays_per_s / base["value"]
         if world == 1:
             res["render_fused_heads"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'])
+            res["render_split_bf16"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], split=True)
         if world == 1 and not a.no_train:
             res["train"] = train_leg(mc, mf, ro, rd, z, a.train_steps, dev)
         print(json.dumps(res), flush=True)

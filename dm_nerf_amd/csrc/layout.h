@@ -118,6 +118,46 @@ DMN_HD inline BlobLayout make_layout(int ins_num, bool fused = false) {
     return L;
 }
 
+// ---- split-bf16 ("bf16x3") inference blob (opt-in; mlp_split.hip) -----------------------------------------
+// v_mfma_f32_32x32x16_bf16: A[i][k]: lane l holds row i = l & 31 and the 8 k-slots 8 (l >> 5) + q, q = 0..7;
+// B likewise with col j = l & 31; C as for the f32 MFMA.  A lane's 8 accumulator registers r = 8 t + q of
+// out-block b are therefore exactly its 8 k-slots of k-block kb = 2 b + t of the next layer: slot 8 h + q of
+// k-block kb <-> k-pair p = 8 kb + q of the f32 kernel (cfeat(p, h) / pefeat(p, h, L)).
+// Every f32 weight w is split by truncation into three bf16 planes, w = hi + mid + lo exactly.  The stream is cut
+// into SLOTS of 48 KiB = 48 tiles of 1 KiB; tile (k-block, plane, out-block) = 64 lanes x 8 bf16:
+//   slot[(((kb_in_slot * 3 + plane) * OB + ob) * 64 + lane) * 8 + q] = plane(W[32 ob + (lane & 31)][col(8 kb + q, lane >> 5)])
+// a slot holds 16 / OB k-blocks (OB in {8, 4, 2, 1}); segments in consumption order:
+//   mlps.0 (4 kb) | L1..L4 (16 kb each) | L5 h part (16) | L5 pe part (4) | L6 | L7 | rgb hidden' (16, OB 4) | dirs (2, OB 4) |
+//   ins hidden' (16, OB 4) | ins_linear (8, OB 1/2/4)          (' = feature linear folded in, weights.py::fuse_heads)
+// The table (biases, VALU heads) is the f32 blob's, unchanged.
+constexpr int SPLIT_SLOT_WORDS = 12288;          // 48 KiB
+constexpr int SPLIT_TILES_PER_SLOT = 48;
+DMN_HD constexpr int split_kb_per_slot(int ob) { return 16 / ob; }
+DMN_HD constexpr int split_slots(int nkb, int ob) { return (nkb + split_kb_per_slot(ob) - 1) / split_kb_per_slot(ob); }
+DMN_HD constexpr int split_ob_ins(int obi) { return obi == 3 ? 4 : obi; }
+struct SplitLayout {
+    int C, OBI, OBX;              // logits, logit blocks, out-blocks used for the ins_linear segment (1, 2 or 4)
+    int s_w0, s_trunk, s_l5pe, s_l6, s_rgbh, s_dirs, s_insh, s_inso, n_slots;   // first slot of each segment
+    int64_t stream, total;        // word offsets: stream start (= TAB_FLOATS), total words (incl. 2 landing slots)
+};
+DMN_HD inline SplitLayout make_split_layout(int ins_num) {
+    SplitLayout S{};
+    S.C = ins_num + 1; S.OBI = (S.C + 31) / 32; S.OBX = split_ob_ins(S.OBI);
+    int o = 0;
+    S.s_w0 = o; o += split_slots(4, 8);
+    S.s_trunk = o; o += 5 * split_slots(16, 8);       // L1..L4, L5 (h columns)
+    S.s_l5pe = o; o += split_slots(4, 8);
+    S.s_l6 = o; o += 2 * split_slots(16, 8);          // L6, L7
+    S.s_rgbh = o; o += split_slots(16, 4);
+    S.s_dirs = o; o += split_slots(2, 4);
+    S.s_insh = o; o += split_slots(16, 4);
+    S.s_inso = o; o += split_slots(8, S.OBX);
+    S.n_slots = o;
+    S.stream = TAB_FLOATS;
+    S.total = S.stream + (int64_t)(o + 2) * SPLIT_SLOT_WORDS;
+    return S;
+}
+
 // Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
 //   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
 constexpr int NSTAGE_T = 8;   // rgb_feature^T, mlps.7^T .. mlps.1^T (mlps.5: its 256 h-columns)

@@ -313,6 +313,7 @@ __device__ __forceinline__ void ws_prime(WStream& ws, int lane) {
         constexpr int ob = decltype(ic)::value;
         lds_read16_async<ob * 1024>(ws.pre[ob], s0);
     });
+    lds_wait<0>(ws.pre);          // (once per workgroup; see the end of gemm_quarter)
 }
 
 // One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
@@ -361,6 +362,10 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
             __builtin_amdgcn_sched_barrier(0);
         });
     });
+    // ws.pre was written by inline-asm reads the compiler believes to be synchronous: turn it into real values before
+    // the caller's code between two quarters (epilogues, stores) gives the register allocator a reason to move it
+    // (the reads were issued at the start of the last k-group, >= 4 OB MFMAs ago: this wait is free)
+    if constexpr (NEXT_OB > 0) lds_wait<0>(ws.pre);
     ws.off += QUARTER_FLOATS * 4;
     ws.cslot ^= 1;
 }

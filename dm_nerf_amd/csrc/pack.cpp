@@ -143,6 +143,46 @@ extern "C" int64_t dmnerf_blob_fused_floats(int ins_num) {
 }
 extern "C" int dmnerf_build_pack_index_fused(int ins_num, int32_t* idx, int64_t n_idx) { return build_pack_index(ins_num, idx, n_idx, true); }
 
+// ---- split-bf16 blob (layout.h::SplitLayout): one int32 per bf16 element = source parameter | plane << 28, or -1
+static void fill_split_seg(int32_t* idx, int slot0, const Lin& l, int nkb, int ob_n, KMap km, int col_off) {
+    const int kps = split_kb_per_slot(ob_n);
+    for (int kb = 0; kb < nkb; ++kb)
+        for (int plane = 0; plane < 3; ++plane)
+            for (int ob = 0; ob < ob_n; ++ob)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 8; ++q) {
+                        const int col = kcol(km, 8 * kb + q, lane >> 5);
+                        const int64_t src = col < 0 ? -1 : l.w(ob * 32 + (lane & 31), col + col_off);
+                        const int64_t e = ((int64_t)(slot0 + kb / kps) * SPLIT_TILES_PER_SLOT + ((kb % kps) * 3 + plane) * ob_n + ob) * 512 + lane * 8 + q;
+                        idx[e] = src < 0 ? -1 : (int32_t)(src | ((int64_t)plane << 28));
+                    }
+}
+
+extern "C" int64_t dmnerf_blob_split_words(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_split_layout(ins_num).total;
+}
+
+extern "C" int dmnerf_build_pack_index_split(int ins_num, int32_t* idx, int64_t n_idx) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "build_pack_index_split: ins_num %d unsupported", ins_num);
+    const SplitLayout S = make_split_layout(ins_num);
+    const int64_t need = (S.total - S.stream) * 2;                  // bf16 elements of the stream (incl. landing slots)
+    if (!idx || n_idx != need) return dmn_fail(DMNERF_E_ARG, "build_pack_index_split: need %lld index slots, got %lld", (long long)need, (long long)n_idx);
+    const Params P = make_params(ins_num);
+    for (int64_t i = 0; i < need; ++i) idx[i] = -1;
+    fill_split_seg(idx, S.s_w0, P.mlps[0], 4, 8, K_POS, 0);
+    const Lin* trunk[5] = {&P.mlps[1], &P.mlps[2], &P.mlps[3], &P.mlps[4], &P.mlps[5]};
+    for (int s = 0; s < 5; ++s) fill_split_seg(idx, S.s_trunk + s * split_slots(16, 8), *trunk[s], 16, 8, K_ACC, 0);
+    fill_split_seg(idx, S.s_l5pe, P.mlps[5], 4, 8, K_POS, W);
+    fill_split_seg(idx, S.s_l6, P.mlps[6], 16, 8, K_ACC, 0);
+    fill_split_seg(idx, S.s_l6 + split_slots(16, 8), P.mlps[7], 16, 8, K_ACC, 0);
+    fill_split_seg(idx, S.s_rgbh, P.rgb_hidden, 16, 4, K_ACC, 0);      // (fused with rgb_feature_linear by the caller)
+    fill_split_seg(idx, S.s_dirs, P.rgb_hidden, 2, 4, K_DIR, W);
+    fill_split_seg(idx, S.s_insh, P.ins_hidden, 16, 4, K_ACC, 0);      // (fused with ins_feature_linear)
+    fill_split_seg(idx, S.s_inso, P.ins_out, 8, S.OBX, K_ACC, 0);
+    return DMNERF_OK;
+}
+
 extern "C" int64_t dmnerf_blob_t_floats(int ins_num) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
     return make_layout_t(ins_num).total;

@@ -111,6 +111,16 @@ class DM_NeRF(nn.Module):
             self._blob_f_key = key
         return self._blob_f
 
+    def blob_split(self):
+        """Split-bf16 inference blob (``args.mfma_split``; same refresh rule as ``blob``)."""
+        self._check_supported()
+        state = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in state.values())
+        if getattr(self, "_blob_s", None) is None or key != self._blob_s_key:
+            self._blob_s = weights.pack_blob_split(state, self.ins_num)
+            self._blob_s_key = key
+        return self._blob_s
+
     def blob_t(self):
         """W^T blob for the backward data-gradient kernel (same refresh rule as ``blob``)."""
         self._check_supported()

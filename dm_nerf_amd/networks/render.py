@@ -96,10 +96,13 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     a = _lib.RenderArgs()
     # args.fuse_heads (extension, default off): inference with the activation-free feature linears folded into the
     # hidden layers (-19 % MACs; results equal up to f32 re-association)
+    # args.mfma_split (extension, default off): split-bf16 MFMA inference (f32-class accuracy, not bitwise the f32 chain)
     fused = bool(getattr(args, "fuse_heads", False))
-    a.fused_heads = 1 if fused else 0
-    a.d_blob_coarse = (model_coarse.blob_fused() if fused else model_coarse.blob()).data_ptr()
-    a.d_blob_fine = (model_fine.blob_fused() if fused else model_fine.blob()).data_ptr()
+    split = bool(getattr(args, "mfma_split", False))
+    a.fused_heads = 2 if split else (1 if fused else 0)
+    pick = (lambda mdl: mdl.blob_split()) if split else ((lambda mdl: mdl.blob_fused()) if fused else (lambda mdl: mdl.blob()))
+    a.d_blob_coarse = pick(model_coarse).data_ptr()
+    a.d_blob_fine = pick(model_fine).data_ptr()
     a.ins_num = ins_num
     a.d_rays_o, a.d_rays_d, a.d_z_in = rays_o.data_ptr(), rays_d.data_ptr(), z_in.data_ptr()
     a.d_t_rand = t_rand.data_ptr() if t_rand is not None else None

@@ -78,6 +78,29 @@ def flat_params(state):
     return torch.cat([state[k].detach().reshape(-1).float() for k in PARAM_KEYS])
 
 
+def pack_blob_split(state, ins_num):
+    """The opt-in split-bf16 inference blob: [table of the fused f32 blob | three bf16 planes of every weight]."""
+    lib = _lib.load()
+    flat = flat_params(fuse_heads(state))
+    _lib.require_gpu(flat)
+    total = lib.dmnerf_blob_split_words(ins_num)
+    if total <= 0:
+        raise ValueError(f"unsupported ins_num={ins_num}")
+    tab = 4096
+    key = (ins_num, str(flat.device), "split")
+    if key not in _index_cache:
+        n = (total - tab) * 2
+        host = np.empty(n, dtype=np.int32)
+        _lib.check(lib.dmnerf_build_pack_index_split(ins_num, host.ctypes.data_as(ctypes.c_void_p), n), "dmnerf_build_pack_index_split")
+        _index_cache[key] = torch.from_numpy(host).to(flat.device)
+    idx = _index_cache[key]
+    blob = torch.empty(total, dtype=torch.float32, device=flat.device)
+    idx_tab = pack_index(ins_num, flat.device, False, True)[:tab].contiguous()
+    _lib.check(lib.dmnerf_pack_weights(_lib.ptr(flat), _lib.ptr(idx_tab), _lib.ptr(blob), tab, _lib.stream()), "dmnerf_pack_weights")
+    _lib.check(lib.dmnerf_pack_split(_lib.ptr(flat), _lib.ptr(idx), _lib.ptr(blob[tab:]), total - tab, _lib.stream()), "dmnerf_pack_split")
+    return blob
+
+
 def pack_blob(state, ins_num, out=None, transposed=False, fused=False):
     """Build (or refresh in place) the kernel blob for one DM_NeRF model (``transposed``: the W^T
     blob of the backward data-gradient kernel; ``fused``: the inference blob with the feature linears folded

@@ -186,6 +186,19 @@ int dmnerf_mlp_fwd_rays_fused(const float* d_blob_fused, int ins_num, const floa
                               const float* d_rays_d, const float* d_z, int64_t N, int S,
                               float* d_raw, void* stream);
 
+/* ---- opt-in split-bf16 ("bf16x3") inference -----------------------------------------
+ * The MLP on v_mfma_f32_32x32x16_bf16 with every f32 operand split by truncation into three bf16 planes
+ * (x = hi + mid + lo exactly) and the six leading products accumulated in f32: the rounding class of an f32 GEMM
+ * at 2.7x fewer MFMA cycles; not the bitwise fmaf chain of dmnerf_mlp_fwd_rays, hence opt-in.  The blob is
+ * [the fused blob's 4096-float table | split stream]: dmnerf_build_pack_index_split gives one int32 per bf16
+ * element of the stream (source parameter | plane << 28, -1 = zero) over the FUSED flat parameter vector
+ * (see above), dmnerf_pack_split writes the stream words (n_words = dmnerf_blob_split_words - 4096).          */
+int64_t dmnerf_blob_split_words(int ins_num);
+int dmnerf_build_pack_index_split(int ins_num, int32_t* h_idx, int64_t n_idx);
+int dmnerf_pack_split(const float* d_flat, const int32_t* d_idx, float* d_stream_words, int64_t n_words, void* stream);
+int dmnerf_mlp_fwd_rays_split(const float* d_blob_split, int ins_num, const float* d_rays_o, const float* d_rays_d,
+                              const float* d_z, int64_t N, int S, float* d_raw, void* stream);
+
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
  * (int32, values 0..ins_num; other values are ignored) -> out4 = {ins_loss_sum, valid_ce, invalid_ce,
@@ -263,7 +276,7 @@ typedef struct {
      * kernel), so a caller can time it live without splitting the call; NULL = not recorded */
     void* ev_fine_mlp_begin;
     void* ev_fine_mlp_end;
-    /* 1: d_blob_coarse / d_blob_fine are fused-heads blobs (dmnerf_build_pack_index_fused), see below */
+    /* 1: d_blob_coarse / d_blob_fine are fused-heads blobs (dmnerf_build_pack_index_fused); 2: split-bf16 blobs */
     int fused_heads;
 } dmnerf_render_args;
 int dmnerf_render_rays_fwd(const dmnerf_render_args* args, void* stream);
