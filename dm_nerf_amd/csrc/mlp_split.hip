@@ -69,15 +69,20 @@ __device__ __forceinline__ bf16x8 as_b(const unsigned* w) {
 }
 __device__ __forceinline__ bf16x8 as_a(const f32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// (x0, x1) -> the three bf16-pair words of the truncation split (x = hi + mid + lo exactly)
+// (x0, x1) -> the three bf16-pair words of the truncation split (x = hi + mid + lo exactly); the two subtractions of a
+// stage are one v_pk_add_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& whi, unsigned& wmid, unsigned& wlo) {
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     whi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const f32x2 x = {x0, x1};
+    const f32x2 h = {__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
+    const f32x2 r = x - h;
+    const unsigned v0 = __float_as_uint(r[0]), v1 = __float_as_uint(r[1]);
     wmid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    wlo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    const f32x2 m = {__uint_as_float(v0 & 0xffff0000u), __uint_as_float(v1 & 0xffff0000u)};
+    const f32x2 q = r - m;
+    wlo = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
 }
 
 // planes of NV accumulator-layout f32x16 blocks: block b, register r = 8 t + q -> k-block 2 b + t, word (q >> 1)
@@ -95,6 +100,10 @@ __device__ __forceinline__ void split_blocks(const f32x16 (&x)[NV], unsigned (&P
 
 // One GEMM segment: NKB k-blocks of B planes P (words 4 kb .. 4 kb + 3 of each plane, kb = KB0 ..), OB out-blocks.
 // NEXT_OB: out-blocks of the segment that follows in the stream (0 = none).
+// Per k-block three groups hi, mid, lo of OB tiles each, with 3 / 2 / 1 MFMAs per tile.  Reads (inline asm, one per MFMA
+// gap) run ahead of their use so that no group waits for LDS: the hi group issues the reads of the mid AND lo tiles of
+// its k-block (2 OB reads in 3 OB gaps), the mid group those of the next k-block's hi tiles (into ws.pre, which is the
+// hi buffer), the short lo group none.  The slot hand-over therefore sits at the start of the LAST k-block's mid group.
 template <int KB0, int NKB, int OB, int NEXT_OB, int NW>
 __device__ __forceinline__ void gemm_split(SStream& ws, const unsigned (&P)[3][NW], f32x16 (&acc)[OB], int lane) {
     constexpr int KPS = split_kb_per_slot(OB);
@@ -103,55 +112,79 @@ __device__ __forceinline__ void gemm_split(SStream& ws, const unsigned (&P)[3][N
     static_for<NSLOT>([&](auto sc) {
         constexpr int sl = decltype(sc)::value;
         constexpr int KBN = (NKB - sl * KPS) < KPS ? (NKB - sl * KPS) : KPS;        // k-blocks in this slot
-        constexpr int NG = KBN * 3;                                                  // groups = (k-block, plane)
         constexpr bool LAST_SLOT = sl == NSLOT - 1;
-        constexpr int NXT = LAST_SLOT ? NEXT_OB : OB;                               // tiles of the next slot's first group
-        // MFMA gaps before the last group (DMA pieces must be issued there)
-        constexpr int GAPS_BEFORE_LAST = (KBN * 6 - 1) * OB;
-        constexpr int PD = (GAPS_BEFORE_LAST - OB) / SP_DMA >= 1 ? (GAPS_BEFORE_LAST - OB) / SP_DMA : 1;
+        constexpr int NXT = LAST_SLOT ? NEXT_OB : OB;                               // hi tiles of the next slot's first k-block
+        constexpr int GAPS_BEFORE_HANDOVER = (KBN * 6 - 3) * OB;                    // MFMA gaps before the last k-block's mid group
+        constexpr int PD = (GAPS_BEFORE_HANDOVER - OB) / SP_DMA >= 1 ? (GAPS_BEFORE_HANDOVER - OB) / SP_DMA : 1;
         const unsigned s0 = lds_addr(ws.ring + ws.cslot * SPLIT_SLOT_WORDS) + lane * 16;
         const int nslot = ws.cslot == 2 ? 0 : ws.cslot + 1;
         const int fslot = ws.cslot == 0 ? 2 : ws.cslot - 1;                          // ring slot released by the last hand-over: target of slot + 2
         const unsigned s1 = lds_addr(ws.ring + nslot * SPLIT_SLOT_WORDS) + lane * 16;
-        f32x4 a[2][OB];
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) a[0][ob] = ws.pre[ob];
-        static_for<NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            constexpr int kbl = g / 3, plane = g % 3, T = 3 - plane;
+        f32x4 am[OB], al[OB];                                                        // mid / lo tiles (hi tiles live in ws.pre)
+        static_for<KBN>([&](auto kc) {
+            constexpr int kbl = decltype(kc)::value;
             constexpr int kb = KB0 + sl * KPS + kbl;
-            constexpr bool LASTG = g == NG - 1;
-            // gaps of this slot before this group
-            constexpr int GBASE = (kbl * 6 + (plane == 0 ? 0 : (plane == 1 ? 3 : 5))) * OB;
-            lds_wait<0>(a[g & 1]);
-            if constexpr (LASTG && NXT > 0) {
+            constexpr bool LASTK = kbl == KBN - 1;
+            constexpr int G0 = kbl * 6 * OB;                                         // gaps of this slot before this k-block
+            auto dma_at = [&](auto ggc) {                                            // the SP_DMA pieces of stream slot + 2
+                constexpr int GG = decltype(ggc)::value;
+                static_for<SP_DMA>([&](auto pc) {
+                    constexpr int k = decltype(pc)::value;
+                    constexpr int at = OB + k * PD < GAPS_BEFORE_HANDOVER ? OB + k * PD : GAPS_BEFORE_HANDOVER - 1;
+                    if constexpr (at == GG) ss_fetch_piece(ws, fslot, k);
+                });
+            };
+            // ---- hi group: 3 OB MFMAs; reads: this k-block's mid tiles, then its lo tiles
+            lds_wait<0>(ws.pre);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<3 * OB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int t = i / OB, ob = i % OB;
+                if constexpr (i < OB) lds_read16_async<((kbl * 3 + 1) * OB + i) * 1024>(am[i], s0);
+                else if constexpr (i < 2 * OB) lds_read16_async<((kbl * 3 + 2) * OB + (i - OB)) * 1024>(al[i - OB], s0);
+                dma_at(std::integral_constant<int, G0 + i>{});
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_a(ws.pre[ob]), as_b(&P[t][kb * 4]), acc[ob], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // ---- mid group: 2 OB MFMAs; reads: the next k-block's hi tiles (next slot's after the hand-over)
+            if constexpr (LASTK && NXT > 0) {
+                lds_wait<0>(am);                       // every read of this slot has returned before the slot is released
+#pragma unroll
+                for (int i = 0; i < OB; ++i) asm volatile("" : "+v"(al[i]));
+            } else {
+                lds_wait<OB>(am);                      // the OB lo reads issued after the mid reads may still be in flight
+            }
+            if constexpr (LASTK && NXT > 0) {
                 // hand-over: the next stream slot has landed (vmcnt retires in order: the SP_DMA younger pieces belong to
-                // the slot after it) in every wave's view, and every wave is done reading the slot before this one
+                // the slot after it) in every wave's view, and every wave has issued all its reads of this slot but the
+                // lo tiles of this k-block, which were issued one group ago and are waited for below
                 __builtin_amdgcn_s_waitcnt(0x0F70 | (SP_DMA & 15) | ((SP_DMA >> 4) << 14));
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            static_for<T * OB>([&](auto ic) {
+            static_for<2 * OB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int t = i / OB, ob = i % OB, GG = GBASE + i;
-                if constexpr (!LASTG && i < OB) lds_read16_async<((g + 1) * OB + i) * 1024>(a[(g + 1) & 1][i], s0);
-                if constexpr (LASTG && i < NXT) lds_read16_async<i * 1024>(ws.pre[i], s1);
-                if constexpr (!LASTG) {
-                    // the SP_DMA pieces of stream slot + 2, spread over the gaps before the last group
-                    static_for<SP_DMA>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        constexpr int at = OB + k * PD < GAPS_BEFORE_LAST ? OB + k * PD : GAPS_BEFORE_LAST - 1;
-                        if constexpr (at == GG) ss_fetch_piece(ws, fslot, k);
-                    });
-                }
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_a(a[g & 1][ob]), as_b(&P[t][kb * 4]), acc[ob], 0, 0, 0);
+                constexpr int t = i / OB, ob = i % OB;
+                if constexpr (!LASTK && i < OB) lds_read16_async<(((kbl + 1) * 3) * OB + i) * 1024>(ws.pre[i], s0);
+                if constexpr (LASTK && i < NXT) lds_read16_async<i * 1024>(ws.pre[i], s1);
+                if constexpr (!LASTK) dma_at(std::integral_constant<int, G0 + 3 * OB + i>{});
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_a(am[ob]), as_b(&P[t][kb * 4]), acc[ob], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // ---- lo group: OB MFMAs, no reads
+            lds_wait<(LASTK ? (NXT < OB ? NXT : OB) : OB)>(al);    // the next hi tiles (issued after the lo reads) may still be in flight
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<OB>([&](auto ic) {
+                constexpr int ob = decltype(ic)::value;
+                if constexpr (!LASTK) dma_at(std::integral_constant<int, G0 + 5 * OB + ob>{});
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_a(al[ob]), as_b(&P[0][kb * 4]), acc[ob], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
         // the carry tiles were read through inline asm: make them real values before any other code (or the register
-        // allocator) may touch them -- the reads were issued at the start of the last group and have long returned
+        // allocator) may touch them
         if constexpr (NXT > 0) lds_wait<0>(ws.pre);
         ws.off += SP_SLOT_BYTES;
         ws.cslot = nslot;
