@@ -7,7 +7,7 @@ Per the MI355X guide: separate --pmc passes, FETCH_SIZE/WRITE_SIZE in KB, FETCH_
 import csv, glob, json, os, sys
 
 out, note = sys.argv[1], sys.argv[2]
-KERNEL, GRID = "mlp_fwd_kernel<1, false, false>", 1572864
+KERNEL, GRID = "mlp_fwd_kernel<1, false, false, false>", 1572864
 
 
 def mean(sub, counter):
