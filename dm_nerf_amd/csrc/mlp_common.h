@@ -365,7 +365,7 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
     // ws.pre was written by inline-asm reads the compiler believes to be synchronous: turn it into real values before
     // the caller's code between two quarters (epilogues, stores) gives the register allocator a reason to move it
     // (the reads were issued at the start of the last k-group, >= 4 OB MFMAs ago: this wait is free)
-    if constexpr (NEXT_OB > 0) lds_wait<0>(ws.pre);
+    if constexpr (NEXT_OB > 0) __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
     ws.off += QUARTER_FLOATS * 4;
     ws.cslot ^= 1;
 }
