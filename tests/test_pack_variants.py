@@ -1,0 +1,97 @@
+"""Host-side checks (no GPU) of the two opt-in inference blobs: the fused-heads f32 blob and the split-bf16 blob
+are re-arrangements of the same parameters as the default blob (include/dmnerf_hip.h; csrc/layout.h, pack.cpp)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from dm_nerf_amd import _lib, weights as W
+
+TAB, QUARTER, SLOT_ELEMS = 4096, 16384, 12288 * 2
+
+
+def cfeat(p, h):
+    return 32 * (p >> 4) + ((p & 15) & 3) + 8 * ((p & 15) >> 2) + 4 * h
+
+
+@pytest.mark.parametrize("ins_num", [13, 59, 93])
+def test_fused_index_is_the_default_index_without_the_two_feature_stages(ins_num):
+    a, b = W.pack_index_host(ins_num), W.pack_index_fused_host(ins_num)
+    assert len(a) - len(b) == 8 * QUARTER                       # rgb_feature (st7) and ins_feature (st8): 4 quarters each
+    upto_st6 = TAB + QUARTER * (1 + 20 + 1 + 8)                 # w0 | st0..st4 | w5pe | st5 st6
+    assert np.array_equal(a[TAB:upto_st6], b[TAB:upto_st6])
+    # table: identical except the (absent) biases of stages 7 and 8
+    assert np.array_equal(np.delete(a[:TAB], np.s_[2048:2560]), np.delete(b[:TAB], np.s_[2048:2560]))
+    assert (b[2048:2560] == -1).all()
+    # rgb hidden (2 quarters) + dirs (1) directly follow st6; ins hidden (2) + ins_linear (1) follow them
+    sa, sb = upto_st6 + 4 * QUARTER, upto_st6
+    assert np.array_equal(a[sa:sa + 3 * QUARTER], b[sb:sb + 3 * QUARTER])
+    sa, sb = sa + 3 * QUARTER + 4 * QUARTER, sb + 3 * QUARTER
+    assert np.array_equal(a[sa:sa + 3 * QUARTER], b[sb:sb + 3 * QUARTER])
+
+
+@pytest.mark.parametrize("ins_num", [13, 59, 93])
+def test_split_index_addresses_the_right_parameters(ins_num):
+    lib = _lib.load()
+    total = lib.dmnerf_blob_split_words(ins_num)
+    n = (total - TAB) * 2
+    idx = np.empty(n, dtype=np.int32)
+    _lib.check(lib.dmnerf_build_pack_index_split(ins_num, idx.ctypes.data_as(ctypes.c_void_p), n), "split index")
+    C = ins_num + 1
+    obx = {1: 1, 2: 2, 3: 4, 4: 4}[(C + 31) // 32]
+    # parameter offsets in the flat vector (reference state_dict order)
+    shapes = {"mlps.0": (256, 63), **{f"mlps.{i}": (256, 319 if i == 5 else 256) for i in range(1, 8)},
+              "rgb_feature_linear": (256, 256), "ins_feature_linear": (256, 256), "rgb_feature_linears.0": (128, 283),
+              "ins_feature_linears.0": (128, 256), "density_linear": (1, 256), "ins_linear": (C, 128), "rgb_linear": (3, 128)}
+    off, o = {}, 0
+    for m in W.PARAM_MODULES:
+        off[m] = o
+        o += shapes[m][0] * shapes[m][1] + shapes[m][0]
+    assert o == lib.dmnerf_param_count(ins_num)
+    # slots: w0 2 | L1..L5h 5x8 | L5 pe 2 | L6, L7 2x8 | rgb hidden 4 | dirs 1 | ins hidden 4 | ins_linear 1-2 | 2 landing slots
+    n_inso = -(-8 // (16 // obx))                                   # ins_linear: 8 k-blocks, 16 / OB per slot
+    assert n == (2 + 40 + 2 + 16 + 4 + 1 + 4 + n_inso + 2) * SLOT_ELEMS
+    s_l7, s_rgbh, s_insh, s_inso = 2 + 40 + 2 + 8, 2 + 40 + 2 + 16, 2 + 40 + 2 + 16 + 4 + 1, 2 + 40 + 2 + 16 + 4 + 1 + 4
+
+    def check(slot0, mod, nkb, ob_n, ncols, col0=0):
+        rows, ld = shapes[mod]
+        kps = 16 // ob_n
+        for kb in (0, 1, nkb // 2, nkb - 1):
+            for plane in range(3):
+                for ob in range(ob_n):
+                    for lane in (0, 7, 31, 32, 63):
+                        for q in range(8):
+                            e = ((slot0 + kb // kps) * 48 + ((kb % kps) * 3 + plane) * ob_n + ob) * 512 + lane * 8 + q
+                            row, col = ob * 32 + (lane & 31), cfeat(8 * kb + q, lane >> 5)
+                            want = -1 if (row >= rows or col >= ncols) else (off[mod] + row * ld + col0 + col) | (plane << 28)
+                            assert idx[e] == want, (mod, kb, plane, ob, lane, q)
+
+    check(s_l7, "mlps.7", 16, 8, 256)
+    check(s_rgbh, "rgb_feature_linears.0", 16, 4, 256)
+    check(s_insh, "ins_feature_linears.0", 16, 4, 256)
+    check(s_inso, "ins_linear", 8, obx, 128)
+    assert (idx[(s_inso + n_inso) * SLOT_ELEMS:] == -1).all()      # landing slots are zero
+
+
+def test_fuse_heads_is_the_same_function():
+    import torch
+    from oracle import ref_cpu as O
+    sd = O.make_weights(9, 13, gain=1.7, sigma_bias=0.3)
+    g = torch.Generator().manual_seed(9)
+    x = torch.cat([O.embed(torch.randn(64, 3, generator=g), 10), O.embed(torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1), 4)], -1)
+    want = O.mlp_forward(sd, x)
+    sf = W.fuse_heads(sd)
+    # evaluate the fused network: hidden layers take h directly
+    xp, xv = x[:, :63], x[:, 63:]
+    h = xp
+    for i in range(8):
+        h = torch.relu(h @ sf[f"mlps.{i}.weight"].t() + sf[f"mlps.{i}.bias"])
+        if i == 4:
+            h = torch.cat([h, xp], -1)
+    den = h @ sf["density_linear.weight"].t() + sf["density_linear.bias"]
+    hr = torch.relu(torch.cat([h, xv], -1) @ sf["rgb_feature_linears.0.weight"].t() + sf["rgb_feature_linears.0.bias"])
+    rgb = hr @ sf["rgb_linear.weight"].t() + sf["rgb_linear.bias"]
+    hi = torch.relu(h @ sf["ins_feature_linears.0.weight"].t() + sf["ins_feature_linears.0.bias"])
+    ins = hi @ sf["ins_linear.weight"].t() + sf["ins_linear.bias"]
+    got = torch.cat([rgb, den, ins], -1)
+    assert float(((got - want).abs() / (1 + want.abs())).max()) <= 2e-6
