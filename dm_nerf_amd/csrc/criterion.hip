@@ -32,7 +32,7 @@ constexpr int CR_MAXC = 128;      // channels (= ins_num) supported by the solve
 // Work buffer layout (byte offsets; everything 8-byte aligned).  L = C + 1 label values 0..C.
 struct CrLayout {
     int64_t part_b, part_t, part_a, part_s, part_cnt;     // chunk partials
-    int64_t ce, siou;                                     // float [C][C]: rows g < V
+    int64_t ce, siou, tp_all;                             // float [C][C]: rows g < V (tp_all: the soft true-positive sums)
     int64_t row4col, lab_of_row, tp_of_col, den_of_col;   // int [C], int [C], float [C], float [C]
     int64_t scal;                                         // int V, int U (+ pad)
     int64_t total;
@@ -52,6 +52,7 @@ __host__ __device__ inline CrLayout cr_layout(int64_t N, int C) {
     w.part_cnt = take((int64_t)w.nch * w.L * 4);
     w.ce = take((int64_t)C * C * 4);
     w.siou = take((int64_t)C * C * 4);
+    w.tp_all = take((int64_t)C * C * 4);
     w.row4col = take((int64_t)C * 4);
     w.lab_of_row = take((int64_t)C * 4);
     w.tp_of_col = take((int64_t)C * 4);
@@ -127,22 +128,40 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
     __shared__ unsigned char s_SR[CR_MAXC], s_SC[CR_MAXC];
     float* ce = reinterpret_cast<float*>(work + w.ce);
     float* siou = reinterpret_cast<float*>(work + w.siou);
+    float* tp_all = reinterpret_cast<float*>(work + w.tp_all);
     const float* pb = reinterpret_cast<const float*>(work + w.part_b);
     const float* pt = reinterpret_cast<const float*>(work + w.part_t);
     const float* pa = reinterpret_cast<const float*>(work + w.part_a);
     const float* ps = reinterpret_cast<const float*>(work + w.part_s);
     const int* pc = reinterpret_cast<const int*>(work + w.part_cnt);
 
-    // 1. label counts, the labels that occur (ascending) -> rows (evaluator.py:21-26)
-    for (int l = tid; l < L; l += blockDim.x) {
-        int c = 0;
-        for (int k = 0; k < w.nch; ++k) c += pc[(int64_t)k * L + l];
-        s_cnt[l] = c;
-    }
-    for (int p = tid; p < C; p += blockDim.x) {
-        double a = 0.0, s = 0.0;
-        for (int k = 0; k < w.nch; ++k) { a += (double)pa[(int64_t)k * C + p]; s += (double)ps[(int64_t)k * C + p]; }
-        s_A[p] = a; s_S[p] = s;
+    // 1. label counts, the labels that occur (ascending) -> rows (evaluator.py:21-26).  Sixteen neighbouring lanes share
+    //    an entry (every 16th chunk partial each, loads in flight together), combined in a fixed butterfly order.
+    auto sum16d = [](double v) {
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        return v;
+    };
+    {
+        const int sub = tid & 15;
+        for (int e0 = 0; e0 < L + 2 * C; e0 += blockDim.x / 16) {
+            const int e = e0 + (tid >> 4);
+            double v = 0.0;
+            if (e < L) {
+                int c = 0;
+                for (int k = sub; k < w.nch; k += 16) c += pc[(int64_t)k * L + e];
+                v = (double)c;                                            // exact
+            } else if (e < L + C) {
+                for (int k = sub; k < w.nch; k += 16) v += (double)pa[(int64_t)k * C + (e - L)];
+            } else if (e < L + 2 * C) {
+                for (int k = sub; k < w.nch; k += 16) v += (double)ps[(int64_t)k * C + (e - L - C)];
+            }
+            v = sum16d(v);
+            if (sub == 0) {
+                if (e < L) s_cnt[e] = (int)v;
+                else if (e < L + C) s_A[e - L] = v;
+                else if (e < L + 2 * C) s_S[e - L - C] = v;
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -156,18 +175,24 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
     for (int l = tid; l < L; l += blockDim.x)
         if (s_rank[l] >= 0) lab_of_row[s_rank[l]] = l;
 
-    // 2. cost matrices (evaluator.py:57-66), f32 entries
-    for (int e = tid; e < L * C; e += blockDim.x) {
-        const int l = e / C, p = e - l * C;
-        const int g = s_rank[l];
-        if (g < 0) continue;
+    // 2. cost matrices (evaluator.py:57-66), f32 entries; same 16-lane sharing
+    for (int e0 = 0; e0 < L * C; e0 += blockDim.x / 16) {
+        const int e = e0 + (tid >> 4), sub = tid & 15;
+        const bool in = e < L * C;
+        const int l = in ? e / C : 0, p = in ? e - l * C : 0;
+        const int g = in ? s_rank[l] : -1;
         double b = 0.0, t = 0.0;
-        for (int k = 0; k < w.nch; ++k) { b += (double)pb[((int64_t)k * L + l) * C + p]; t += (double)pt[((int64_t)k * L + l) * C + p]; }
-        ce[g * C + p] = (float)((s_A[p] + b) / (double)N);
-        const float TP = (float)t;
-        const float FP = (float)s_S[p] - TP;
-        const float FN = (float)s_cnt[l] - TP;
-        siou[g * C + p] = 1.0f - TP / (TP + FP + FN + 1e-6f);
+        if (g >= 0)
+            for (int k = sub; k < w.nch; k += 16) { b += (double)pb[((int64_t)k * L + l) * C + p]; t += (double)pt[((int64_t)k * L + l) * C + p]; }
+        b = sum16d(b); t = sum16d(t);
+        if (g >= 0 && sub == 0) {
+            ce[g * C + p] = (float)((s_A[p] + b) / (double)N);
+            const float TP = (float)t;
+            tp_all[g * C + p] = TP;
+            const float FP = (float)s_S[p] - TP;
+            const float FN = (float)s_cnt[l] - TP;
+            siou[g * C + p] = 1.0f - TP / (TP + FP + FN + 1e-6f);
+        }
     }
     __syncthreads();
 
@@ -238,9 +263,7 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
         row4col[p] = g;
         if (g >= 0) {
             const int l = lab_of_row[g];
-            double t = 0.0;
-            for (int k = 0; k < w.nch; ++k) t += (double)pt[((int64_t)k * L + l) * C + p];
-            const float TP = (float)t;
+            const float TP = tp_all[g * C + p];                          // the value the cost matrix used
             tp_of_col[p] = TP;
             den_of_col[p] = TP + ((float)s_S[p] - TP) + ((float)s_cnt[l] - TP) + 1e-6f;
         }
