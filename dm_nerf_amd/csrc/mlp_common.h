@@ -41,7 +41,7 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 //   (x * freq is exact for power-of-two freq, dm_nerf.py:25,31), cheaper and tighter than a full-range sincosf.
 __device__ __forceinline__ double rev_of(float v) { return (double)v * 0.15915494309189535; }      // 1 / (2 pi)
 
-__device__ __forceinline__ float sin_rev(double t, int k, int quarter) {
+__device__ __forceinline__ double sin_rev_d(double t, int k, int quarter) {
     double g = t * (double)(1 << k) + 0.25 * (double)quarter;
     g = g - __builtin_rint(g);
     const double ag = __builtin_fabs(g);
@@ -56,11 +56,16 @@ __device__ __forceinline__ float sin_rev(double t, int k, int quarter) {
     p = __builtin_fma(p, x2, -1.0 / 120.0);
     p = __builtin_fma(p, x2, 1.0 / 6.0);
     const double s = x - x * x2 * p;                     // x (1 - x2/6 + x4/120 - ...)
-    return (float)__builtin_copysign(s, g);
+    return __builtin_copysign(s, g);
 }
+__device__ __forceinline__ float sin_rev(double t, int k, int quarter) { return (float)sin_rev_d(t, k, quarter); }
 
 // Encoding of one 3-vector in the k-pair order of layout.h::pefeat: lanes 0-31 take the sin
 // slot (and x, z), lanes 32-63 the cos slot (and y, pad).
+// Per coordinate ONE sin / cos pair is evaluated (frequency 1) and the higher octaves follow from the double-
+// angle recurrence in double precision, s' = 2 s c, c' = 1 - 2 s^2: the absolute error grows like 2^k x 1e-16
+// (<= 1e-13 at k = 9), far below half an f32 ulp of values in [-1, 1], at 5 instead of ~19 f64 instructions per
+// output (the encoding is pure VALU work in front of the first MFMA).
 template <int L, int NV>
 __device__ __forceinline__ void encode(const float (&v)[3], f32x16 (&out)[NV], int half) {
     static_assert(NV * 16 >= 2 + 3 * L, "encoding registers too small");
@@ -68,13 +73,17 @@ __device__ __forceinline__ void encode(const float (&v)[3], f32x16 (&out)[NV], i
     for (int i = 0; i < NV; ++i) out[i] = (f32x16)(0.f);
     out[0][0] = half ? v[1] : v[0];
     out[0][1] = half ? 0.f : v[2];
-    const double t[3] = {rev_of(v[0]), rev_of(v[1]), rev_of(v[2])};
 #pragma unroll
-    for (int k = 0; k < L; ++k) {
+    for (int c = 0; c < 3; ++c) {
+        const double t = rev_of(v[c]);
+        double sn = sin_rev_d(t, 0, 0), cs = sin_rev_d(t, 0, 1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int k = 0; k < L; ++k) {
             const int p = 2 + 3 * k + c;
-            out[p >> 4][p & 15] = sin_rev(t[c], k, half);
+            out[p >> 4][p & 15] = (float)(half ? cs : sn);
+            const double s_old = sn, t2 = s_old + s_old;
+            sn = t2 * cs;                                    // sin 2a = 2 sin a cos a
+            cs = __builtin_fma(-t2, s_old, 1.0);             // cos 2a = 1 - 2 sin^2 a
         }
     }
 }
@@ -259,10 +268,23 @@ __device__ __forceinline__ void ws_fetch_first(WStream& ws) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long long)(DMN_LAS const void*)p;
 }
-template <int OFF>
+// Register class of the asm-read operand tiles, chosen per translation unit in the Makefile: "v" or "a" (an MFMA
+// takes its A operand from either file).  The compiler believes an asm read has completed when it has been issued; if
+// the register allocator then decides that the value should live in the OTHER file it copies a register whose read
+// is still in flight.  Asking for the class the allocator wants anyway removes the copy; scripts/check_asm_hazard.py
+// proves on the shipped ISA that none is left (the build fails otherwise).  CARRY selects the class of the hand-over
+// tiles (WStream::pre), whose live range spans the code between two quarters.
+#ifndef DMN_TILE_RC
+#define DMN_TILE_RC "v"
+#endif
+#ifndef DMN_CARRY_RC
+#define DMN_CARRY_RC DMN_TILE_RC
+#endif
+template <int OFF, bool CARRY = false>
 __device__ __forceinline__ void lds_read16_async(f32x4& v, unsigned addr) {
     static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset field");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    if constexpr (CARRY) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" DMN_CARRY_RC(v) : "v"(addr), "n"(OFF));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=" DMN_TILE_RC(v) : "v"(addr), "n"(OFF));
 }
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) -- the
 // index is a constant expression inside f (literal instruction offsets; no address arithmetic for the
@@ -276,11 +298,14 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 // wait until at most N LDS operations are outstanding, then hand the registers back to the compiler
-template <int N, int NV>
+template <int N, bool CARRY = false, int NV>
 __device__ __forceinline__ void lds_wait(f32x4 (&v)[NV]) {
     __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));           // lgkmcnt(N) only (gfx9 encoding)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
+    for (int i = 0; i < NV; ++i) {
+        if constexpr (CARRY) asm volatile("" : "+" DMN_CARRY_RC(v[i]));
+        else asm volatile("" : "+" DMN_TILE_RC(v[i]));
+    }
 }
 
 // Quarter hand-over.  Quarter q + 1 is complete in the other ring slot once every wave has seen its own
@@ -311,9 +336,9 @@ __device__ __forceinline__ void ws_prime(WStream& ws, int lane) {
     const unsigned s0 = lds_addr(ws.ring + ws.cslot * SLOT_FLOATS) + lane * 16;
     static_for<OB>([&](auto ic) {
         constexpr int ob = decltype(ic)::value;
-        lds_read16_async<ob * 1024>(ws.pre[ob], s0);
+        lds_read16_async<ob * 1024, true>(ws.pre[ob], s0);
     });
-    lds_wait<0>(ws.pre);          // (once per workgroup; see the end of gemm_quarter)
+    lds_wait<0, true>(ws.pre);    // (once per workgroup; see the end of gemm_quarter)
 }
 
 // One quarter's worth of a GEMM segment: k-groups [G0, G0 + NG) of a segment with OB out-blocks, A
@@ -353,7 +378,7 @@ __device__ __forceinline__ void gemm_quarter(WStream& ws, const f32x16 (&B)[NB],
             constexpr int p = (G0 + gl) * 4 + kk;
             if constexpr (gl + 1 < NG && i < OB)
                 lds_read16_async<((gl + 1) * OB + i) * 1024>(a[(gl + 1) & 1][i], s0);           // group gl + 1, out-block i
-            if constexpr (gl == NG - 1 && i < NEXT_OB) lds_read16_async<i * 1024>(ws.pre[i], s1);  // next quarter, group 0
+            if constexpr (gl == NG - 1 && i < NEXT_OB) lds_read16_async<i * 1024, true>(ws.pre[i], s1);  // next quarter, group 0
             if constexpr (M >= OB && (M - OB) % P == 0 && (M - OB) / P < DMA_PER_QUARTER) ws_fetch_piece(ws, (M - OB) / P);
             if constexpr (NSIDE > 0 && M >= S0 && (M - S0) % SP == 0 && (M - S0) / SP < NSIDE) side((M - S0) / SP);
             // ZERO: this quarter starts the GEMM -- C = 0 is an inline constant of the MFMA, no accumulator clear

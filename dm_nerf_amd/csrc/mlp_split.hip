@@ -150,7 +150,7 @@ __device__ __forceinline__ void gemm_split(SStream& ws, const unsigned (&P)[3][N
             if constexpr (LASTK && NXT > 0) {
                 lds_wait<0>(am);                       // every read of this slot has returned before the slot is released
 #pragma unroll
-                for (int i = 0; i < OB; ++i) asm volatile("" : "+v"(al[i]));
+                for (int i = 0; i < OB; ++i) asm volatile("" : "+" DMN_TILE_RC(al[i]));
             } else {
                 lds_wait<OB>(am);                      // the OB lo reads issued after the mid reads may still be in flight
             }

@@ -175,7 +175,7 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
             constexpr int r = decltype(rc)::value;
             lds_wait<0>(av[r & 1]);
 #pragma unroll
-            for (int k = 0; k < SBn; ++k) asm volatile("" : "+v"(bv[r & 1][k]));
+            for (int k = 0; k < SBn; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
             if constexpr (r == 3) {
                 // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released
                 __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
@@ -207,7 +207,14 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
         });
         sb = nb;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the ring's last (clamped) refills
+    // the ring's last (clamped) refills and the read-ahead of the chunk after the last one: both land in registers /
+    // LDS nobody uses, but they must have landed before the epilogue reuses either (the ties keep the read-ahead's
+    // destination registers allocated until then)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < SAn; ++k) asm volatile("" : "+" DMN_TILE_RC(av[0][k]));
+#pragma unroll
+    for (int k = 0; k < SBn; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
 
     // epilogue: partial tile [NBA*32][NBB*32], C layout: lane holds column j = li, rows crow(r, half)
     float* __restrict__ P = a.part + jb.part_off;
