@@ -110,6 +110,35 @@ def train_leg(mc, mf, ro, rd, z, steps, dev):
             "batch_rays": N_RAYS, "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"}
 
 
+def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
+    """The same optimisation step on the oracle (CPU port: PyTorch autograd, scipy assignment, torch Adam) on a
+    bounded number of rays of the same chunk; one untimed step calibrates the sample size and warms up."""
+    from oracle import ref_cpu as O
+    sdc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mc.state_dict().items()}
+    sdf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mf.state_dict().items()}
+    opt = torch.optim.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4, betas=(0.9, 0.999))
+    g = torch.Generator().manual_seed(0)
+    target = torch.rand(N_RAYS, 3, generator=g)
+    labels = torch.randint(0, 9, (N_RAYS,), generator=g)
+
+    def one(n):
+        rays = rays_cpu[:, :n]
+        o = O.dm_nerf(rays, sdc, sdf, z_cpu[:n], perturb=1.)
+        loss = ((o['rgb_fine'] - target[:n]) ** 2).mean() + ((o['rgb_coarse'] - target[:n]) ** 2).mean() \
+            + O.ins_criterion(o['ins_fine'], labels[:n], INS_NUM)[0].sum() + O.ins_criterion(o['ins_coarse'], labels[:n], INS_NUM)[0].sum() \
+            + O.ins_penalizer(o['raw_fine'], o['z_vals_fine'], o['depth_fine'], rays[1], 0.05, 0.05).sum() \
+            + O.ins_penalizer(o['raw_coarse'], o['z_vals_coarse'], o['depth_coarse'], rays[1], 0.05, 0.05).sum()
+        opt.zero_grad(); loss.backward(); opt.step()
+
+    n0 = 128
+    t0 = time.perf_counter(); one(n0); t1 = time.perf_counter() - t0
+    # (the step's cost grows faster than linearly with the batch -- autograd's saved activations fall out of cache)
+    n = int(min(512, max(128, 0.4 * (seconds / max(t1, 1e-3)) * n0 // 128 * 128)))
+    t0 = time.perf_counter(); one(n); dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one optimisation step on {n} rays of the same chunk (64+128 samples, perturb=1), oracle/ref_cpu + torch autograd + Adam, {dt:.1f} s"}
+
+
 def fused_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref, split=False):
     """Not the headline: the same render step with an opt-in inference mode.  split=False: the activation-free
     rgb_feature_linear / ins_feature_linear folded into the hidden layers (562 432 instead of 693 504
@@ -251,7 +280,13 @@ def main():
             res["render_fused_heads"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'])
             res["render_split_bf16"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], split=True)
         if world == 1 and not a.no_train:
+            tb = None
+            if not a.no_cpu_baseline:                   # (before the GPU leg: it updates the weights in place)
+                tb = cpu_train_baseline(mc, mf, torch.stack([ro[:N_RAYS], rd[:N_RAYS]]).cpu(), z.cpu(), a.cpu_seconds / 2)
             res["train"] = train_leg(mc, mf, ro, rd, z, a.train_steps, dev)
+            if tb is not None:
+                res["train"]["cpu_baseline"] = tb
+                res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,81 @@
+"""GPU tests of what sits around the hot path: the full-frame driver (reference: the per-pose body of render_test,
+networks/tester.py:58-85) and the boundary's promise that the library never allocates, frees or synchronises
+(SURVEY 8(b) "Ownership"), which makes a render step capturable in a HIP graph."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from dm_nerf_amd import _lib, distributed as D
+    from dm_nerf_amd.networks import dm_nerf as M, helpers as H, render as R
+    _lib.load()
+    return types.SimpleNamespace(M=M, H=H, R=R, D=D)
+
+
+def models(A, ins_num=13):
+    out = []
+    for seed in (61, 62):
+        m = A.M.DM_NeRF(8, 256, 63, 27, [4], ins_num)
+        m.load_state_dict(O.make_weights(seed, ins_num, gain=1.7, sigma_bias=0.3))
+        out.append(m.cuda().eval())
+    return out
+
+
+def test_render_frame_ragged_chunks_equal_one_shot_render(A):
+    """A 9 x 13 frame in chunks of 50 rays (two full chunks + a ragged one of 17, tester.py:65-67) assembles to exactly
+    what one dm_nerf call over all 117 rays returns: rays are independent, so chunking must not change a bit."""
+    H, W = 9, 13
+    mc, mf = models(A)
+    K = np.array([[20.0, 0, W / 2], [0, -20.0, H / 2], [0, 0, -1]])
+    c2w = O.pose_spherical(30.0, -65.0, 7.0).cuda()
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        rgb, ins, depth = A.D.render_frame(H, W, K, c2w, (mc, mf), 4.0, 15.0, args, chunk=50, n_samples=64)
+        ro, rd = A.H.get_rays_k(H, W, K, c2w)
+        z = A.H.z_val_sample(H * W, 4.0, 15.0, 64, device=ro.device)
+        one = A.R.dm_nerf(torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)]), None, None, mc, mf, z, args)
+    assert rgb.shape == (H, W, 3) and ins.shape == (H, W, 13) and depth.shape == (H, W)
+    assert torch.equal(rgb.reshape(-1, 3), one['rgb_fine'])
+    assert torch.equal(ins.reshape(-1, 13), one['ins_fine'])
+    assert torch.equal(depth.reshape(-1), one['depth_fine'])
+    assert torch.equal(ins.argmax(-1).reshape(-1), one['ins_fine'].argmax(-1))
+
+
+def test_render_step_is_graph_capturable(A):
+    """No allocation, free or synchronisation inside the library: a dm_nerf render step records into a HIP graph and
+    the replay on new ray data reproduces the eager result bit for bit."""
+    N = 256
+    mc, mf = models(A)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(50.0, -65.0, 7.0))
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    pick = lambda s: torch.stack([ro[s:s + N], rd[s:s + N]]).cuda()
+    z = A.H.z_val_sample(N, 4.0, 15.0, 64, device="cuda")
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    rays = pick(1000)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on a side stream (weight blobs packed, workspaces sized)
+            A.R.dm_nerf(rays, None, None, mc, mf, z, args)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = A.R.dm_nerf(rays, None, None, mc, mf, z, args)
+        rays.copy_(pick(150000))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = {k: v.clone() for k, v in out.items()}
+        want = A.R.dm_nerf(pick(150000), None, None, mc, mf, z, args)
+    for k in ("rgb_fine", "ins_fine", "depth_fine", "z_vals_fine", "raw_fine", "raw_coarse"):
+        assert torch.equal(got[k], want[k]), k
+    assert float(got["rgb_fine"].std()) > 0
