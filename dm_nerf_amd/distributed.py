@@ -61,20 +61,23 @@ def all_gather_cat(t, sizes=None):
     if world == 1:
         return t
     t = t.contiguous()
-    if sizes is None or len(set(sizes)) == 1:
-        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+
+    def gather(x):                                       # [n, ...] -> [world * n, ...]
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         try:
-            dist.all_gather_into_tensor(out, t)          # one RCCL all-gather
+            dist.all_gather_into_tensor(out, x)          # one RCCL all-gather
         except (RuntimeError, NotImplementedError):      # backends without the tensor form (gloo on device tensors)
-            parts = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
+            parts = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(parts, x)
             out = torch.cat(parts, 0)
         return out
+
+    if sizes is None or len(set(sizes)) == 1:
+        return gather(t)
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
-    out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad)
+    out = gather(pad)
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
 
 
@@ -105,6 +108,99 @@ def data_parallel_backward(loss_local, models, n_local, n_global):
     del n_local
     (loss_local / float(n_global)).backward()
     return allreduce_grads(models)
+
+
+class _GatherBatch(torch.autograd.Function):
+    """Forward: the full batch tensor on every rank (one all-gather of the detached local slices).
+    Backward: the gradient w.r.t. the full tensor is identical on every rank (the losses that consume it are
+    evaluated redundantly); each rank keeps the rows of its own slice."""
+
+    @staticmethod
+    def forward(ctx, local, sizes):
+        rank, world = world_info()
+        ctx.s0, ctx.cnt = sum(sizes[:rank]), sizes[rank]
+        return all_gather_cat(local.detach(), sizes)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.s0:ctx.s0 + ctx.cnt].contiguous(), None
+
+
+def gather_batch(local, sizes):
+    """``[n_local, ...] -> [N, ...]`` on every rank, differentiable w.r.t. the local rows (the small
+    per-ray outputs -- rgb ``[N,3]``, ins ``[N,ins_num]`` -- that batch-global losses need: ≈0.2 MB per step)."""
+    rank, world = world_info()
+    if world == 1:
+        return local
+    return _GatherBatch.apply(local, list(sizes))
+
+
+def allreduce_sums(t):
+    """In-place sum over ranks of a small tensor of batch-global partial sums (the emptiness penalizer's mask
+    normalisers, networks/penalizer.py:43,52).  No-op in a single process."""
+    rank, world = world_info()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, ins_num,
+                       render=None, mse=None, criterion=None, penalizer=None, t_rand=None, u=None):
+    """One optimisation step of train_dmsr.py:26-64 with the ray batch sharded over the ranks, producing the SAME
+    update as a single process on the whole batch (BASELINE config 5):
+
+    * every rank holds the same ``rays [2,N,3]``, ``z_vals [N,S]``, ``target [N,3]``, ``labels`` (the loaders draw the
+      batch from a numpy stream that is seeded identically on every rank) and renders rows ``ray_slice(N)``;
+      with ``args.perturb > 0`` the two jitter tensors are drawn FULL-size from the (identically seeded) device
+      generator, in the reference's order (render.py:46, helpers.py:135), and sliced, so the jitter of ray i does not
+      depend on the world size;
+    * the per-ray outputs the batch-global losses need are all-gathered (``gather_batch``: 2 x (rgb + ins), ≈0.2 MB):
+      img2mse's mean and the Hungarian cost matrices / soft-IoU sums of ins_criterion (evaluator.py:19-74) are then
+      evaluated identically on every rank, and autograd hands each rank the gradient rows of its own slice;
+      ``args.N_ins`` (ScanNet: only the LAST N_ins rays carry labels, render.py:88-90) is applied to the gathered tensor;
+    * the emptiness penalizer is a ratio of batch sums: numerators and mask counts are summed over ranks
+      (``allreduce_sums``) before the division, inside the penalizer (``sharded=True``);
+    * ``loss.backward()`` then yields on each rank the gradient contribution of its rays to the GLOBAL loss, one flat
+      all-reduce (sum) of both models' gradients completes them, and every rank takes the same optimizer step.
+
+    ``render / mse / criterion / penalizer`` default to the HIP path (networks.render.dm_nerf, evaluator.img2mse,
+    evaluator.ins_criterion, penalizer.ins_penalizer); they are injectable so that the sharding logic itself is
+    covered on CPU with gloo.  Returns the (global) loss and the number of bytes all-reduced."""
+    from .networks import evaluator as E, penalizer as P, render as R
+    rank, world = world_info()
+    N = rays.shape[1]
+    sizes = [ray_slice(N, r, world)[1] for r in range(world)]
+    s0, cnt = ray_slice(N, rank, world)
+    sl = slice(s0, s0 + cnt)
+    n_imp = int(args.N_importance)
+    if float(args.perturb) > 0.:
+        if t_rand is None:
+            t_rand = torch.rand(z_vals.shape, device=z_vals.device)
+        if u is None:
+            u = torch.rand([N, n_imp], device=z_vals.device)
+    import copy
+    largs = copy.copy(args)
+    n_ins = getattr(args, "N_ins", None)
+    largs.N_ins = None                                   # the label slice is taken on the gathered batch
+    render = render or (lambda r, z, a, tr, uu: R.dm_nerf(r, None, None, models[0], models[1], z, a, t_rand=tr, u=uu))
+    mse = mse or E.img2mse
+    criterion = criterion or (lambda pred, gt: E.ins_criterion(pred, gt, ins_num)[0])
+    penalizer = penalizer or (lambda out, lvl, rays_d: P.ins_penalizer(out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl],
+                                                                       rays_d, largs, sharded=True))
+    out = render(rays[:, sl].contiguous(), z_vals[sl].contiguous(), largs,
+                 None if t_rand is None else t_rand[sl].contiguous(), None if u is None else u[sl].contiguous())
+    loss = 0.
+    for lvl in ("fine", "coarse"):
+        rgb = gather_batch(out['rgb_' + lvl], sizes)
+        ins = gather_batch(out['ins_' + lvl], sizes)
+        if n_ins is not None:
+            ins = ins[-n_ins:]
+        loss = loss + mse(rgb, target) + criterion(ins, labels) + penalizer(out, lvl, rays[1, sl]).sum()
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    nbytes = allreduce_grads(models)
+    optimizer.step()
+    return loss.detach(), nbytes
 
 
 def _default_raygen(H, W, K, c2w, row0, nrows):

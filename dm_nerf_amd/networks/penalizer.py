@@ -16,7 +16,7 @@ def _consts(deta_w):
 
 class _Penalizer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, z, depth, rays_d, tolerance, deta_w):
+    def forward(ctx, raw, z, depth, rays_d, tolerance, deta_w, sharded=False):
         lib = _lib.load()
         N, S, ch = raw.shape
         C = ch - 4
@@ -25,6 +25,9 @@ class _Penalizer(torch.autograd.Function):
         _lib.check(lib.dmnerf_penalizer_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(depth), _lib.ptr(rays_d), N, S, C,
                                             float(tolerance), k2w, kh, _lib.ptr(part), _lib.stream()), "dmnerf_penalizer_fwd")
         s = part.sum(0)                                               # 4 doubles; stays on the device
+        if sharded:                                                   # ray-sharded batch: the four sums are batch-global
+            from .. import distributed
+            distributed.allreduce_sums(s)
         nb = torch.clamp(s[1], min=1e-8)
         nm = torch.clamp(s[3], min=1e-8)
         loss = (s[0] / (C * nb) + s[2] / nm).to(torch.float32)
@@ -42,19 +45,20 @@ class _Penalizer(torch.autograd.Function):
         d_raw = torch.empty_like(raw)
         _lib.check(lib.dmnerf_penalizer_bwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(depth), _lib.ptr(rays_d), N, S, C, tol, k2w, kh,
                                             _lib.ptr(scales.contiguous()), _lib.ptr(d_raw), _lib.stream()), "dmnerf_penalizer_bwd")
-        return d_raw, None, None, None, None, None
+        return d_raw, None, None, None, None, None, None
 
 
-def emptiness_penalizer(raw, z_vals, depths, rays_d, tolerance, deta_w):
+def emptiness_penalizer(raw, z_vals, depths, rays_d, tolerance, deta_w, sharded=False):
     """``emptiness_penalizer`` (networks/penalizer.py:5-55).  ``depths``: [N,1] or [N]; no gradient flows to it
-    (the reference's only caller detaches it), nor to ``z_vals`` / ``rays_d``."""
+    (the reference's only caller detaches it), nor to ``z_vals`` / ``rays_d``.  ``sharded`` (extension): the rays are
+    one rank's slice of a batch; the loss and its gradient are those of the whole batch (distributed.py)."""
     raw = _lib.f32(raw)
     z, depth, d = _lib.f32(z_vals.detach()), _lib.f32(depths.detach().reshape(-1)), _lib.f32(rays_d.detach())
     _lib.require_gpu(raw, z, depth, d)
-    return _Penalizer.apply(raw, z, depth, d, tolerance, deta_w)
+    return _Penalizer.apply(raw, z, depth, d, tolerance, deta_w, sharded)
 
 
-def ins_penalizer(raw, z_vals, depth, rays_d, args):
+def ins_penalizer(raw, z_vals, depth, rays_d, args, sharded=False):
     """``ins_penalizer`` (networks/penalizer.py:58-62)."""
     depth = depth[..., None].detach()
-    return emptiness_penalizer(raw, z_vals, depth, rays_d, args.tolerance, args.deta_w)
+    return emptiness_penalizer(raw, z_vals, depth, rays_d, args.tolerance, args.deta_w, sharded)

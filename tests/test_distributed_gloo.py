@@ -122,3 +122,90 @@ def test_two_rank_sharded_frame_equals_single_process():
         assert np.array_equal(rgb, single[0]) and np.array_equal(ins, single[1]) and np.array_equal(depth, single[2])
         assert g_ok and nbytes == (3 * 2 + 2 + 2 + 1) * 4
         assert np.array_equal(cat[:, 0], np.array([0, 1, 10, 11, 12], dtype=np.float32))
+
+
+# ---- ray-sharded training step (BASELINE config 5) --------------------------------------------------
+TN, TS, TIMP, TNINS = 25, 16, 16, 10      # 25 rays -> slices of 13 + 12; only the last 10 rays carry labels
+
+
+class _SD:
+    """The oracle's weights (a state_dict of leaf tensors) behind the two methods the step needs."""
+
+    def __init__(self, sd):
+        self.sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+    def parameters(self):
+        return list(self.sd.values())
+
+
+def _train_two_steps():
+    import types
+    K, c2w, sd_c, sd_f = _scene()
+    o, d = O.get_rays_k(H, W, K, c2w)
+    sel = torch.from_numpy(np.random.RandomState(3).choice(H * W, TN, replace=False))
+    rays = torch.stack([o.reshape(-1, 3)[sel], d.reshape(-1, 3)[sel]])
+    z = O.z_val_sample(TN, 4.0, 15.0, TS).contiguous()
+    g = torch.Generator().manual_seed(11)
+    target = torch.rand(TN, 3, generator=g)
+    labels = torch.randint(0, 4, (TNINS,), generator=g)
+    mc, mf = _SD(sd_c), _SD(sd_f)
+    # (plain gradient steps: the update is proportional to the gradient, so parameter differences measure gradient
+    # differences; Adam would turn float noise on near-zero gradients into +-lr steps)
+    opt = torch.optim.SGD(mc.parameters() + mf.parameters(), lr=2e-2)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=TIMP, is_train=True, N_ins=TNINS)
+    sizes = [D.ray_slice(TN, r, D.world_info()[1])[1] for r in range(D.world_info()[1])]
+
+    def render(r, zz, a, tr, uu):
+        assert a.N_ins is None                               # the label slice belongs to the gathered batch
+        return O.dm_nerf(r, mc.sd, mf.sd, zz, perturb=1., N_importance=TIMP, is_train=True, N_ins=None, t_rand=tr, u=uu)
+
+    def penalizer(out, lvl, rays_d):                         # exact batch-global semantics through gather_batch
+        full = [D.gather_batch(t, sizes) for t in (out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl], rays_d)]
+        return O.ins_penalizer(full[0], full[1], full[2], full[3], 0.05, 0.05)
+
+    torch.manual_seed(7)                                     # the jitter stream: identical on every rank
+    losses = []
+    for _ in range(2):
+        loss, nbytes = D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, INS, render=render,
+                                            mse=lambda a, b: ((a - b) ** 2).mean(),
+                                            criterion=lambda p, gt: O.ins_criterion(p, gt, INS)[0].sum(), penalizer=penalizer)
+        losses.append(float(loss))
+    flat = torch.cat([p.detach().reshape(-1) for p in mc.parameters() + mf.parameters()])
+    return losses, flat.numpy(), nbytes
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _train_two_steps())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_training_equals_single_process():
+    """Two gradient steps with jitter, a partially labelled batch (N_ins) and uneven slices: both ranks end with the
+    parameters a single process reaches on the whole batch (differences: f32 summation order of the all-reduce)."""
+    want_losses, want, nb0 = _train_two_steps()
+    assert nb0 == 0
+    _, _, sd_c, sd_f = _scene()
+    start = torch.cat([v.reshape(-1) for v in list(sd_c.values()) + list(sd_f.values())]).numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n_param = want.size
+    for rank, losses, flat, nbytes in res:
+        assert nbytes == 4 * n_param                        # ONE flat bucket with both models' gradients
+        assert np.allclose(losses, want_losses, rtol=1e-5), (losses, want_losses)
+        assert np.abs(flat - want).max() <= 1e-6, np.abs(flat - want).max()
+        assert np.abs(flat - start).max() >= 1e-3           # ... of steps that did move the weights
+    assert np.array_equal(res[0][2], res[1][2])            # the replicas stay bit-identical

@@ -1,0 +1,82 @@
+"""The ray-sharded training step (dm_nerf_amd.distributed.sharded_train_step, SURVEY 8(e) / BASELINE config 5) with the
+real HIP kernels: two ranks -- two processes sharing the box's one GPU, exchanging through gloo, which runs the same
+code path as RCCL up to the transport -- reach the parameters a single process reaches on the whole batch."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+INS, N, N_INS = 13, 131, 70          # 131 rays -> slices of 66 + 65; the last 70 rays carry labels (ScanNet convention)
+
+
+def _two_steps():
+    from dm_nerf_amd import distributed as D
+    from dm_nerf_amd.networks import dm_nerf as M
+    models = []
+    for seed in (71, 72):
+        m = M.DM_NeRF(8, 256, 63, 27, [4], INS)
+        m.load_state_dict(O.make_weights(seed, INS, gain=1.7, sigma_bias=0.3))
+        models.append(m.cuda().train())
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(35.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(9).choice(480 * 640, N, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]]).cuda()
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous().cuda()
+    g = torch.Generator().manual_seed(73)
+    target = torch.rand(N, 3, generator=g).cuda()
+    labels = torch.randint(0, 7, (N_INS,), generator=g).cuda()
+    opt = torch.optim.SGD([p for m in models for p in m.parameters()], lr=2e-2)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=N_INS, tolerance=0.05, deta_w=0.05)
+    torch.manual_seed(7)
+    torch.cuda.manual_seed(7)                               # the jitter stream: identical on every rank
+    losses = []
+    for _ in range(2):
+        loss, nbytes = D.sharded_train_step(rays, z, target, labels, models, args, opt, INS)
+        losses.append(float(loss))
+    flat = torch.cat([p.detach().reshape(-1) for m in models for p in m.parameters()]).cpu().numpy()
+    return losses, flat, nbytes
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _two_steps())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_training_step_equals_single_process():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    want_losses, want, nb0 = _two_steps()
+    assert nb0 == 0
+    start = torch.cat([v.reshape(-1) for seed in (71, 72) for v in O.make_weights(seed, INS, gain=1.7, sigma_bias=0.3).values()]).numpy()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, losses, flat, nbytes in res:
+        assert nbytes == 4 * want.size
+        assert np.allclose(losses, want_losses, rtol=2e-5), (losses, want_losses)
+        assert np.abs(flat - want).max() <= 2e-6, np.abs(flat - want).max()
+    assert np.abs(want - start).max() >= 1e-3
+    assert np.array_equal(res[0][2], res[1][2])
