@@ -67,52 +67,61 @@ def build_models(device):
     return pe, ve, mc.eval(), mf.eval()
 
 
-def train_leg(mc, mf, ro, rd, z, steps, dev):
-    """Secondary measurement: rays/s of one full optimisation step on a 4096-ray batch (64+128 samples,
+def train_leg(mc, mf, ro, rd, z, steps, dev, world=1):
+    """Secondary measurement: rays/s of one full optimisation step on a 4096-ray batch per GPU (64+128 samples,
     perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
     levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
     configs/dmsr/train/study.txt), the Hungarian-matched object-code loss ins_criterion on both levels (device
     kernels: the reference solves the assignment with scipy on the host), backward (composite_bwd,
-    dgrad, wgrad kernels), Adam(lr 5e-4).  Labels: a synthetic 9-object segmentation of the chunk."""
-    from dm_nerf_amd.networks import evaluator as E
-    from dm_nerf_amd.networks import penalizer as P
-    from dm_nerf_amd.networks import render as R
+    dgrad, wgrad kernels), Adam(lr 5e-4).  Labels: a synthetic 9-object segmentation of the batch.
+    world > 1 (weak scaling): ONE batch of world x 4096 rays, sharded over the ranks by
+    dm_nerf_amd.distributed.sharded_train_step -- batch-global losses on all-gathered rgb / ins, penalizer sums and
+    the 5.57 MB gradient bucket all-reduced over RCCL; ``ro`` / ``rd`` must then hold the same rays on every rank."""
+    from dm_nerf_amd import distributed as D
     mc.train(); mf.train()
     params = list(mc.parameters()) + list(mf.parameters())
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
     args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, tolerance=0.05, deta_w=0.05)
+    n = N_RAYS * world
     g = torch.Generator(device=dev).manual_seed(0)
-    target = torch.rand(N_RAYS, 3, device=dev, generator=g)
-    labels = torch.randint(0, 9, (N_RAYS,), device=dev, generator=g)
-    rays = torch.stack([ro[:N_RAYS], rd[:N_RAYS]])
+    target = torch.rand(n, 3, device=dev, generator=g)
+    labels = torch.randint(0, 9, (n,), device=dev, generator=g)
+    rays = torch.stack([ro[:n], rd[:n]])
+    assert rays.shape[1] == n and z.shape[0] == n
+    torch.manual_seed(0)                                # identical jitter streams on every rank
+    torch.cuda.manual_seed(0)
 
     def one():
-        out = R.dm_nerf(rays, None, None, mc, mf, z, args)
-        loss = E.img2mse(out['rgb_fine'], target) + E.img2mse(out['rgb_coarse'], target) \
-            + E.ins_criterion(out['ins_fine'], labels, INS_NUM)[0] + E.ins_criterion(out['ins_coarse'], labels, INS_NUM)[0] \
-            + P.ins_penalizer(out['raw_fine'], out['z_vals_fine'], out['depth_fine'], rays[1], args).sum() \
-            + P.ins_penalizer(out['raw_coarse'], out['z_vals_coarse'], out['depth_coarse'], rays[1], args).sum()
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        return loss
+        return D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, INS_NUM)[0]
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
     one(); one()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = one()
-    torch.cuda.synchronize()
+    fence()
     dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     mc.eval(); mf.eval()
-    flop = 2.0 * (2 * MAC_PER_SAMPLE + (MAC_PER_SAMPLE - 101248)) * (2 * S_COARSE + N_IMP) * N_RAYS
-    return {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "tflops": flop / dt / 1e12,
-            "frac_of_f32_mfma_peak": flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "final_loss": float(loss.detach()),
-            "batch_rays": N_RAYS, "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"}
+    flop = 2.0 * (2 * MAC_PER_SAMPLE + (MAC_PER_SAMPLE - 101248)) * (2 * S_COARSE + N_IMP) * n
+    return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop / dt / 1e12,
+            "frac_of_f32_mfma_peak": flop / dt / 1e12 / (F32_MFMA_PEAK_TFLOPS * world), "final_loss": float(loss.detach()),
+            "batch_rays": n, "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"
+                                     + (f"; one batch sharded over {world} ranks (sharded_train_step), weak scaling" if world > 1 else "")}
 
 
 def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
     """The same optimisation step on the oracle (CPU port: PyTorch autograd, scipy assignment, torch Adam) on a
-    bounded number of rays of the same chunk; one untimed step calibrates the sample size and warms up."""
+    bounded number of rays of the same chunk; a warm-up step and a calibration step on 128 rays choose the sample size."""
     from oracle import ref_cpu as O
     sdc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mc.state_dict().items()}
     sdf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mf.state_dict().items()}
@@ -131,6 +140,7 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
         opt.zero_grad(); loss.backward(); opt.step()
 
     n0 = 128
+    one(n0)                                              # warm-up (thread pools, autograd graph caches)
     t0 = time.perf_counter(); one(n0); t1 = time.perf_counter() - t0
     # (the step's cost grows faster than linearly with the batch -- autograd's saved activations fall out of cache)
     n = int(min(512, max(128, 0.4 * (seconds / max(t1, 1e-3)) * n0 // 128 * 128)))
@@ -250,6 +260,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    train_multi = None
+    if world > 1 and not a.no_train:
+        # every rank takes part; a failure here must not cost the headline line
+        try:
+            rows_t = -(-N_RAYS * world // W_IMG)
+            tro, trd = H.get_rays_k(H_IMG, W_IMG, K, c2w.to(dev), row0=0, nrows=rows_t)
+            zt = H.z_val_sample(N_RAYS * world, NEAR, FAR, S_COARSE, device=dev)
+            train_multi = train_leg(mc, mf, tro.reshape(-1, 3), trd.reshape(-1, 3), zt, a.train_steps, dev, world)
+        except Exception as e:                                  # noqa: BLE001
+            train_multi = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
         k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
@@ -287,6 +308,8 @@ def main():
             if tb is not None:
                 res["train"]["cpu_baseline"] = tb
                 res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
+        if train_multi is not None:
+            res["train"] = train_multi
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
