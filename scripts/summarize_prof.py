@@ -53,7 +53,10 @@ for sub in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     for r in csv.DictReader(open(p)):
         agg[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"== {sub} :: per-dispatch mean of each counter, grouped by (kernel, grid threads) ==")
-    for k, cs in sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values()))[:4]:
+    ranked = sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values()))
+    # the four largest, plus the MLP kernels whatever their rank (the roofline kernel's traffic is small by design)
+    rows = ranked[:4] + [kv for kv in ranked[4:] if kv[0][0].startswith(("mlp_", "wgrad_kernel"))]
+    for k, cs in rows:
         desc = "  ".join(f"{c}={sum(v) / len(v):.5g}" for c, v in sorted(cs.items()))
         n = len(next(iter(cs.values())))
         print(f"{k[0]:48s} grid={k[1]:>9d} n={n:>3d}  {desc}")
