@@ -332,12 +332,10 @@ extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_la
     const CrLayout w = cr_layout(N, ins_num);
     if (work_bytes < w.total) return dmn_fail(DMNERF_E_ARG, "ins_criterion: work buffer too small (%lld < %lld bytes)", (long long)work_bytes, (long long)w.total);
     const size_t lds = (size_t)(2 * w.L * ins_num + w.L) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)cr_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (CR_MAXC + 1) * CR_MAXC * 4 + (CR_MAXC + 1) * 4) != hipSuccess)
-            return dmn_check_launch("ins_criterion: hipFuncSetAttribute");
-        attr_done = true;
-    }
+    static DmnOncePerDevice once;
+    if (once.run([] { return hipFuncSetAttribute((const void*)cr_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 2 * (CR_MAXC + 1) * CR_MAXC * 4 + (CR_MAXC + 1) * 4); }) != hipSuccess)
+        return dmn_check_launch("ins_criterion: hipFuncSetAttribute");
     hipLaunchKernelGGL(cr_partial_kernel, dim3((unsigned)w.nch), dim3(CR_MAXC), lds, (hipStream_t)stream, d_pred, (const int*)d_labels, N, ins_num, (char*)d_work);
     int rc = dmn_check_launch("ins_criterion: partial sums");
     if (rc) return rc;

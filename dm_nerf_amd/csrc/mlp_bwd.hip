@@ -227,13 +227,10 @@ extern "C" int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, i
     constexpr size_t lds_bytes = (size_t)(RING_FLOATS + TAB_T_FLOATS) * sizeof(float);
 #define DMN_LAUNCH(OBI_)                                                                                          \
     {                                                                                                            \
-        static bool attr_done = false;                                                                           \
-        if (!attr_done) {                                                                                        \
-            if (hipFuncSetAttribute((const void*)mlp_bwd_kernel<OBI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds_bytes) != hipSuccess)                                               \
-                return dmn_check_launch("mlp_bwd_data: hipFuncSetAttribute");                                    \
-            attr_done = true;                                                                                    \
-        }                                                                                                        \
+        static DmnOncePerDevice once;                                                                                 \
+        if (once.run([] { return hipFuncSetAttribute((const void*)mlp_bwd_kernel<OBI_>,                              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess) \
+            return dmn_check_launch("mlp_bwd_data: hipFuncSetAttribute");                                       \
         hipLaunchKernelGGL(mlp_bwd_kernel<OBI_>, g, b, lds_bytes, (hipStream_t)stream, a);                        \
     }
     switch (a.L.OBI) {

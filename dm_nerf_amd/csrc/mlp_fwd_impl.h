@@ -305,13 +305,10 @@ int launch(const MlpArgs& a, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);      // 147 456 B: one workgroup per CU
 #define DMN_LAUNCH(OBI_)                                                                                              \
     {                                                                                                                \
-        static bool attr_done = false;                                                                               \
-        if (!attr_done) {                                                                                            \
-            if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>,                                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)       \
-                return dmn_check_launch("mlp_fwd: hipFuncSetAttribute");                                             \
-            attr_done = true;                                                                                        \
-        }                                                                                                            \
+        static DmnOncePerDevice once;                                                                                 \
+        if (once.run([] { return hipFuncSetAttribute((const void*)(mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>),                              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess) \
+            return dmn_check_launch("mlp_fwd: hipFuncSetAttribute");                                       \
         hipLaunchKernelGGL((mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>), g, b, lds_bytes, stream, a);                       \
     }
     switch (a.L.OBI) {

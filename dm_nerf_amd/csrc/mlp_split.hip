@@ -393,13 +393,10 @@ extern "C" int dmnerf_mlp_fwd_rays_split(const float* d_blob_split, int ins_num,
     constexpr size_t lds_bytes = (size_t)SP_LDS_FLOATS * sizeof(float);
 #define DMN_LAUNCH(OBX_)                                                                                                   \
     {                                                                                                                     \
-        static bool attr_done = false;                                                                                    \
-        if (!attr_done) {                                                                                                 \
-            if (hipFuncSetAttribute((const void*)mlp_split_kernel<OBX_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                    (int)lds_bytes) != hipSuccess)                                                        \
-                return dmn_check_launch("mlp_fwd_rays_split: hipFuncSetAttribute");                                       \
-            attr_done = true;                                                                                             \
-        }                                                                                                                 \
+        static DmnOncePerDevice once;                                                                                 \
+        if (once.run([] { return hipFuncSetAttribute((const void*)mlp_split_kernel<OBX_>,                              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess) \
+            return dmn_check_launch("mlp_fwd_rays_split: hipFuncSetAttribute");                                       \
         hipLaunchKernelGGL(mlp_split_kernel<OBX_>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, a);    \
     }
     switch (a.S.OBX) {
