@@ -61,6 +61,7 @@ SIGNATURES = {
     "dmnerf_manipulator_render": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_z_val_lerp": (c_int, [c_vp, c_float, c_float, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_sort_rows": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "dmnerf_ins_label_conf": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_exchanger": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_penalizer_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp]),
     "dmnerf_penalizer_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp]),
@@ -97,7 +98,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 2:
+    if lib.dmnerf_abi_version() != 3:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

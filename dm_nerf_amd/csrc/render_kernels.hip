@@ -829,6 +829,30 @@ extern "C" int dmnerf_sort_rows(const float* d_in, int64_t N, int K, float* d_ou
     return dmn_check_launch("sort_rows");
 }
 
+// ins_eval's per-pixel label and confidence (networks/evaluator.py:127-137): label = argmax over the object channels
+// (first maximum wins, like torch.argmax on CPU), conf = that maximum.  One thread per ray; a row is <= 94 floats.
+__global__ void label_conf_kernel(const float* __restrict__ ins, int64_t N, int C, int64_t* __restrict__ label, float* __restrict__ conf) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* x = ins + n * C;
+    int best = 0;
+    float bv = x[0];
+    for (int c = 1; c < C; ++c) {
+        const float v = x[c];
+        if (v > bv) { bv = v; best = c; }
+    }
+    label[n] = best;
+    if (conf) conf[n] = bv;
+}
+
+extern "C" int dmnerf_ins_label_conf(const float* d_ins, int64_t N, int C, int64_t* d_label, float* d_conf, void* stream) {
+    if (N < 0 || C < 1) return dmn_fail(DMNERF_E_ARG, "ins_label_conf: bad N=%lld C=%d", (long long)N, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_ins || !d_label) return dmn_fail(DMNERF_E_ARG, "ins_label_conf: null pointer");
+    hipLaunchKernelGGL(label_conf_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, d_ins, N, C, d_label, d_conf);
+    return dmn_check_launch("ins_label_conf");
+}
+
 extern "C" int dmnerf_exchanger(float* d_ori_raw, const float* const* h_tar_raws, const float* d_ori_acc,
                                 const float* const* h_tar_accs, const int* h_labels, int T, int64_t N, int S, int C,
                                 int64_t* d_ori_label, int64_t* d_tar_label, void* stream) {

@@ -215,13 +215,15 @@ def _default_render_chunk(rays_o, rays_d, z, models, args):
 
 
 def render_frame(H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64,
-                 raygen=None, render_chunk=None, z_fn=None):
+                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None):
     """Full-frame render, rows sharded over ranks, one all-gather per output.
 
     Mirrors the per-pose body of ``render_test`` (networks/tester.py:58-85): same chunking
     (``chunk`` = N_test rays, ragged last chunk), ``args.perturb`` is the caller's business
     (test scripts set it False, test_dmsr.py:86).  Returns ``rgb [H,W,3]``, ``ins [H,W,ins_num]``,
-    ``depth [H,W]`` on every rank.
+    ``depth [H,W]`` on every rank.  ``labels_only=True``: the object map is reduced on the device to what ``ins_eval``
+    consumes (evaluator.py:127-137) -- ``label [H,W]`` int64 = argmax, ``conf [H,W]`` = max -- before the gather, and
+    ``(rgb, label, conf, depth)`` is returned: 12 instead of 4*ins_num bytes per pixel cross the links.
     """
     rank, world = world_info()
     raygen = raygen or _default_raygen
@@ -246,5 +248,13 @@ def render_frame(H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64
             depth = torch.empty(n_local, dtype=c_depth.dtype, device=dev)
         rgb[s:e], ins[s:e], depth[s:e] = c_rgb, c_ins, c_depth
     sizes = [row_band(H, r, world)[1] * W for r in range(world)]
+    if labels_only:
+        if label_conf is None:
+            from .networks import evaluator
+            label_conf = evaluator.ins_label_conf
+        label, conf = label_conf(ins)
+        rgb, depth = all_gather_cat(rgb, sizes), all_gather_cat(depth, sizes)
+        label, conf = all_gather_cat(label, sizes), all_gather_cat(conf, sizes)
+        return rgb.reshape(H, W, 3), label.reshape(H, W), conf.reshape(H, W), depth.reshape(H, W)
     rgb, ins, depth = all_gather_cat(rgb, sizes), all_gather_cat(ins, sizes), all_gather_cat(depth, sizes)
     return rgb.reshape(H, W, 3), ins.reshape(H, W, -1), depth.reshape(H, W)

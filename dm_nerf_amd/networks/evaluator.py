@@ -3,7 +3,8 @@
 
 ``ins_criterion`` runs entirely on the GPU stream (csrc/criterion.hip): the reference moves the cost matrix to the
 host for ``scipy.optimize.linear_sum_assignment`` and syncs twice per step.  The metrics half of
-the file (``calculate_ap``, ``ins_eval``) is evaluation tooling and stays with the reference.
+the file (``calculate_ap``, ``ins_eval``) is evaluation tooling and stays with the reference, except the per-pixel
+label / confidence every rendered frame needs (``ins_label_conf``), which the frame driver computes on the device.
 """
 import torch
 
@@ -57,3 +58,17 @@ def ins_criterion(pred_ins, gt_labels, ins_num):
         raise ValueError("ins_criterion: one label per ray")
     out = _InsCriterion.apply(pred, labels, int(ins_num))
     return out[0], out[1], out[2], out[3]
+
+
+def ins_label_conf(pred_ins):
+    """The first two lines of ``ins_eval`` (networks/evaluator.py:127-137): ``pred_label = argmax(pred_ins, -1)`` (int64,
+    first maximum) and ``pred_conf_mask = max(pred_ins, -1)`` for ``pred_ins [..., ins_num]``, on the device."""
+    x = _lib.f32(pred_ins)
+    _lib.require_gpu(x)
+    C = x.shape[-1]
+    flat = x.reshape(-1, C)
+    label = torch.empty(flat.shape[0], dtype=torch.int64, device=x.device)
+    conf = torch.empty(flat.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dmnerf_ins_label_conf(_lib.ptr(flat), flat.shape[0], C, _lib.ptr(label), _lib.ptr(conf), _lib.stream()),
+               "dmnerf_ins_label_conf")
+    return label.reshape(x.shape[:-1]), conf.reshape(x.shape[:-1])

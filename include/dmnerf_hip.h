@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 2
+#define DMNERF_ABI_VERSION 3
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -228,6 +228,11 @@ int dmnerf_sort_rows(const float* d_in, int64_t N, int K, float* d_out, void* st
 int dmnerf_exchanger(float* d_ori_raw, const float* const* h_tar_raws, const float* d_ori_acc,
                      const float* const* h_tar_accs, const int* h_labels, int T, int64_t N, int S, int C,
                      int64_t* d_ori_label, int64_t* d_tar_label, void* stream);
+
+/* ---- evaluator.py ins_eval, the part every frame needs (networks/evaluator.py:127-137) ----------------
+ * d_label [N] int64 = argmax over the C object channels of d_ins [N,C] (first maximum, like torch.argmax on CPU);
+ * d_conf [N] (nullable) = that maximum (np.max(pred_ins, -1)).                                                    */
+int dmnerf_ins_label_conf(const float* d_ins, int64_t N, int C, int64_t* d_label, float* d_conf, void* stream);
 
 /* ---- penalizer.py (the consumer of raw / z_vals / depth) ---------------------------
  * emptiness_penalizer (networks/penalizer.py:5-55) fused: _fwd writes per-ray partial sums

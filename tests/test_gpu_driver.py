@@ -48,6 +48,26 @@ def test_render_frame_ragged_chunks_equal_one_shot_render(A):
     assert torch.equal(ins.reshape(-1, 13), one['ins_fine'])
     assert torch.equal(depth.reshape(-1), one['depth_fine'])
     assert torch.equal(ins.argmax(-1).reshape(-1), one['ins_fine'].argmax(-1))
+    with torch.no_grad():
+        rgb2, label, conf, depth2 = A.D.render_frame(H, W, K, c2w, (mc, mf), 4.0, 15.0, args, chunk=50, n_samples=64, labels_only=True)
+    assert torch.equal(rgb2, rgb) and torch.equal(depth2, depth)
+    assert label.dtype == torch.int64 and torch.equal(label.cpu(), ins.cpu().argmax(-1))        # ins_eval runs on ins.cpu()
+    assert torch.equal(conf.cpu(), ins.cpu().max(-1).values)
+
+
+def test_ins_label_conf_ties_and_wide_rows(A):
+    """First maximum wins (torch.argmax on CPU, what ins_eval sees), for the three object-code widths of the configs."""
+    from dm_nerf_amd.networks import evaluator as E
+    g = torch.Generator().manual_seed(3)
+    for C in (13, 59, 93):
+        x = torch.rand(1000, C, generator=g)
+        x[::7] = torch.round(x[::7] * 4) / 4                     # many exact ties
+        x[5] = 0.25
+        label, conf = E.ins_label_conf(x.cuda().reshape(10, 100, C))
+        assert label.shape == (10, 100) and torch.equal(label.cpu().reshape(-1), x.argmax(-1))
+        assert torch.equal(conf.cpu().reshape(-1), x.max(-1).values)
+    with pytest.raises(RuntimeError):
+        E.ins_label_conf(torch.rand(4, 13))                      # CPU tensors are refused: there is no CPU path
 
 
 def test_render_step_is_graph_capturable(A):
