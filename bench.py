@@ -286,7 +286,7 @@ def main():
                        "rays_per_step_per_gpu": N_RAYS, "parallelism": f"ray-sharded x{world}" + (" + RCCL all-gather of tiles" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": "mlp_fwd_kernel<1,false> (fine network, 4096x192 samples)", "kernel_ms": k_ms,
+                         "kernel": "mlp_fwd_kernel<1,false,false,false> (fine network, 4096x192 samples)", "kernel_ms": k_ms,
                          "flop_per_launch": flop_per_launch},
             "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
         }
