@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     p.add_argument("--train-steps", type=int, default=5)
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
+    p.add_argument("--ins-num", type=int, default=INS_NUM,
+                   help="object-code width: 13 = DM-SR 'study' (the headline config); 59 / 93 = Replica office_0 / room_0 (BASELINE config 2)")
     return p.parse_args()
 
 
@@ -196,7 +198,10 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
 
 
 def main():
+    global INS_NUM, MAC_PER_SAMPLE
     a = parse()
+    INS_NUM = a.ins_num
+    MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -281,12 +286,12 @@ def main():
             "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DM-SR 'study' 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
-                                   "4096-ray chunk per step per GPU, det sampling, ins_num=13, random-init weights",
+            "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,") + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
+                                   f"4096-ray chunk per step per GPU, det sampling, ins_num={INS_NUM}, random-init weights",
                        "rays_per_step_per_gpu": N_RAYS, "parallelism": f"ray-sharded x{world}" + (" + RCCL all-gather of tiles" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": "mlp_fwd_kernel<1,false,false,false> (fine network, 4096x192 samples)", "kernel_ms": k_ms,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic() if INS_NUM == 13 else None,
+                         "kernel": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,false,false> (fine network, 4096x192 samples)", "kernel_ms": k_ms,
                          "flop_per_launch": flop_per_launch},
             "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
         }
