@@ -260,6 +260,34 @@ def test_dm_nerf_vs_oracle_1024_rays(A):
     assert flips <= 1e-3 + 1.0 / 1024, flips
 
 
+@pytest.mark.parametrize("ins_num", [59, 93])
+def test_dm_nerf_vs_oracle_wide_object_heads(A, ins_num):
+    """BASELINE config 2 (Replica office_0 / room_0: 59 / 93 object codes, two / three 32-row blocks in the ins_linear
+    stage of the rays kernel): the whole dm_nerf dict against the oracle on 96 rays."""
+    sd_c = O.make_weights(100 + ins_num, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(200 + ins_num, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(75.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(ins_num).choice(480 * 640, 96, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    z = O.z_val_sample(96, 0.0, 4.7, 64).contiguous()                  # configs/replica/train/office_0.txt:13-14
+    with torch.no_grad():
+        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0.)
+        args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+        got = {k: cpu(v) for k, v in A.R.dm_nerf(dev(rays), None, None, mc, mf, dev(z), args).items()}
+        # fine network on the oracle's own depths: the inverse-CDF step is compared on golden inputs elsewhere
+        raw_f = cpu(A.R.run_network(mf, dev(rays[0]), dev(rays[1]), dev(want['z_vals_fine'])))
+    assert got['raw_fine'].shape == (96, 192, 4 + ins_num + 1) and got['ins_fine'].shape == (96, ins_num)
+    assert maxrel(got['raw_coarse'], want['raw_coarse']) <= 1e-5
+    assert maxrel(raw_f, want['raw_fine']) <= 1e-5
+    assert torch.allclose(got['rgb_coarse'], want['rgb_coarse'], rtol=2e-6, atol=2e-6)
+    assert torch.allclose(got['ins_coarse'], want['ins_coarse'], rtol=2e-6, atol=2e-6)
+    assert torch.equal(got['ins_coarse'].argmax(-1), want['ins_coarse'].argmax(-1))
+    mse = float(((got['rgb_fine'] - want['rgb_fine']) ** 2).mean())
+    assert -10 * np.log10(max(mse, 1e-20)) >= 80.0
+
+
 def test_full_size_properties(A):
     """BASELINE config 1 size (4096 rays x 64+128) without the oracle: structural invariants."""
     ins_num = 13
