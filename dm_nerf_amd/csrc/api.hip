@@ -41,6 +41,7 @@ extern "C" int dmnerf_device_count(void) {
 // dm_nerf inference (networks/render.py:31-96): every stage enqueued on one stream, no sync.
 extern "C" int dmnerf_render_rays_fwd(const dmnerf_render_args* a, void* stream) {
     if (!a) return dmn_fail(DMNERF_E_ARG, "render_rays_fwd: null args");
+    if (a->N == 0 && a->S >= 3 && a->n_imp >= 1) return DMNERF_OK;      // an empty chunk: its buffers may be null
     if (!a->d_blob_coarse || !a->d_blob_fine || !a->d_rays_o || !a->d_rays_d || !a->d_z_in || !a->d_u ||
         !a->d_z_coarse || !a->d_raw_coarse || !a->d_rgb_coarse || !a->d_depth_coarse || !a->d_ins_coarse ||
         !a->d_z_fine || !a->d_raw_fine || !a->d_rgb_fine || !a->d_depth_fine || !a->d_ins_fine || !a->d_weights_ws)

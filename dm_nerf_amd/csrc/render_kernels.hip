@@ -676,23 +676,26 @@ extern "C" int dmnerf_raygen(int H, int W, const float* h_intr, const float* h_c
 }
 
 extern "C" int dmnerf_z_val_sample(const float* d_t, float near_, float far_, int64_t N, int S, float* d_z, void* stream) {
-    if (!d_t || !d_z || N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "z_val_sample: bad argument");
-    if (N == 0) return DMNERF_OK;
+    if (N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "z_val_sample: bad N=%lld S=%d", (long long)N, S);
+    if (N == 0) return DMNERF_OK;                        // an empty batch is legal and has null data pointers
+    if (!d_t || !d_z) return dmn_fail(DMNERF_E_ARG, "z_val_sample: null pointer");
     hipLaunchKernelGGL(zvals_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, (hipStream_t)stream, d_t, near_, far_, N * S, S, d_z);
     return dmn_check_launch("z_val_sample");
 }
 
 extern "C" int dmnerf_stratify(const float* d_z_in, const float* d_t_rand, int64_t N, int S, float* d_z_out, void* stream) {
-    if (!d_z_in || !d_t_rand || !d_z_out || N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "stratify: bad argument");
-    if (d_z_in == d_z_out) return dmn_fail(DMNERF_E_ARG, "stratify: in-place not supported (reads neighbours)");
+    if (N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "stratify: bad N=%lld S=%d", (long long)N, S);
     if (N == 0) return DMNERF_OK;
+    if (!d_z_in || !d_t_rand || !d_z_out) return dmn_fail(DMNERF_E_ARG, "stratify: null pointer");
+    if (d_z_in == d_z_out) return dmn_fail(DMNERF_E_ARG, "stratify: in-place not supported (reads neighbours)");
     hipLaunchKernelGGL(stratify_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, (hipStream_t)stream, d_z_in, d_t_rand, N * S, S, d_z_out);
     return dmn_check_launch("stratify");
 }
 
 extern "C" int dmnerf_embed(const float* d_x, int64_t M, int L, float* d_out, void* stream) {
-    if (!d_x || !d_out || M < 0 || L < 0 || L > 30) return dmn_fail(DMNERF_E_ARG, "embed: bad argument");
+    if (M < 0 || L < 0 || L > 30) return dmn_fail(DMNERF_E_ARG, "embed: bad M=%lld L=%d", (long long)M, L);
     if (M == 0) return DMNERF_OK;
+    if (!d_x || !d_out) return dmn_fail(DMNERF_E_ARG, "embed: null pointer");
     hipLaunchKernelGGL(embed_kernel, dim3(blocks_for(M * 3, 256)), dim3(256), 0, (hipStream_t)stream, d_x, M, L, d_out);
     return dmn_check_launch("embed");
 }
@@ -700,10 +703,10 @@ extern "C" int dmnerf_embed(const float* d_x, int64_t M, int L, float* d_out, vo
 extern "C" int dmnerf_composite_fwd(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N,
                                     int S, int C, float* d_rgb_map, float* d_weights, float* d_depth_map,
                                     float* d_ins_map, void* stream) {
-    if (!d_raw || !d_z || !d_rays_d || !d_rgb_map || !d_weights || !d_depth_map || !d_ins_map)
-        return dmn_fail(DMNERF_E_ARG, "composite_fwd: null pointer");
     if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "composite_fwd: bad N=%lld S=%d (max %d) C=%d", (long long)N, S, MAX_S, C);
     if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_rays_d || !d_rgb_map || !d_weights || !d_depth_map || !d_ins_map)
+        return dmn_fail(DMNERF_E_ARG, "composite_fwd: null pointer");
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
                        d_raw, d_z, d_rays_d, N, S, C, C - 1, d_rgb_map, d_weights, d_depth_map, d_ins_map);
     return dmn_check_launch("composite_fwd");
@@ -724,9 +727,9 @@ extern "C" int dmnerf_manipulator_render(const float* d_raw, const float* d_z, c
 extern "C" int dmnerf_sample_pdf(const float* d_bins, const float* d_weights, const float* d_u, int64_t u_row_stride,
                                  int64_t N, int nb, int n_samples, float* d_samples, float* d_cdf, int64_t* d_inds,
                                  void* stream) {
-    if (!d_bins || !d_weights || !d_u || !d_samples) return dmn_fail(DMNERF_E_ARG, "sample_pdf: null pointer");
     if (N < 0 || nb < 2 || nb > MAX_NB || n_samples < 1) return dmn_fail(DMNERF_E_ARG, "sample_pdf: bad N=%lld nb=%d n_samples=%d", (long long)N, nb, n_samples);
     if (N == 0) return DMNERF_OK;
+    if (!d_bins || !d_weights || !d_u || !d_samples) return dmn_fail(DMNERF_E_ARG, "sample_pdf: null pointer");
     SampleArgs a{};
     a.bins = d_bins; a.weights = d_weights; a.u = d_u; a.u_row_stride = u_row_stride; a.N = N; a.nb = nb;
     a.n_samples = n_samples; a.samples = d_samples; a.cdf_out = d_cdf; a.inds_out = d_inds;
@@ -736,9 +739,9 @@ extern "C" int dmnerf_sample_pdf(const float* d_bins, const float* d_weights, co
 
 extern "C" int dmnerf_sample_from_cdf(const float* d_bins, const float* d_cdf, const float* d_u, int64_t u_row_stride,
                                       int64_t N, int nb, int n_samples, float* d_samples, int64_t* d_inds, void* stream) {
-    if (!d_bins || !d_cdf || !d_u || !d_samples) return dmn_fail(DMNERF_E_ARG, "sample_from_cdf: null pointer");
     if (N < 0 || nb < 2 || nb > MAX_NB || n_samples < 1) return dmn_fail(DMNERF_E_ARG, "sample_from_cdf: bad sizes");
     if (N == 0) return DMNERF_OK;
+    if (!d_bins || !d_cdf || !d_u || !d_samples) return dmn_fail(DMNERF_E_ARG, "sample_from_cdf: null pointer");
     SampleArgs a{};
     a.bins = d_bins; a.cdf_in = d_cdf; a.u = d_u; a.u_row_stride = u_row_stride; a.N = N; a.nb = nb;
     a.n_samples = n_samples; a.samples = d_samples; a.inds_out = d_inds;
@@ -749,10 +752,10 @@ extern "C" int dmnerf_sample_from_cdf(const float* d_bins, const float* d_cdf, c
 extern "C" int dmnerf_importance_resample(const float* d_z_coarse, const float* d_weights_coarse, const float* d_u,
                                           int64_t u_row_stride, int64_t N, int S, int n_imp, float* d_z_fine,
                                           float* d_z_samples, void* stream) {
-    if (!d_z_coarse || !d_weights_coarse || !d_u || !d_z_fine) return dmn_fail(DMNERF_E_ARG, "importance_resample: null pointer");
     if (N < 0 || S < 3 || S - 1 > MAX_NB || n_imp < 1 || S + n_imp > MAX_MERGE)
         return dmn_fail(DMNERF_E_ARG, "importance_resample: bad N=%lld S=%d n_imp=%d", (long long)N, S, n_imp);
     if (N == 0) return DMNERF_OK;
+    if (!d_z_coarse || !d_weights_coarse || !d_u || !d_z_fine) return dmn_fail(DMNERF_E_ARG, "importance_resample: null pointer");
     SampleArgs a{};
     a.z_coarse = d_z_coarse; a.w_coarse = d_weights_coarse; a.u = d_u; a.u_row_stride = u_row_stride; a.N = N;
     a.nb = S - 1; a.n_samples = n_imp; a.S = S; a.samples = d_z_samples; a.z_fine = d_z_fine;
@@ -815,8 +818,9 @@ extern "C" int dmnerf_raygen_select(int H, int W, const float* h_intr, const flo
 }
 
 extern "C" int dmnerf_z_val_lerp(const float* d_t, float near_, float far_, int64_t N, int S, float* d_z, void* stream) {
-    if (!d_t || !d_z || N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "z_val_lerp: bad argument");
+    if (N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "z_val_lerp: bad N=%lld S=%d", (long long)N, S);
     if (N == 0) return DMNERF_OK;
+    if (!d_t || !d_z) return dmn_fail(DMNERF_E_ARG, "z_val_lerp: null pointer");
     hipLaunchKernelGGL(zlerp_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, (hipStream_t)stream, d_t, near_, far_, N * S, S, d_z);
     return dmn_check_launch("z_val_lerp");
 }

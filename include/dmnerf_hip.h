@@ -15,6 +15,8 @@
  *     path, and launches only on the `stream` it is given (hipStream_t passed as void*),
  *     so every call is graph-capturable.
  *   - return 0 on success; negative on error (DMNERF_E_*), message via dmnerf_last_error().
+ *   - sizes are validated first; an EMPTY batch (N == 0 rays / M == 0 rows) is legal, returns 0 without launching
+ *     and without looking at the data pointers (an empty tensor's pointer is null).
  *   - N rays, S samples per ray, C = ins_num + 1 object logits, raw row = [r g b sigma | C logits].
  */
 #ifndef DMNERF_HIP_H

@@ -346,6 +346,31 @@ def test_errors_are_loud(A):
                          torch.ones(2, 3, device="cuda"))    # S beyond the kernel's per-ray staging
 
 
+def test_empty_and_single_ray_batches(A):
+    """N = 0 (an empty chunk: every entry point returns immediately) and N = 1 (one ray fills 1/32 of one wave's
+    sample tile; the other lanes compute on clamped duplicates and store nothing)."""
+    ins_num = 13
+    sd_c, sd_f = O.make_weights(81, ins_num, gain=1.7, sigma_bias=0.3), O.make_weights(82, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        out = A.R.dm_nerf(torch.zeros(2, 0, 3, device="cuda"), None, None, mc, mf, torch.zeros(0, 64, device="cuda"), args)
+        torch.cuda.synchronize()
+        assert out['rgb_fine'].shape == (0, 3) and out['raw_fine'].shape == (0, 192, 18) and out['ins_fine'].shape == (0, 13)
+        rgb, w, depth, ins = A.R.render_train(torch.zeros(0, 64, 18, device="cuda"), torch.zeros(0, 64, device="cuda"), torch.zeros(0, 3, device="cuda"))
+        assert rgb.shape == (0, 3) and w.shape == (0, 64) and depth.shape == (0,) and ins.shape == (0, 13)
+        assert A.H.sample_pdf(torch.zeros(0, 63, device="cuda"), torch.zeros(0, 62, device="cuda"), 128, det=True).shape == (0, 128)
+        K = O.dmsr_intrinsics(480, 640)
+        ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(10.0, -65.0, 7.0))
+        rays = torch.stack([ro.reshape(-1, 3)[123456:123457], rd.reshape(-1, 3)[123456:123457]])
+        z = O.z_val_sample(1, 4.0, 15.0, 64).contiguous()
+        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0.)
+        got = {k: cpu(v) for k, v in A.R.dm_nerf(dev(rays), None, None, mc, mf, dev(z), args).items()}
+    assert maxrel(got['raw_coarse'], want['raw_coarse']) <= 1e-5
+    assert torch.allclose(got['rgb_coarse'], want['rgb_coarse'], rtol=2e-6, atol=2e-6)
+    assert torch.allclose(got['rgb_fine'], want['rgb_fine'], atol=1e-4)
+
+
 def test_get_select_full_same_rng_stream_as_reference(A, golden):
     """identical numpy stream => identical pixels, targets and rays."""
     g = golden("select")
