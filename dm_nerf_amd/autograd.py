@@ -157,6 +157,9 @@ class CompositeFunction(torch.autograd.Function):
         return d_raw, None, None
 
 
+MAX_TRAIN_SAMPLES = 1048576          # DMNERF_MAX_TRAIN_SAMPLES (include/dmnerf_hip.h)
+
+
 def _params(model):
     return [p for _, p in model.named_parameters()]
 
@@ -166,7 +169,16 @@ def run_network_train(model, rays_o, rays_d, z):
     rays_o, rays_d, z = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3)), _lib.f32(z)
     _lib.require_gpu(rays_o, rays_d, z)
     model._check_supported()
-    return MLPRaysFunction.apply(model, rays_o, rays_d, z, *_params(model))
+    N, S = z.shape
+    max_rays = max(1, MAX_TRAIN_SAMPLES // S)
+    if N <= max_rays:
+        return MLPRaysFunction.apply(model, rays_o, rays_d, z, *_params(model))
+    # a training launch addresses its saved-activation workspace with 32-bit byte offsets (DMNERF_MAX_TRAIN_SAMPLES in
+    # include/dmnerf_hip.h): larger batches run as several launches, each with its own workspace; autograd adds the
+    # parameter gradients of the pieces (rays are independent, so this is the same sum in a different order)
+    params = _params(model)
+    return torch.cat([MLPRaysFunction.apply(model, rays_o[s:s + max_rays], rays_d[s:s + max_rays], z[s:s + max_rays], *params)
+                      for s in range(0, N, max_rays)], 0)
 
 
 def render_train_train(raw, z_vals, rays_d):

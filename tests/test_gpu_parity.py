@@ -318,6 +318,30 @@ def test_full_size_properties(A):
     assert torch.equal(rgb, out['rgb_fine']) and torch.equal(dep, out['depth_fine']) and torch.equal(ins, out['ins_fine'])
 
 
+def test_one_call_beyond_2_31_elements_equals_chunked(A):
+    """Maximum sizes: 700 001 rays in ONE dm_nerf call -- raw_fine has 2.42e9 elements (> 2^31) and 9.7 GB (> 2^32 bytes
+    behind one base pointer), N is not a multiple of the 32-sample tile -- equals the 4096-ray chunks the drivers use,
+    bit for bit: at the start, across the 2^31-element boundary (ray 621 378) and in the ragged tail."""
+    ins_num, N = 13, 700001
+    mc = model_from(A, O.make_weights(23, ins_num, gain=1.7, sigma_bias=0.3), ins_num)
+    mf = model_from(A, O.make_weights(24, ins_num, gain=1.7, sigma_bias=0.3), ins_num)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = A.H.get_rays_k(480, 640, K, dev(O.pose_spherical(20.0, -65.0, 7.0)))
+    idx = torch.arange(N, device="cuda") % (480 * 640)
+    ro, rd = ro.reshape(-1, 3)[idx].contiguous(), rd.reshape(-1, 3)[idx].contiguous()
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        big = A.R.dm_nerf(torch.stack([ro, rd]), None, None, mc, mf, A.H.z_val_sample(N, 4.0, 15.0, 64), args)
+        assert big['raw_fine'].numel() > 2 ** 31
+        for s0, n in ((0, 4096), (619520, 4096), (N - 2913, 2913)):
+            part = A.R.dm_nerf(torch.stack([ro[s0:s0 + n], rd[s0:s0 + n]]), None, None, mc, mf, A.H.z_val_sample(n, 4.0, 15.0, 64), args)
+            for k in ('raw_coarse', 'raw_fine', 'z_vals_fine', 'rgb_fine', 'ins_fine', 'depth_fine', 'rgb_coarse'):
+                assert torch.equal(big[k][s0:s0 + n], part[k]), (k, s0)
+        assert bool(torch.isfinite(big['rgb_fine']).all())
+        # the frame repeats: ray i and ray i + 307200 are the same ray
+        assert torch.equal(big['rgb_fine'][:85601], big['rgb_fine'][614400:])
+
+
 def test_create_nerf_and_state_dict_roundtrip(A):
     args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256,
                                  ins_num=13, device=torch.device("cuda:0"))

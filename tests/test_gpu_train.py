@@ -169,6 +169,41 @@ def test_dm_nerf_training_grads_vs_oracle(A):
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in mc.parameters())   # z_samples.detach() (render.py:68)
 
 
+def test_large_training_batch_equals_sum_of_chunks(A):
+    """Maximum sizes on the training side: one dm_nerf + backward over 12 001 rays (2.3 M fine samples: beyond the
+    1 048 576 samples one training launch addresses, so the fine network runs as three launches behind the same call;
+    N is not a multiple of the 32-sample tile) gives the gradients of the same rays taken 4096 at a time -- the loss is
+    a sum over rays, so the chunk gradients add up (f32 summation order aside)."""
+    ins_num, N = 13, 12001
+    sd_c = O.make_weights(91, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(92, ins_num, gain=1.7, sigma_bias=0.3)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(55.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(13).choice(480 * 640, N, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).cuda()
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous().cuda()
+    g = torch.Generator().manual_seed(93)
+    c_rgb, c_ins = torch.randn(N, 3, generator=g).cuda(), torch.randn(N, ins_num, generator=g).cuda()
+    args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None)
+
+    def grads(chunks):
+        mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+        for s0, n in chunks:
+            sl = slice(s0, s0 + n)
+            out = A.R.dm_nerf(rays[:, sl].contiguous(), None, None, mc, mf, z[sl].contiguous(), args)
+            ((out['rgb_fine'] * c_rgb[sl]).sum() + (out['rgb_coarse'] * c_rgb[sl]).sum()
+             + (out['ins_fine'] * c_ins[sl]).sum() + (out['ins_coarse'] * c_ins[sl]).sum()).backward()
+            del out
+        return torch.cat([p.grad.reshape(-1) for m in (mc, mf) for p in m.parameters()]).double().cpu()
+
+    whole = grads([(0, N)])
+    parts = grads([(0, 4096), (4096, 4096), (8192, N - 8192)])
+    assert bool(torch.isfinite(whole).all()) and float(whole.abs().max()) > 0
+    rel = float((whole - parts).norm() / parts.norm())
+    assert rel <= 1e-5, rel
+    assert float((whole - parts).abs().max()) <= 1e-4 * float(parts.abs().max())
+
+
 def test_adam_steps_follow_the_oracle_trajectory(A):
     """Three optimiser steps of the reference recipe (Adam lr 5e-4, img2mse on both levels + an ins term)."""
     ins_num, N = 13, 32
