@@ -370,6 +370,34 @@ def test_errors_are_loud(A):
                          torch.ones(2, 3, device="cuda"))    # S beyond the kernel's per-ray staging
 
 
+@pytest.mark.parametrize("S,n_imp,N", [(40, 24, 50), (16, 200, 7), (100, 1, 33)])
+def test_dm_nerf_with_unusual_sample_counts(A, S, n_imp, N):
+    """The shipped configs use 64 + 128 samples; the path itself takes any S >= 3 and N_importance >= 1
+    (N_samples / N_importance are config values, config.py:41-43).  Whole dict against the oracle."""
+    ins_num = 13
+    sd_c, sd_f = O.make_weights(83, ins_num, gain=1.7, sigma_bias=0.3), O.make_weights(84, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(15.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(S).choice(480 * 640, N, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    z = O.z_val_sample(N, 4.0, 15.0, S).contiguous()
+    args = types.SimpleNamespace(perturb=False, N_importance=n_imp, is_train=False, N_ins=None)
+    with torch.no_grad():
+        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0., N_importance=n_imp)
+        got = {k: cpu(v) for k, v in A.R.dm_nerf(dev(rays), None, None, mc, mf, dev(z), args).items()}
+        raw_f = cpu(A.R.run_network(mf, dev(rays[0]), dev(rays[1]), dev(want['z_vals_fine'])))
+    assert got['raw_fine'].shape == (N, S + n_imp, 18) and got['z_vals_fine'].shape == (N, S + n_imp)
+    assert maxrel(got['raw_coarse'], want['raw_coarse']) <= 1e-5
+    assert maxrel(raw_f, want['raw_fine']) <= 1e-5
+    assert torch.allclose(got['rgb_coarse'], want['rgb_coarse'], rtol=2e-6, atol=2e-6)
+    assert torch.allclose(got['depth_coarse'], want['depth_coarse'], rtol=2e-6, atol=2e-6)
+    zf = got['z_vals_fine']
+    assert bool((zf[:, 1:] >= zf[:, :-1]).all())
+    assert float(((zf - want['z_vals_fine']).abs() <= 1e-4).float().mean()) >= 0.999
+    assert torch.allclose(got['rgb_fine'], want['rgb_fine'], atol=2e-3)
+
+
 def test_empty_and_single_ray_batches(A):
     """N = 0 (an empty chunk: every entry point returns immediately) and N = 1 (one ray fills 1/32 of one wave's
     sample tile; the other lanes compute on clamped duplicates and store nothing)."""
