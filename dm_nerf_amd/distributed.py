@@ -258,3 +258,38 @@ def render_frame(H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64
         return rgb.reshape(H, W, 3), label.reshape(H, W), conf.reshape(H, W), depth.reshape(H, W)
     rgb, ins, depth = all_gather_cat(rgb, sizes), all_gather_cat(ins, sizes), all_gather_cat(depth, sizes)
     return rgb.reshape(H, W, 3), ins.reshape(H, W, -1), depth.reshape(H, W)
+
+
+def render_path(render_poses, hwk, models, args, gt_imgs=None, crop_mask=None, labels_only=False, **frame_kw):
+    """The pose loop of ``render_test`` (networks/tester.py:55-90) without its file output and CPU metrics: every pose of
+    ``render_poses [P,3or4,4]`` through ``render_frame`` (rows sharded over the ranks, chunks of ``args.N_test`` rays),
+    the ScanNet ``crop_mask`` applied as the reference applies it (:78-82: the pixels with mask 1, reshaped to
+    ``args.crop_height x args.crop_width``), and, given ``gt_imgs [P,h,w,3]``, the per-pose PSNR on the device
+    (data_range 1, what ``skimage.metrics.peak_signal_noise_ratio`` computes at :89).
+
+    Returns a dict of stacked device tensors: ``rgb [P,h,w,3]``, ``depth [P,h,w]``, and either ``ins [P,h,w,ins_num]`` or,
+    with ``labels_only=True``, ``label [P,h,w]`` (int64) and ``conf [P,h,w]``; ``psnr [P]`` when ``gt_imgs`` is given."""
+    H, W, K = hwk
+    chunk = int(getattr(args, "N_test", 4096))
+    n_samples = int(getattr(args, "N_samples", 64))
+    keep = None
+    if crop_mask is not None:
+        keep = torch.as_tensor(crop_mask).reshape(-1) == 1
+        h, w = int(args.crop_height), int(args.crop_width)
+    else:
+        h, w = H, W
+    cols = {}
+    for i, c2w in enumerate(render_poses):
+        frame = render_frame(H, W, K, c2w, models, args.near, args.far, args, chunk=chunk, n_samples=n_samples,
+                             labels_only=labels_only, **frame_kw)
+        names = ("rgb", "label", "conf", "depth") if labels_only else ("rgb", "ins", "depth")
+        for name, t in zip(names, frame):
+            flat = t.reshape(H * W, *t.shape[2:])
+            if keep is not None:
+                flat = flat[keep.to(flat.device)]
+            cols.setdefault(name, []).append(flat.reshape(h, w, *t.shape[2:]))
+        if gt_imgs is not None:
+            gt = torch.as_tensor(gt_imgs[i]).to(cols["rgb"][-1])
+            mse = torch.mean((cols["rgb"][-1] - gt) ** 2)
+            cols.setdefault("psnr", []).append(-10.0 * torch.log10(mse))
+    return {k: torch.stack(v, 0) for k, v in cols.items()}

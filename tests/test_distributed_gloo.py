@@ -104,6 +104,30 @@ def test_single_process_frame_matches_direct_oracle():
     assert torch.allclose(rgb.reshape(-1, 3), want['rgb_fine'], atol=1e-5)
 
 
+def test_render_path_poses_crop_and_psnr():
+    """The pose loop with a crop mask and ground truth: frames equal render_frame's, the crop keeps the masked pixels
+    in order, PSNR is that of the cropped frame (oracle as the chunk renderer, single process)."""
+    import types
+    K, c2w, sd_c, sd_f = _scene()
+    poses = torch.stack([c2w, O.pose_spherical(60.0, -65.0, 7.0)])
+    mask = torch.zeros(H, W, dtype=torch.int64)
+    mask[2:8, 3:11] = 1                                           # a 6 x 8 window
+    args = types.SimpleNamespace(N_test=CHUNK, N_samples=16, near=4.0, far=15.0, crop_height=6, crop_width=8)
+    gt = torch.rand(2, 6, 8, 3, generator=torch.Generator().manual_seed(1))
+    kw = dict(raygen=_raygen, render_chunk=_render_chunk, z_fn=_z_fn)
+    out = D.render_path(poses, (H, W, K), (sd_c, sd_f), args, gt_imgs=gt, crop_mask=mask, **kw)
+    assert out["rgb"].shape == (2, 6, 8, 3) and out["ins"].shape == (2, 6, 8, INS) and out["depth"].shape == (2, 6, 8)
+    full = D.render_frame(H, W, K, poses[1], (sd_c, sd_f), 4.0, 15.0, args, chunk=CHUNK, n_samples=16, **kw)
+    assert torch.equal(out["rgb"][1], full[0][2:8, 3:11]) and torch.equal(out["depth"][1], full[2][2:8, 3:11])
+    want = -10 * torch.log10(((full[0][2:8, 3:11] - gt[1]) ** 2).mean())
+    assert torch.allclose(out["psnr"][1], want)
+    lab = D.render_path(poses[:1], (H, W, K), (sd_c, sd_f), args, labels_only=True,
+                        label_conf=lambda x: (x.argmax(-1), x.max(-1).values), **kw)
+    assert lab["label"].shape == (1, H, W) and lab["label"].dtype == torch.int64
+    assert torch.equal(lab["label"][0], D.render_frame(H, W, K, poses[0], (sd_c, sd_f), 4.0, 15.0, args, chunk=CHUNK,
+                                                       n_samples=16, **kw)[1].argmax(-1))
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_sharded_frame_equals_single_process():
     single = [t.numpy() for t in _frame()]
