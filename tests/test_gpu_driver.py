@@ -55,6 +55,27 @@ def test_render_frame_ragged_chunks_equal_one_shot_render(A):
     assert torch.equal(conf.cpu(), ins.cpu().max(-1).values)
 
 
+def test_render_path_on_the_device(A):
+    """The pose loop through the HIP path: two poses, ScanNet-style crop window, ground truth for the device PSNR."""
+    H, W = 9, 13
+    mc, mf = models(A)
+    K = np.array([[20.0, 0, W / 2], [0, -20.0, H / 2], [0, 0, -1]])
+    poses = torch.stack([O.pose_spherical(30.0, -65.0, 7.0), O.pose_spherical(80.0, -65.0, 7.0)]).cuda()
+    mask = torch.zeros(H, W, dtype=torch.int64)
+    mask[1:7, 2:12] = 1
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, N_test=50, N_samples=64,
+                                 near=4.0, far=15.0, crop_height=6, crop_width=10)
+    gt = torch.rand(2, 6, 10, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        out = A.D.render_path(poses, (H, W, K), (mc, mf), args, gt_imgs=gt, crop_mask=mask, labels_only=True)
+        rgb, ins, depth = A.D.render_frame(H, W, K, poses[1], (mc, mf), 4.0, 15.0, args, chunk=50, n_samples=64)
+    assert out["rgb"].shape == (2, 6, 10, 3) and out["label"].shape == (2, 6, 10) and out["psnr"].shape == (2,)
+    assert torch.equal(out["rgb"][1], rgb[1:7, 2:12]) and torch.equal(out["depth"][1], depth[1:7, 2:12])
+    assert torch.equal(out["label"][1].cpu(), ins[1:7, 2:12].cpu().argmax(-1))
+    want = -10 * torch.log10(((rgb[1:7, 2:12] - gt[1]) ** 2).mean())
+    assert torch.allclose(out["psnr"][1], want)
+
+
 def test_ins_label_conf_ties_and_wide_rows(A):
     """First maximum wins (torch.argmax on CPU, what ins_eval sees), for the three object-code widths of the configs."""
     from dm_nerf_amd.networks import evaluator as E
