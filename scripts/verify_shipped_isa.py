@@ -31,9 +31,9 @@ def from_objdump(co):
         m = re.match(r"^\s+([a-z][a-z0-9_]+)\b", l)
         if m and k:
             d[k].append(norm(m.group(1)))
-    for v in d.values():                                 # padding behind the last s_endpgm decodes as junk
-        while v and v[-1] != "s_endpgm":
-            v.pop()
+    for v in d.values():                                 # alignment padding behind the kernel's last instruction (a kernel
+        while v and v[-1] in ("s_nop", "s_code_end", "v_cndmask_b32"):   # ends in s_endpgm or a branch; zero words decode
+            v.pop()                                                      # as v_cndmask_b32)
     return d
 
 
