@@ -47,6 +47,16 @@ def parse():
     return p.parse_args()
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner with printf (NCCL_DEBUG=VERSION on this pool); on a pipe that sits in the C
+    buffer until exit and would land BEHIND the JSON line.  Push it out early instead."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                           # noqa: BLE001
+        pass
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/pmc_traffic.json), or None."""
@@ -241,6 +251,7 @@ def main():
     if world > 1:
         dist.all_reduce(torch.zeros(1, device=dev))
     torch.cuda.synchronize()
+    flush_c_stdio()
     tile = torch.empty(N_RAYS, 3 + INS_NUM + 1, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
@@ -322,6 +333,10 @@ def main():
                 res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
         if train_multi is not None:
             res["train"] = train_multi
+    if world > 1:
+        dist.barrier()                                          # nobody is still printing
+    flush_c_stdio()
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
