@@ -54,6 +54,7 @@ SIGNATURES = {
     "dmnerf_render_rays_fwd": (c_int, [ctypes.POINTER(RenderArgs), c_vp]),
     "dmnerf_composite_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "dmnerf_train_save_floats": (c_i64, [c_i64]),
+    "dmnerf_mlp_fwd_embedded_train": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dmnerf_mlp_fwd_rays_train": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_blob_t_floats": (c_i64, [c_int]),
     "dmnerf_build_pack_index_t": (c_int, [c_int, c_vp, c_i64]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "dmnerf_build_pack_index_fused": (c_int, [c_int, c_vp, c_i64]),
     "dmnerf_mlp_fwd_rays_fused": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_ins_criterion_work_bytes": (c_i64, [c_i64, c_int]),
+    "dmnerf_ins_criterion_flags_offset": (c_i64, [c_i64, c_int]),
     "dmnerf_ins_criterion_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_ins_criterion_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
 }
@@ -98,7 +100,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 3:
+    if lib.dmnerf_abi_version() != 4:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

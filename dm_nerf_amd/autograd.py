@@ -19,6 +19,27 @@ from .networks import helpers
 W = 256
 HW = 128
 
+# Measurement hook (bench.py): when this is a list, the three MFMA kernels of the training step -- saved-activation
+# forward, data gradient, weight gradient -- are bracketed by HIP events on the stream they are launched on and
+# ``(kernel, samples M, begin, end)`` is appended per launch.  None (the default): nothing is recorded.
+KERNEL_EVENTS = None
+
+
+class _timed:
+    def __init__(self, tag, M):
+        self.tag, self.M = tag, M
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.b, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.b.record()
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.e.record()
+            KERNEL_EVENTS.append((self.tag, self.M, self.b, self.e))
+        return False
+
 
 def _row_len(M):
     """Rows of the training workspace are padded to a multiple of 32 samples (csrc/layout.h::save_row_len)."""
@@ -82,6 +103,63 @@ def split_flat_grads(model, flat):
     return out
 
 
+class GradArena:
+    """ONE flat f32 buffer holding the gradients of several models back to back, in ``named_parameters`` order (coarse
+    model first: 2 x 696 338 floats = 5.57 MB at ins_num 13).  The weight-gradient kernel already produces one flat
+    vector per model; with an arena it writes that vector straight into the model's slot, autograd installs the
+    per-parameter views as ``p.grad`` without copying, and the data-parallel step all-reduces ``arena.flat`` IN PLACE --
+    one RCCL message, no ``cat`` before it and no 60 ``copy_`` after it (distributed.allreduce_grads).
+
+    ``begin_step()`` marks every slot free; the first backward launch of a model in that step takes the slot, further
+    launches of the same model (batches beyond DMNERF_MAX_TRAIN_SAMPLES run as several) use scratch vectors that
+    autograd ADDS into the installed views, i.e. into the arena."""
+
+    def __init__(self, models):
+        self.models = list(models)
+        lib = _lib.load()
+        dev = next(self.models[0].parameters()).device
+        sizes = [int(lib.dmnerf_param_count(m.ins_num)) for m in self.models]
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.slots, o = [], 0
+        for m, n in zip(self.models, sizes):
+            self.slots.append(self.flat[o:o + n])
+            m._grad_arena = (self, len(self.slots) - 1)
+            o += n
+        self.free = [False] * len(self.models)
+
+    def begin_step(self):
+        self.free = [True] * len(self.models)
+
+    def take(self, i):
+        if self.free[i]:
+            self.free[i] = False
+            return self.slots[i]
+        return None
+
+    def resident(self):
+        """True when every parameter's ``.grad`` IS its view of the arena (what autograd installs after
+        ``zero_grad(set_to_none=True)`` + backward)."""
+        base = self.flat.data_ptr()
+        o = 0
+        for m in self.models:
+            for _, p in m.named_parameters():
+                g = p.grad
+                if g is None or g.data_ptr() != base + 4 * o or not g.is_contiguous() or g.dtype != torch.float32:
+                    return False
+                o += p.numel()
+        return o == self.flat.numel()
+
+
+def grad_arena(models):
+    """The arena shared by exactly these models (created on first use, kept on the models)."""
+    models = list(models)
+    cur = getattr(models[0], "_grad_arena", None)
+    if cur is not None and len(cur[0].models) == len(models) and all(a is b for a, b in zip(cur[0].models, models)) \
+            and cur[0].flat.device == next(models[0].parameters()).device:
+        return cur[0]
+    return GradArena(models)
+
+
 class MLPRaysFunction(torch.autograd.Function):
     """raw[N,S,4+C] = DM_NeRF(embed(o + d z) | embed(d/|d|)); parameters are inputs 3.. in state_dict order."""
 
@@ -93,32 +171,68 @@ class MLPRaysFunction(torch.autograd.Function):
         ins_num = model.ins_num
         raw = torch.empty(N, S, 4 + ins_num + 1, dtype=torch.float32, device=z.device)
         save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
-        _lib.check(lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(model.blob()), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
-                                                 N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
+        blob = model.blob()
+        with _timed("mlp_fwd_train", M):
+            _lib.check(lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(blob), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
+                                                     N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
         ctx.model, ctx.M, ctx.save = model, M, save
         ctx.blob, ctx.blob_t = model.blob(), model.blob_t()      # the weights this forward used
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
-        lib = _lib.load()
-        model, M = ctx.model, ctx.M
-        ins_num = model.ins_num
-        C = ins_num + 1
-        g = _lib.f32(g_raw).reshape(M, 4 + C)
-        dsave = torch.empty_like(ctx.save)
-        Mp = _row_len(M)
-        gt = torch.empty(Mp // 32, 4 + C, 32, dtype=torch.float32, device=g.device)   # d raw, block-major, written by the kernel
+        return (None, None, None, None) + _mlp_backward(ctx, g_raw)
+
+
+def _mlp_backward(ctx, g_raw):
+    """dgrad + wgrad of one saved forward (rays or pre-embedded rows): the parameter gradients as views of one flat vector."""
+    lib = _lib.load()
+    model, M = ctx.model, ctx.M
+    ins_num = model.ins_num
+    C = ins_num + 1
+    g = _lib.f32(g_raw).reshape(M, 4 + C)
+    dsave = torch.empty_like(ctx.save)
+    Mp = _row_len(M)
+    gt = torch.empty(Mp // 32, 4 + C, 32, dtype=torch.float32, device=g.device)   # d raw, block-major, written by the kernel
+    with _timed("mlp_bwd_data", M):
         _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                            _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
-        jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
-        part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
+    jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
+    part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
+    flat = None
+    arena = getattr(model, "_grad_arena", None)                  # data-parallel step: write into the shared all-reduce buffer
+    if arena is not None and arena[0].flat.device == g.device:
+        flat = arena[0].take(arena[1])
+    if flat is None:
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)
+    with _timed("mlp_bwd_weights", M):
         _lib.check(lib.dmnerf_mlp_bwd_weights(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs,
                                               _lib.ptr(outs), n_outs, _lib.ptr(part), _lib.ptr(flat), _lib.stream()),
                    "dmnerf_mlp_bwd_weights")
-        ctx.save = None
-        return (None, None, None, None) + tuple(split_flat_grads(model, flat))
+    ctx.save = None
+    return tuple(split_flat_grads(model, flat))
+
+
+class MLPEmbeddedFunction(torch.autograd.Function):
+    """raw[M,4+C] = DM_NeRF(x) for pre-embedded rows x [M,90] (DM_NeRF.forward called directly, dm_nerf.py:80-106);
+    parameters are inputs 2.. in state_dict order.  Gradients: parameters only."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        lib = _lib.load()
+        M = x.shape[0]
+        ins_num = model.ins_num
+        raw = torch.empty(M, 4 + ins_num + 1, dtype=torch.float32, device=x.device)
+        save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=x.device)
+        _lib.check(lib.dmnerf_mlp_fwd_embedded_train(_lib.ptr(model.blob()), ins_num, _lib.ptr(x), M, _lib.ptr(raw), _lib.ptr(save),
+                                                     _lib.stream()), "dmnerf_mlp_fwd_embedded_train")
+        ctx.model, ctx.M, ctx.save = model, M, save
+        ctx.blob, ctx.blob_t = model.blob(), model.blob_t()
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        return (None, None) + _mlp_backward(ctx, g_raw)
 
 
 class CompositeFunction(torch.autograd.Function):
@@ -188,9 +302,26 @@ def render_train_train(raw, z_vals, rays_d):
 
 
 def mlp_forward_train(model, x):
-    raise NotImplementedError(
-        "dm_nerf_amd: DM_NeRF.forward on pre-embedded rows is inference-only; training goes through dm_nerf() / "
-        "run_network_train (the reference's train loops only ever call the model through dm_nerf, train_dmsr.py:32)")
+    """Differentiable (w.r.t. the parameters) ``DM_NeRF.forward`` on pre-embedded rows ``[..., 90]`` -- what a caller
+    that embeds the points itself gets in training mode (the reference's train loops go through ``dm_nerf``,
+    train_dmsr.py:32; mesh / third-party code calls the model directly).  The kernels produce no gradient for ``x``
+    itself: an input that requires grad is refused instead of silently getting none."""
+    if x.requires_grad:
+        raise NotImplementedError("dm_nerf_amd: DM_NeRF.forward gives gradients for the parameters only; detach the "
+                                  "embedded input (none of the reference's callers differentiates w.r.t. it)")
+    model._check_supported()
+    x2 = _lib.f32(x.reshape(-1, x.shape[-1]))
+    _lib.require_gpu(x2)
+    if x2.shape[-1] != model.input_ch_pts + model.input_ch_views:
+        raise ValueError(f"DM_NeRF.forward expects {model.input_ch_pts + model.input_ch_views} input channels")
+    M = x2.shape[0]
+    params = _params(model)
+    if M <= MAX_TRAIN_SAMPLES:
+        out = MLPEmbeddedFunction.apply(model, x2, *params)
+    else:                                              # as run_network_train: several launches, autograd adds the gradients
+        out = torch.cat([MLPEmbeddedFunction.apply(model, x2[s:s + MAX_TRAIN_SAMPLES], *params)
+                         for s in range(0, M, MAX_TRAIN_SAMPLES)], 0)
+    return out.reshape(*x.shape[:-1], out.shape[-1])
 
 
 def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=None, u=None):
@@ -202,18 +333,16 @@ def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=No
     N, S = z_in.shape
     n_imp = int(args.N_importance)
     perturb = float(args.perturb)
-    if perturb > 0.:                                   # RNG order of the reference: [N,S] then [N,n_imp]
-        if t_rand is None:
-            t_rand = torch.rand(z_in.shape, device=z_in.device)
-        if u is None:
-            u = torch.rand([N, n_imp], device=z_in.device)
-        z_coarse = helpers.stratify(z_in, t_rand)
-    else:
-        z_coarse = z_in
+    from .networks.render import check_draws             # RNG order of the reference: [N,S] then [N,n_imp]; shapes validated
+    t_rand, u, _ = check_draws(t_rand, u, N, S, n_imp, perturb, z_in.device)
+    z_coarse = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
     raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse)
     rgb_coarse, weights_coarse, depth_coarse, ins_coarse = CompositeFunction.apply(raw_coarse, z_coarse, rays_d)
     with torch.no_grad():                              # z_samples.detach()  (render.py:68)
-        z_fine = helpers.importance_resample(z_coarse, weights_coarse.detach(), n_imp, det=(perturb == 0.), u=u)
+        if n_imp == 0:                                 # sample_pdf returns [N, 0]: the fine depths are the coarse ones
+            z_fine = z_coarse.clone()
+        else:
+            z_fine = helpers.importance_resample(z_coarse, weights_coarse.detach(), n_imp, det=(perturb == 0.), u=u)
     raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine)
     rgb_fine, weights_fine, depth_fine, ins_fine = CompositeFunction.apply(raw_fine, z_fine, rays_d)
     if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:

@@ -26,6 +26,11 @@ int dmn_check_launch(const char* what) {
     return dmn_fail(DMNERF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
 }
 
+int dmn_fail_hip(hipError_t e, const char* what) {
+    (void)hipGetLastError();                                 // clear the sticky error: it is being reported here
+    return dmn_fail(DMNERF_E_LAUNCH, "%s: %s", what, hipGetErrorString(e != hipSuccess ? e : hipErrorUnknown));
+}
+
 extern "C" int dmnerf_abi_version(void) { return DMNERF_ABI_VERSION; }
 extern "C" const char* dmnerf_last_error(void) { return g_err; }
 

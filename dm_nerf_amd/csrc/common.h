@@ -10,6 +10,10 @@
 int dmn_fail(int code, const char* fmt, ...);
 // After a kernel launch: 0, or DMNERF_E_LAUNCH with hipGetErrorString recorded.
 int dmn_check_launch(const char* what);
+// A HIP runtime call that FAILED with `e` (hipFuncSetAttribute, hipMemsetAsync ...): always an error return.
+// (dmn_check_launch() is the wrong tool there: it reports hipGetLastError(), which may have nothing to say, and the
+// caller would return DMNERF_OK without having launched anything.)
+int dmn_fail_hip(hipError_t e, const char* what);
 
 // hipFuncSetAttribute (large dynamic LDS) is per function AND per device: one bit per device ordinal in a per-call-site
 // mask, so a process that drives several GPUs configures each of them, and two host threads racing here both succeed.

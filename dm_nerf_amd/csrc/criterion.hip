@@ -34,7 +34,7 @@ struct CrLayout {
     int64_t part_b, part_t, part_a, part_s, part_cnt;     // chunk partials
     int64_t ce, siou, tp_all;                             // float [C][C]: rows g < V (tp_all: the soft true-positive sums)
     int64_t row4col, lab_of_row, tp_of_col, den_of_col;   // int [C], int [C], float [C], float [C]
-    int64_t scal;                                         // int V, int U (+ pad)
+    int64_t scal;                                         // int V, int U, int flags (DMNERF_CRIT_*), pad
     int64_t total;
     int nch, L;
 };
@@ -92,6 +92,9 @@ __global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const float* __rest
             }
         }
         if (p == 0 && lab_ok) lc[l] += 1;
+        // a label outside [0, ins_num]: the reference's one_hot / column indexing (:21-25) would raise; here the ray
+        // takes part in no row, and the condition is reported in the flags word (zeroed by the host before this launch)
+        if (p == 0 && !lab_ok) atomicOr(reinterpret_cast<int*>(work + w.scal) + 2, DMNERF_CRIT_LABEL_RANGE);
     }
     __syncthreads();
     float* pb = reinterpret_cast<float*>(work + w.part_b) + (int64_t)blockIdx.x * L * C;
@@ -166,7 +169,12 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
     __syncthreads();
     if (tid == 0) {
         int v = 0;
-        for (int l = 0; l < L; ++l) s_rank[l] = (s_cnt[l] > 0 && v < C) ? v++ : -1;
+        int extra = 0;
+        for (int l = 0; l < L; ++l) {
+            if (s_cnt[l] > 0 && v >= C) ++extra;          // more distinct labels than channels: the reference raises on
+            s_rank[l] = (s_cnt[l] > 0 && v < C) ? v++ : -1;   // the one-hot column mismatch (:24); here the first C are kept
+        }
+        if (extra) atomicOr(reinterpret_cast<int*>(work + w.scal) + 2, DMNERF_CRIT_TOO_MANY_LABELS);
         s_V = v;
     }
     __syncthreads();
@@ -325,6 +333,11 @@ extern "C" int64_t dmnerf_ins_criterion_work_bytes(int64_t N, int ins_num) {
     return cr_layout(N, ins_num).total;
 }
 
+extern "C" int64_t dmnerf_ins_criterion_flags_offset(int64_t N, int ins_num) {
+    if (N < 1 || ins_num < 1 || ins_num > CR_MAXC) return -1;
+    return cr_layout(N, ins_num).scal + 8;
+}
+
 extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, void* d_work,
                                         int64_t work_bytes, float* d_out4, void* stream) {
     if (N < 1 || ins_num < 1 || ins_num > CR_MAXC) return dmn_fail(DMNERF_E_ARG, "ins_criterion: bad N=%lld ins_num=%d (max %d)", (long long)N, ins_num, CR_MAXC);
@@ -333,9 +346,13 @@ extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_la
     if (work_bytes < w.total) return dmn_fail(DMNERF_E_ARG, "ins_criterion: work buffer too small (%lld < %lld bytes)", (long long)work_bytes, (long long)w.total);
     const size_t lds = (size_t)(2 * w.L * ins_num + w.L) * sizeof(float);
     static DmnOncePerDevice once;
-    if (once.run([] { return hipFuncSetAttribute((const void*)cr_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 2 * (CR_MAXC + 1) * CR_MAXC * 4 + (CR_MAXC + 1) * 4); }) != hipSuccess)
-        return dmn_check_launch("ins_criterion: hipFuncSetAttribute");
+    if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)cr_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                2 * (CR_MAXC + 1) * CR_MAXC * 4 + (CR_MAXC + 1) * 4); });
+        e != hipSuccess)
+        return dmn_fail_hip(e, "ins_criterion: hipFuncSetAttribute");
+    // V, U and the flags word start at zero (a memset node: still no allocation, no sync, graph-capturable)
+    if (hipError_t e = hipMemsetAsync((char*)d_work + w.scal, 0, 16, (hipStream_t)stream); e != hipSuccess)
+        return dmn_fail_hip(e, "ins_criterion: hipMemsetAsync");
     hipLaunchKernelGGL(cr_partial_kernel, dim3((unsigned)w.nch), dim3(CR_MAXC), lds, (hipStream_t)stream, d_pred, (const int*)d_labels, N, ins_num, (char*)d_work);
     int rc = dmn_check_launch("ins_criterion: partial sums");
     if (rc) return rc;

@@ -81,13 +81,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     // columns contribute nothing to the weight / bias gradients
     const float g_rgb[3] = {valid ? gr[0] : 0.f, valid ? gr[1] : 0.f, valid ? gr[2] : 0.f};
     const float g_sigma = valid ? gr[3] : 0.f;
+    // Branch-free: a channel beyond C is loaded from the (valid) last channel and replaced by 0 with a select -- per-
+    // element `if`s cost an exec-mask save each and the 48 / 64 of them of the Replica-width kernels spilled 37 / 67 SGPRs.
+    // d raw is also written transposed for the weight-gradient kernel, [blk][4+C rows][32], element by element as it is
+    // loaded (one live lane mask at a time).  No transposed output wanted: an empty descriptor drops every store.
+    const int GR = 4 + L.C;
+    rsrc_t grs = uniform_rsrc(a.graw_t, a.graw_t ? (int64_t)srows * GR * MP : 0);
+    const int gv = (int)((blk * GR * 32 + (lane & 31)) * 4);
     f32x16 gi[OBI];
 #pragma unroll
     for (int b = 0; b < OBI; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
-            gi[b][r] = (ch < L.C && valid) ? gr[4 + ch] : 0.f;
+            const bool in = ch < L.C;
+            const float v = gr[4 + (in ? ch : L.C - 1)];
+            gi[b][r] = (in && valid) ? v : 0.f;
+            // rows beyond C do not exist: those lanes get an offset outside the descriptor's range and the hardware drops
+            // the store (raw buffer bounds check) -- no branch
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(gi[b][r]), grs, in ? gv + (4 + ch) * 128 : 0x7ffffff0, 0, 0);
         }
     unsigned hbits[8][4], g1bits[2], g2bits[2];
     {
@@ -104,24 +116,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.blobT) + threadIdx.x;
         reinterpret_cast<f32x4*>(tab)[threadIdx.x] = src[0];              // TAB_T_FLOATS = 1024 = 256 x float4
     }
-    // d raw transposed for the weight-gradient kernel: [blk][4+C rows][32]
-    if (a.graw_t) {
-        const int GR = 4 + L.C;
-        rsrc_t grs = uniform_rsrc(a.graw_t, (int64_t)srows * GR * MP);
-        const int gv = (int)((blk * GR * 32 + (lane & 31)) * 4);
-        if (half == 0) {
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[0]), grs, gv, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[1]), grs, gv + 128, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[2]), grs, gv + 256, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(g_sigma), grs, gv + 384, 0, 0);
-        }
-#pragma unroll
-        for (int b = 0; b < OBI; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ch < L.C) __builtin_amdgcn_raw_buffer_store_b32(f2u(gi[b][r]), grs, gv + (4 + ch) * 128, 0, 0);
-            }
+    if (half == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[0]), grs, gv, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[1]), grs, gv + 128, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(g_rgb[2]), grs, gv + 256, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(g_sigma), grs, gv + 384, 0, 0);
     }
     WStream ws;
     ws_init(ws, a.blobT, LT.total, lds, lane, wave, LT.stream);
@@ -228,9 +227,9 @@ extern "C" int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, i
 #define DMN_LAUNCH(OBI_)                                                                                          \
     {                                                                                                            \
         static DmnOncePerDevice once;                                                                                 \
-        if (once.run([] { return hipFuncSetAttribute((const void*)mlp_bwd_kernel<OBI_>,                              \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess) \
-            return dmn_check_launch("mlp_bwd_data: hipFuncSetAttribute");                                       \
+        if (hipError_t e_ = once.run([] { return hipFuncSetAttribute((const void*)mlp_bwd_kernel<OBI_>,              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }); e_ != hipSuccess) \
+            return dmn_fail_hip(e_, "mlp_bwd_data: hipFuncSetAttribute");                                       \
         hipLaunchKernelGGL(mlp_bwd_kernel<OBI_>, g, b, lds_bytes, (hipStream_t)stream, a);                        \
     }
     switch (a.L.OBI) {

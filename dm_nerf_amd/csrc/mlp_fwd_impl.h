@@ -29,6 +29,8 @@ using namespace dmn;
 
 namespace {
 
+constexpr int PARK_FLOATS = 4096;     // 16 KiB behind ring + table: 4 KiB per wave, the parked direction encoding
+
 struct MlpArgs {
     const float* blob;
     BlobLayout L;
@@ -53,7 +55,7 @@ struct MlpArgs {
 template <int OBI, bool EMBEDDED, bool SAVE, bool FUSED = false>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     static_assert(!(FUSED && SAVE), "the fused-heads blob is inference-only");
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 16 KiB]
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 16 KiB][park 16 KiB]
     float* const tab = lds + RING_FLOATS;
     DMN_STAMP(0);
     const int lane = threadIdx.x & 63;
@@ -66,9 +68,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     const int64_t blk_raw = (int64_t)blockIdx.x * 4 + wave;
     const bool wave_active = blk_raw < nblk;
     const int64_t blk = wave_active ? blk_raw : nblk - 1;
-    const int64_t m_raw = blk * 32 + (lane & 31);
-    const bool valid = m_raw < a.M;
-    const int64_t m = m_raw < a.M ? m_raw : a.M - 1;                      // tail lanes recompute the last sample
+    // (recomputed where the outputs are written: blk is wave-uniform and the lane id is free, so nothing of this has
+    // to stay live in VGPRs across the network)
+    // `fresh` hides a value's origin from the optimizer: an address or index derived from fresh(lane) / fresh(half) is
+    // computed where it is used instead of being hoisted to the top of the kernel and carried (spilled) across the network
+    auto fresh = [](int x) -> int { asm volatile("" : "+v"(x)); return x; };
+    auto sample_of_lane = [&]() -> int64_t { return blk * 32 + (fresh(lane) & 31); };
+    const int64_t m_in = blk * 32 + (lane & 31);
+    const int64_t m = m_in < a.M ? m_in : a.M - 1;                           // tail lanes recompute the last sample
+    // The direction encoding (16 registers) is needed once, ~4400 MFMAs from here, by the rgb hidden layer: it is parked in
+    // this wave's 4 KiB of the last 16 KiB of the CU's LDS instead of occupying VGPRs through the whole trunk (with it
+    // resident the training variants spilled ~30 registers to scratch around the heads).
+    auto park = [&]() -> f32x4* { return reinterpret_cast<f32x4*>(lds + LDS_FLOATS + wave * (PARK_FLOATS / 4)) + lane; };
 
     const float* __restrict__ blob = a.blob;
     const BlobLayout& L = a.L;
@@ -141,6 +152,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         store_encoded_rows<POS_L, 2>(a.save + SL.pe, srows * MP, blk, lane, pe);
         store_encoded_rows<DIR_L, 1>(a.save + SL.de, srows * MP, blk, lane, de);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                  // park the direction encoding (conflict-free: 16 B per lane, lane-major)
+        const f32x4 v = {de[0][4 * q + 0], de[0][4 * q + 1], de[0][4 * q + 2], de[0][4 * q + 3]};
+        park()[q * 64] = v;
+    }
     init_bias_lds<8>(tab + L.b0, acc, half);
     gemm_quarter<0, 8, 8, 8>(ws, pe, acc, lane);
 #pragma unroll
@@ -149,7 +165,6 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 
     DMN_STAMP(2);
     float sigma = 0.f, rgb_out[3] = {0.f, 0.f, 0.f};
-    float* __restrict__ out_row = a.raw + m * (4 + L.C);
 
     // One 256 -> 256 stage = 4 quarters.  Stage st consumes h_st (st = 0..7; st = 8 re-reads h_7): training
     // saves it with stores spread over the MFMA gaps of quarters 1..3, younger than each quarter's DMA pieces
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
     {
         // density_linear(h) (dm_nerf.py:101) on the VALU: 128 features per lane + the other half
-        const f32x4* wd = reinterpret_cast<const f32x4*>(tab + L.w_den + half * 128);
+        const f32x4* wd = reinterpret_cast<const f32x4*>(tab + L.w_den + fresh(half) * 128);
         float part = 0.f;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -198,7 +213,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
             }
         }
         sigma = part + __shfl_xor(part, 32) + tab[L.b_den];
-    }
+        asm volatile("" : "+v"(sigma));      // finished HERE: otherwise the tail of the dot product is sunk below the rgb branch
+    }                                        // and its 24 weight registers are spilled across it
 
     DMN_STAMP(3);
     // ---- rgb branch: acc = rgb_feature (no activation, dm_nerf.py:89); hidden = relu(W [rgb_feature, dirs]) (:90-93)
@@ -214,7 +230,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         auto& fsrc = *(FUSED ? &h : &acc);                             // the hidden layer's input: rgb_feature, or h itself when fused
         gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, fsrc, hid, lane, st_f(0));
         gemm_quarter<16, 16, 4, 4, false, SAVE ? 63 : 0>(ws, fsrc, hid, lane, st_f(63));
-        gemm_quarter<0, 4, 4, 8, false, SAVE ? 2 : 0>(ws, de, hid, lane, st_f(126));
+        f32x16 dpk[1];                                                 // the parked direction encoding comes back for its one quarter
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = park()[q * 64];
+            dpk[0][4 * q + 0] = v[0]; dpk[0][4 * q + 1] = v[1]; dpk[0][4 * q + 2] = v[2]; dpk[0][4 * q + 3] = v[3];
+        }
+        gemm_quarter<0, 4, 4, 8, false, SAVE ? 2 : 0>(ws, dpk, hid, lane, st_f(126));
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
         if constexpr (SAVE) {
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         // rgb_linear (dm_nerf.py:102) on the VALU
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const f32x4* wr = reinterpret_cast<const f32x4*>(tab + L.w_rgbo + (c * 2 + half) * 64);
+            const f32x4* wr = reinterpret_cast<const f32x4*>(tab + L.w_rgbo + (c * 2 + fresh(half)) * 64);
             float part = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -239,6 +261,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
                 }
             }
             rgb_out[c] = part + __shfl_xor(part, 32) + tab[L.b_rgbo + c];
+            asm volatile("" : "+v"(rgb_out[c]));
         }
     }
 
@@ -271,12 +294,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         init_bias_lds<OBI>(tab + L.b_inso, io, half);
         auto st_3 = [&](int k) { if (k < 2) store_row_one(qio, acc, 126 + k); else store_row_one(g2io, hid, k - 2); };
         gemm_quarter<0, 16, OBI, 0, false, NS3>(ws, hid, io, lane, st_3);   // ins_linear (:103); its fetch runs into the zero-filled landing zone
-        if (valid) {
+        const int64_t ms = sample_of_lane();
+        const int hf = fresh(half);
+        float* __restrict__ out_row = a.raw + (ms < a.M ? ms : a.M - 1) * (4 + L.C);
+        if (ms < a.M) {
 #pragma unroll
             for (int b = 0; b < OBI; ++b) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hf;
                     if (ch < L.C) out_row[4 + ch] = io[b][r];
                 }
             }
@@ -284,7 +310,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     }
     DMN_STAMP(4);
     // cat[rgb, density, ins]  (dm_nerf.py:105)
-    if (valid && half == 0) {
+    const int64_t ms = sample_of_lane();
+    float* __restrict__ out_row = a.raw + (ms < a.M ? ms : a.M - 1) * (4 + L.C);
+    if (ms < a.M && fresh(half) == 0) {
         out_row[0] = rgb_out[0];
         out_row[1] = rgb_out[1];
         out_row[2] = rgb_out[2];
@@ -302,13 +330,13 @@ int launch(const MlpArgs& a, hipStream_t stream) {
         return dmn_fail(DMNERF_E_ARG, "mlp_fwd_train: %lld samples per launch exceed %lld (32-bit row offsets); split the batch",
                         (long long)a.M, (long long)DMNERF_MAX_TRAIN_SAMPLES);
     dim3 g((unsigned)grid), b(256);
-    constexpr size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);      // 147 456 B: one workgroup per CU
+    constexpr size_t lds_bytes = (size_t)(LDS_FLOATS + PARK_FLOATS) * sizeof(float);   // 163 840 B = the CU's whole LDS: one workgroup per CU
 #define DMN_LAUNCH(OBI_)                                                                                              \
     {                                                                                                                \
         static DmnOncePerDevice once;                                                                                 \
-        if (once.run([] { return hipFuncSetAttribute((const void*)(mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>),                              \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess) \
-            return dmn_check_launch("mlp_fwd: hipFuncSetAttribute");                                       \
+        if (hipError_t e_ = once.run([] { return hipFuncSetAttribute((const void*)(mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>),              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }); e_ != hipSuccess) \
+            return dmn_fail_hip(e_, "mlp_fwd: hipFuncSetAttribute");                                       \
         hipLaunchKernelGGL((mlp_fwd_kernel<OBI_, EMBEDDED, SAVE, FUSED>), g, b, lds_bytes, stream, a);                       \
     }
     switch (a.L.OBI) {

@@ -394,9 +394,9 @@ extern "C" int dmnerf_mlp_fwd_rays_split(const float* d_blob_split, int ins_num,
 #define DMN_LAUNCH(OBX_)                                                                                                   \
     {                                                                                                                     \
         static DmnOncePerDevice once;                                                                                 \
-        if (once.run([] { return hipFuncSetAttribute((const void*)mlp_split_kernel<OBX_>,                              \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess) \
-            return dmn_check_launch("mlp_fwd_rays_split: hipFuncSetAttribute");                                       \
+        if (hipError_t e_ = once.run([] { return hipFuncSetAttribute((const void*)mlp_split_kernel<OBX_>,              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }); e_ != hipSuccess) \
+            return dmn_fail_hip(e_, "mlp_fwd_rays_split: hipFuncSetAttribute");                                       \
         hipLaunchKernelGGL(mlp_split_kernel<OBX_>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, a);    \
     }
     switch (a.S.OBX) {

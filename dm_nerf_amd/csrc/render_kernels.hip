@@ -17,7 +17,9 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int RAYS_PER_BLOCK = 4;          // one wave per ray, 256-thread blocks
-constexpr int MAX_S = 1024;                // samples per ray supported by the per-ray LDS staging
+// samples per ray supported by the per-ray LDS staging: the manipulation render composites 64 + 128 + 128 T samples
+// for T moved objects (manipulator.py:187-189), and the exchanger takes T <= MAX_MOVE = 8 -> 1216
+constexpr int MAX_S = 1280;
 
 __device__ __forceinline__ double shfl_up_d(double v, int delta) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -584,6 +586,8 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void sort_rows_kernel(const f
 
 // exchanger (networks/manipulator.py:18-83): per (ray, sample) label logic + masked swaps of the raw rows
 constexpr int MAX_MOVE = 8;
+static_assert(64 + 128 + 128 * MAX_MOVE <= MAX_S, "a manipulation with MAX_MOVE objects must composite");
+static_assert(3 * RAYS_PER_BLOCK * MAX_S * 4 <= 65536, "composite_bwd stages three rows per ray in static LDS");
 struct ExchArgs {
     float* ori_raw;                       // [N,S,4+C], modified in place
     const float* tar_raw[MAX_MOVE];       // T x [N,S,4+C]

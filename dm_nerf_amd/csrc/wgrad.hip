@@ -442,8 +442,9 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
     a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_wgrad_trace;
     const size_t lds_bytes = WG_LDS_BYTES;
     static DmnOncePerDevice once;
-    if (once.run([&] { return hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }) != hipSuccess)
-        return dmn_check_launch("mlp_bwd_weights: hipFuncSetAttribute");
+    if (hipError_t e = once.run([&] { return hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); });
+        e != hipSuccess)
+        return dmn_fail_hip(e, "mlp_bwd_weights: hipFuncSetAttribute");
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_jobs), dim3(256), lds_bytes, (hipStream_t)stream, a);
     int rc = dmn_check_launch("mlp_bwd_weights");
     if (rc) return rc;

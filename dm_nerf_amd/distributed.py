@@ -62,15 +62,19 @@ def all_gather_cat(t, sizes=None):
         return t
     t = t.contiguous()
 
+    # The collective is chosen UP FRONT from the backend, identically on every rank -- never by catching an exception
+    # (a failure on some ranks only would make the ranks issue different collectives and hang; a real RCCL error must
+    # surface): RCCL ("nccl") has the single-buffer form, gloo gathers into a list.
+    tensor_form = dist.get_backend() == "nccl"
+
     def gather(x):                                       # [n, ...] -> [world * n, ...]
-        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        try:
+        if tensor_form:
+            out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(out, x)          # one RCCL all-gather
-        except (RuntimeError, NotImplementedError):      # backends without the tensor form (gloo on device tensors)
-            parts = [torch.empty_like(x) for _ in range(world)]
-            dist.all_gather(parts, x)
-            out = torch.cat(parts, 0)
-        return out
+            return out
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x)
+        return torch.cat(parts, 0)
 
     if sizes is None or len(set(sizes)) == 1:
         return gather(t)
@@ -81,20 +85,36 @@ def all_gather_cat(t, sizes=None):
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], 0)
 
 
-def allreduce_grads(models, average=False):
-    """Sum (or average) the gradients of ``models`` across ranks in ONE flat bucket."""
+def allreduce_grads(models, average=False, arena=None):
+    """Sum (or average) the gradients of ``models`` across ranks in ONE flat message (5.57 MB at ins_num 13).
+
+    With a ``GradArena`` (dm_nerf_amd.autograd) whose slots the backward kernels filled, the parameters' ``.grad`` ARE
+    views of one buffer and that buffer is all-reduced in place: no ``cat``, no copies.  Otherwise the bucket is built
+    over ALL parameters of the models, zero-filling those without a gradient, so that every rank contributes the same
+    number of elements whatever it rendered (a rank whose slice produced no gradient for some tensor must not shrink
+    its bucket), and the result is copied back."""
     rank, world = world_info()
-    params = [p for m in models for p in m.parameters() if p.grad is not None]
-    if world == 1 or not params:
+    if world == 1:
         return 0
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if arena is not None and arena.resident():
+        dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM)
+        if average:
+            arena.flat /= world
+        return arena.flat.numel() * arena.flat.element_size()
+    params = [p for m in models for p in m.parameters()]
+    if not params:
+        return 0
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= world
     o = 0
     for p in params:
         n = p.numel()
-        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        if p.grad is None:
+            p.grad = flat[o:o + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
     return flat.numel() * flat.element_size()
 
@@ -158,7 +178,8 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
       img2mse's mean and the Hungarian cost matrices / soft-IoU sums of ins_criterion (evaluator.py:19-74) are then
       evaluated identically on every rank, and autograd hands each rank the gradient rows of its own slice;
       ``args.N_ins`` (ScanNet: only the LAST N_ins rays carry labels, render.py:88-90) is applied to the gathered tensor;
-    * the emptiness penalizer is a ratio of batch sums: numerators and mask counts are summed over ranks
+    * with ``args.penalize`` (train_dmsr.py:51-58; off by default in config.py:86, on in every shipped train config) the
+      emptiness penalizer is added: a ratio of batch sums, numerators and mask counts summed over ranks
       (``allreduce_sums``) before the division, inside the penalizer (``sharded=True``);
     * ``loss.backward()`` then yields on each rank the gradient contribution of its rays to the GLOBAL loss, one flat
       all-reduce (sum) of both models' gradients completes them, and every rank takes the same optimizer step.
@@ -168,6 +189,10 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     covered on CPU with gloo.  Returns the (global) loss and the number of bytes all-reduced."""
     from .networks import evaluator as E, penalizer as P, render as R
     rank, world = world_info()
+    arena = None
+    if render is None and world > 1:                     # HIP path: backward writes both models' gradients into one buffer
+        from . import autograd
+        arena = autograd.grad_arena(models)
     N = rays.shape[1]
     sizes = [ray_slice(N, r, world)[1] for r in range(world)]
     s0, cnt = ray_slice(N, rank, world)
@@ -188,17 +213,23 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     penalizer = penalizer or (lambda out, lvl, rays_d: P.ins_penalizer(out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl],
                                                                        rays_d, largs, sharded=True))
     out = render(rays[:, sl].contiguous(), z_vals[sl].contiguous(), largs,
-                 None if t_rand is None else t_rand[sl].contiguous(), None if u is None else u[sl].contiguous())
+                 None if t_rand is None else t_rand[sl].contiguous(),
+                 None if u is None else (u if u.dim() == 1 else u[sl].contiguous()))      # a 1-D u is the grid shared by all rays
+    penalize = bool(getattr(args, "penalize", False))    # train_dmsr.py:51: the emptiness term is optional (--penalize)
     loss = 0.
     for lvl in ("fine", "coarse"):
         rgb = gather_batch(out['rgb_' + lvl], sizes)
         ins = gather_batch(out['ins_' + lvl], sizes)
         if n_ins is not None:
             ins = ins[-n_ins:]
-        loss = loss + mse(rgb, target) + criterion(ins, labels) + penalizer(out, lvl, rays[1, sl]).sum()
+        loss = loss + mse(rgb, target) + criterion(ins, labels)
+        if penalize:
+            loss = loss + penalizer(out, lvl, rays[1, sl]).sum()
     optimizer.zero_grad(set_to_none=True)
+    if arena is not None:
+        arena.begin_step()
     loss.backward()
-    nbytes = allreduce_grads(models)
+    nbytes = allreduce_grads(models, arena=arena)
     optimizer.step()
     return loss.detach(), nbytes
 

@@ -80,6 +80,8 @@ class DM_NeRF(nn.Module):
         self._blob_key = None
         self._blob_t = None
         self._blob_t_key = None
+        self._blob_f = self._blob_s = None
+        self._blob_f_key = self._blob_s_key = None
 
     # -- kernel-layout weights --------------------------------------------------------------
     def _check_supported(self):
@@ -89,8 +91,18 @@ class DM_NeRF(nn.Module):
                 "dm_nerf_amd kernels implement the configuration create_nerf builds "
                 "(D=8, W=256, skips=[4], 63+27 input channels; config.py:126-138)")
 
+    def invalidate_blobs(self):
+        """Forget every cached kernel-layout copy of the weights; the next call re-packs from the parameters.
+
+        The caches are keyed on ``(data_ptr, tensor._version)`` of every parameter, which follows
+        ``optimizer.step()``, ``load_state_dict`` and any in-place op on the parameter itself.  Updates made THROUGH
+        ``.data`` (``p.data.add_(...)``, hand-written optimizers, EMA / weight-clipping code) do not bump ``_version``:
+        call this after them, or the kernels keep using the stale copy."""
+        self._blob_key = self._blob_t_key = None
+        self._blob_f_key = self._blob_s_key = None
+
     def blob(self):
-        """Kernel-layout weights, refreshed if any parameter was updated in place or replaced."""
+        """Kernel-layout weights, refreshed if any parameter was updated in place or replaced (see ``invalidate_blobs``)."""
         self._check_supported()
         state = dict(self.named_parameters())
         key = tuple((p.data_ptr(), p._version) for p in state.values())

@@ -28,10 +28,11 @@ class _InsCriterion(torch.autograd.Function):
                                                 _lib.stream()), "dmnerf_ins_criterion_fwd")
         ctx.save_for_backward(pred, labels, work)
         ctx.ins_num = ins_num
-        return out
+        ctx.mark_non_differentiable(work)
+        return out, work
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, _g_work=None):
         pred, labels, work = ctx.saved_tensors
         grad = torch.empty_like(pred)
         g = _lib.f32(g_out)
@@ -40,14 +41,20 @@ class _InsCriterion(torch.autograd.Function):
         return grad, None, None
 
 
-def ins_criterion(pred_ins, gt_labels, ins_num):
+CRIT_TOO_MANY_LABELS, CRIT_LABEL_RANGE = 1, 2          # DMNERF_CRIT_* (include/dmnerf_hip.h)
+
+
+def ins_criterion(pred_ins, gt_labels, ins_num, check=None):
     """``ins_criterion`` (networks/evaluator.py:19-37): ``pred_ins [N, ins_num]``, ``gt_labels [N]`` ->
     ``(ins_loss_sum, valid_ce, invalid_ce, valid_siou)`` as 0-dim tensors, differentiable w.r.t. ``pred_ins``.
 
     Same definition as the reference: rows of the cost matrices are the labels that occur (ascending), matched to
     channels by a minimum-cost assignment of ``cost_ce + cost_siou``; ``invalid_ce`` is the mean prediction of the
     unmatched channels (0 when every channel is matched, where the reference returns ``tensor([0])``).
-    No host synchronisation.
+    No host synchronisation -- which is also why two conditions on which the reference RAISES cannot raise here by
+    default: more distinct labels than ``ins_num`` channels (the first ``ins_num`` are kept) and labels outside
+    ``[0, ins_num]`` (they join no row).  The kernels record both in a flags word; ``check=True`` (or the environment
+    variable ``DMNERF_CHECK_LABELS=1``; default off) reads it back -- one sync -- and raises ``ValueError`` like the reference.
     """
     pred = _lib.f32(pred_ins)
     _lib.require_gpu(pred)
@@ -56,7 +63,17 @@ def ins_criterion(pred_ins, gt_labels, ins_num):
     labels = gt_labels.reshape(-1).to(device=pred.device, dtype=torch.int32).contiguous()
     if labels.shape[0] != pred.shape[0]:
         raise ValueError("ins_criterion: one label per ray")
-    out = _InsCriterion.apply(pred, labels, int(ins_num))
+    out, work = _InsCriterion.apply(pred, labels, int(ins_num))
+    if check is None:
+        import os
+        check = os.environ.get("DMNERF_CHECK_LABELS", "0") == "1"
+    if check:
+        off = _lib.load().dmnerf_ins_criterion_flags_offset(pred.shape[0], int(ins_num))
+        flags = int(work[off:off + 4].view(torch.int32).item())
+        if flags & CRIT_TOO_MANY_LABELS:
+            raise ValueError(f"ins_criterion: more than ins_num={ins_num} distinct labels in the batch (evaluator.py:21-25 raises too)")
+        if flags & CRIT_LABEL_RANGE:
+            raise ValueError(f"ins_criterion: a label lies outside [0, {ins_num}]")
     return out[0], out[1], out[2], out[3]
 
 

@@ -87,7 +87,9 @@ def get_select_crop(rgb, pose, K, ins_target, ins_index, crop_mask, N_train):
     N_rgb = N_train - N_ins
     crop_indices = np.where(np.asarray(crop_mask).reshape(-1) == 1)[0]
     labeled_idx = ins_index[np.random.choice(ins_index.shape[0], size=[N_ins], replace=False)]
-    n_unlabeled = len(set(crop_indices.tolist()) - set(labeled_idx.tolist()))
+    # |set(crop) - set(labeled)| (helpers.py:81) without building two 300 k-element Python sets per step: the labelled
+    # pixels are distinct (drawn without replacement from np.where output), so it is |crop| minus those inside the crop
+    n_unlabeled = len(crop_indices) - int((np.asarray(crop_mask).reshape(-1)[labeled_idx] == 1).sum())
     unlabeled_idx = crop_indices[np.random.choice(n_unlabeled, size=[N_rgb], replace=False)]
     flat = np.concatenate([unlabeled_idx, labeled_idx]).astype(np.int64)
     idx = torch.from_numpy(flat).to(rgb.device)
@@ -99,6 +101,15 @@ def get_select_crop(rgb, pose, K, ins_target, ins_index, crop_mask, N_train):
     target_c = rgb.reshape(-1, rgb.shape[-1])[idx]
     target_i = ins_target.reshape(-1)[idx[N_rgb:]]
     return target_c, target_i, rays, N_ins
+
+
+def _check_u(u, N, n, what):
+    """``u``: the inverse-CDF draw, ``[n]`` (shared by all rays) or ``[N, n]``; returns (f32 contiguous u, row stride)."""
+    if tuple(u.shape) not in ((n,), (N, n)):
+        raise ValueError(f"{what}: u must be [{n}] or [{N}, {n}], got {tuple(u.shape)}")
+    u = _lib.f32(u)
+    _lib.require_gpu(u)
+    return u, (0 if u.dim() == 1 else n)
 
 
 def z_val_sample(N_rays, near, far, N_samples, device=None):
@@ -120,8 +131,7 @@ def sample_pdf(bins, weights, N_samples, det=False, u=None, return_aux=False):
         raise ValueError("sample_pdf: weights must be [N, bins-1]")
     if u is None:
         u = linspace01(N_samples, bins.device) if det else torch.rand([N, N_samples], device=bins.device)
-    u = _lib.f32(u)
-    stride = 0 if u.dim() == 1 else N_samples
+    u, stride = _check_u(u, N, int(N_samples), "sample_pdf")
     samples = torch.empty(N, N_samples, dtype=torch.float32, device=bins.device)
     cdf = torch.empty(N, nb, dtype=torch.float32, device=bins.device) if return_aux else None
     inds = torch.empty(N, N_samples, dtype=torch.int64, device=bins.device) if return_aux else None
@@ -138,7 +148,9 @@ def sample_from_cdf(bins, cdf, u):
     _lib.require_gpu(bins, cdf, u)
     N, nb = bins.shape
     ns = u.shape[-1]
-    stride = 0 if u.dim() == 1 else ns
+    u, stride = _check_u(u, N, ns, "sample_from_cdf")
+    if cdf.shape != bins.shape:
+        raise ValueError("sample_from_cdf: cdf and bins must both be [N, n_bins]")
     samples = torch.empty(N, ns, dtype=torch.float32, device=bins.device)
     inds = torch.empty(N, ns, dtype=torch.int64, device=bins.device)
     _lib.check(_lib.load().dmnerf_sample_from_cdf(_lib.ptr(bins), _lib.ptr(cdf), _lib.ptr(u), stride, N, nb, ns,
@@ -150,6 +162,8 @@ def stratify(z_vals, t_rand):
     """Stratified jitter of render.py:42-47 with the draw passed in."""
     z, t = _lib.f32(z_vals), _lib.f32(t_rand)
     _lib.require_gpu(z, t)
+    if t.shape != z.shape:
+        raise ValueError(f"stratify: t_rand must have z_vals' shape {tuple(z.shape)}, got {tuple(t.shape)}")
     out = torch.empty_like(z)
     _lib.check(_lib.load().dmnerf_stratify(_lib.ptr(z), _lib.ptr(t), z.shape[0], z.shape[1], _lib.ptr(out), _lib.stream()), "dmnerf_stratify")
     return out
@@ -162,8 +176,9 @@ def importance_resample(z_coarse, weights_coarse, N_importance, det=True, u=None
     N, S = z.shape
     if u is None:
         u = linspace01(N_importance, z.device) if det else torch.rand([N, N_importance], device=z.device)
-    u = _lib.f32(u)
-    stride = 0 if u.dim() == 1 else N_importance
+    u, stride = _check_u(u, N, int(N_importance), "importance_resample")
+    if w.shape != z.shape:
+        raise ValueError("importance_resample: weights must be [N, S] like z_coarse")
     z_fine = torch.empty(N, S + N_importance, dtype=torch.float32, device=z.device)
     zs = torch.empty(N, N_importance, dtype=torch.float32, device=z.device) if return_samples else None
     _lib.check(_lib.load().dmnerf_importance_resample(_lib.ptr(z), _lib.ptr(w), _lib.ptr(u), stride, N, S, int(N_importance),

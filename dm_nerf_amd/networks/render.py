@@ -38,6 +38,33 @@ def run_network(model, rays_o, rays_d, z_vals):
     return raw
 
 
+def check_draws(t_rand, u, N, S, n_imp, perturb, dev):
+    """The two random tensors of one ``dm_nerf`` call, validated before raw pointers reach the kernels.
+    ``perturb > 0``: ``t_rand [N,S]`` (render.py:46) then ``u [N,n_imp]`` (helpers.py:135), drawn here in the reference's
+    order unless passed in.  Otherwise no jitter and ``u`` = the deterministic grid ``linspace(0,1,n_imp)`` shared by all
+    rays (``det = (perturb == 0.)``, render.py:67) -- or a caller-supplied ``[n_imp]`` / ``[N,n_imp]`` tensor.
+    Returns ``(t_rand or None, u, u_row_stride)``; a wrong shape raises instead of reading out of bounds."""
+    if perturb > 0.:
+        if t_rand is None:
+            t_rand = torch.rand([N, S], device=dev)
+        if u is None:
+            u = torch.rand([N, n_imp], device=dev)
+    else:
+        t_rand = None
+        if u is None:
+            u = helpers.linspace01(n_imp, dev)
+    if t_rand is not None:
+        if tuple(t_rand.shape) != (N, S):
+            raise ValueError(f"dm_nerf: t_rand must be [{N}, {S}] (one draw per coarse sample), got {tuple(t_rand.shape)}")
+        t_rand = _lib.f32(t_rand)
+        _lib.require_gpu(t_rand)
+    if tuple(u.shape) not in ((n_imp,), (N, n_imp)):
+        raise ValueError(f"dm_nerf: u must be [{n_imp}] or [{N}, {n_imp}], got {tuple(u.shape)}")
+    u = _lib.f32(u)
+    _lib.require_gpu(u)
+    return t_rand, u, (0 if u.dim() == 1 else n_imp)
+
+
 def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args,
             t_rand=None, u=None, _events=None):
     """``dm_nerf`` (networks/render.py:31-96) -> the reference's 10-key dict.
@@ -49,7 +76,8 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     are made here, in that order, on the rays' device -- or pass ``t_rand`` / ``u`` (extension).
     ``_events``: optional (begin, end) ``torch.cuda.Event`` pair recorded around the fine MLP kernel.
     """
-    training = torch.is_grad_enabled() and any(p.requires_grad for p in model_fine.parameters())
+    # training = gradients are wanted for EITHER model (a frozen fine model with a trainable coarse one still trains)
+    training = torch.is_grad_enabled() and any(p.requires_grad for m in (model_coarse, model_fine) for p in m.parameters())
     if training:
         from .. import autograd
         return autograd.dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=t_rand, u=u)
@@ -63,24 +91,25 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     dev = rays_o.device
     N, S = z_in.shape
     n_imp = int(args.N_importance)
-    if n_imp < 1:
-        raise NotImplementedError("dm_nerf: N_importance must be >= 1 (every shipped config uses 128)")
+    if n_imp < 0:
+        raise ValueError("dm_nerf: N_importance must be >= 0")
     ins_num = model_fine.ins_num
     C = ins_num + 1
     perturb = float(args.perturb)
-    if perturb > 0.:
-        if t_rand is None:
-            t_rand = torch.rand(z_in.shape, device=dev)
-        if u is None:
-            u = torch.rand([N, n_imp], device=dev)
-        t_rand, u = _lib.f32(t_rand), _lib.f32(u)
-        u_stride = n_imp
-    else:
-        t_rand = None
-        if u is None:
-            u = helpers.linspace01(n_imp, dev)      # det = (perturb == 0.)  (render.py:67)
-        u = _lib.f32(u)
-        u_stride = 0 if u.dim() == 1 else n_imp
+    t_rand, u, u_stride = check_draws(t_rand, u, N, S, n_imp, perturb, dev)
+    if n_imp == 0:
+        # N_importance = 0 (config.py:43 allows it; no shipped config uses it): sample_pdf returns [N, 0], the merged
+        # depths are the coarse ones (render.py:66-70) and the fine network is evaluated on them
+        z_c = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
+        raw_c = run_network(model_coarse, rays_o, rays_d, z_c)
+        rgb_c, _, dep_c, ins_c = render_train(raw_c, z_c, rays_d)
+        z_f = z_c.clone()
+        raw_f = run_network(model_fine, rays_o, rays_d, z_f)
+        rgb_f, _, dep_f, ins_f = render_train(raw_f, z_f, rays_d)
+        if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
+            ins_f, ins_c = ins_f[-args.N_ins:], ins_c[-args.N_ins:]
+        return {'rgb_fine': rgb_f, 'ins_fine': ins_f, 'z_vals_fine': z_f, 'raw_fine': raw_f, 'raw_coarse': raw_c, 'rgb_coarse': rgb_c,
+                'ins_coarse': ins_c, 'z_vals_coarse': z_c, 'depth_fine': dep_f, 'depth_coarse': dep_c}
     SF = S + n_imp
     f = dict(dtype=torch.float32, device=dev)
     out = {

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 3
+#define DMNERF_ABI_VERSION 4
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -146,6 +146,12 @@ int64_t dmnerf_train_save_floats(int64_t M);
 int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_rays_o,
                               const float* d_rays_d, const float* d_z, int64_t N, int S,
                               float* d_raw, float* d_save, void* stream);
+/* DM_NeRF.forward on pre-embedded rows (networks/dm_nerf.py:80-106 called directly, as mesh / third-party code does) in
+ * training mode: d_raw as dmnerf_mlp_fwd_embedded, plus the activation workspace d_save (dmnerf_train_save_floats(M))
+ * that dmnerf_mlp_bwd_data / dmnerf_mlp_bwd_weights consume.  Parameter gradients only: the kernels produce no
+ * gradient for the embedded rows themselves. */
+int dmnerf_mlp_fwd_embedded_train(const float* d_blob, int ins_num, const float* d_x, int64_t M, float* d_raw,
+                                  float* d_save, void* stream);
 
 /* Backward blob (W^T as MFMA A operand) and the data-gradient pass: dL/draw [M,4+C] + d_save ->
  * d_dsave (same layout as d_save): dy of mlps.0..7 in the h rows, d rgb_feature, d ins_feature,
@@ -208,8 +214,16 @@ int dmnerf_mlp_fwd_rays_split(const float* d_blob_split, int ins_num, const floa
  * scipy.optimize.linear_sum_assignment (:43-54; same optimum, solved on the device by shortest augmenting
  * paths) and the three means (:28-37) run on `stream`; d_work (dmnerf_ins_criterion_work_bytes) carries the
  * assignment to _bwd, which writes d loss / d pred [N, ins_num] for upstream gradients gout4 of the four outputs.
- * ins_num <= 128; at most ins_num distinct labels may occur (the reference's own limit, :21-26).            */
+ * ins_num <= 128; at most ins_num distinct labels may occur (the reference's own limit, :21-26).
+ * Where the reference RAISES, the stream cannot: more distinct labels than channels (its one-hot column assignment
+ * fails, :24) keeps the first ins_num of them, and a label outside [0, ins_num] (its F.one_hot / indexing fails, :23)
+ * joins no row.  Both conditions are recorded in an int32 flags word inside d_work, at byte offset
+ * dmnerf_ins_criterion_flags_offset(N, ins_num), valid once _fwd has run on the stream: a caller that wants the
+ * reference's behaviour reads it back and raises (the Python mirror does under check=True / DMNERF_CHECK_LABELS=1). */
+#define DMNERF_CRIT_TOO_MANY_LABELS 1
+#define DMNERF_CRIT_LABEL_RANGE 2
 int64_t dmnerf_ins_criterion_work_bytes(int64_t N, int ins_num);
+int64_t dmnerf_ins_criterion_flags_offset(int64_t N, int ins_num);
 int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, void* d_work,
                              int64_t work_bytes, float* d_out4, void* stream);
 int dmnerf_ins_criterion_bwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, const void* d_work,

@@ -73,11 +73,14 @@ def param_shapes(ins_num, W=256, input_ch_pts=63, input_ch_views=27, D=8, skips=
     return shapes
 
 
-def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0):
+def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0, sigma_gain=1.0, head_gain=1.0):
     """Deterministic synthetic weights from a numpy seed (no 2.8 MB blobs in the repo).
 
     ``nn.Linear``-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)) scaled by ``gain``;
     ``sigma_bias`` shifts the density head so rays see surfaces ("trained-like").
+    ``sigma_gain`` / ``head_gain`` (applied after the draw, so seeds keep their meaning) scale the density
+    head and the rgb / object-code output layers: ``PEAKY`` below gives opaque surfaces in empty space
+    (sigma in about [-140, 36], half of the coarse pdf bins below 1e-5), the regime of a trained scene.
     Returns ``{name.weight / name.bias: float32 torch tensor}`` keyed as the
     reference state_dict.
     """
@@ -87,8 +90,18 @@ def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0):
         bound = gain / np.sqrt(i)
         sd[name + ".weight"] = torch.from_numpy(rng.uniform(-bound, bound, size=(o, i)).astype(np.float32))
         sd[name + ".bias"] = torch.from_numpy(rng.uniform(-bound, bound, size=(o,)).astype(np.float32))
+    if sigma_gain != 1.0:
+        sd["density_linear.weight"] = sd["density_linear.weight"] * np.float32(sigma_gain)
+        sd["density_linear.bias"] = sd["density_linear.bias"] * np.float32(sigma_gain)
+    if head_gain != 1.0:
+        sd["ins_linear.weight"] = sd["ins_linear.weight"] * np.float32(head_gain)
+        sd["rgb_linear.weight"] = sd["rgb_linear.weight"] * np.float32(head_gain)
     sd["density_linear.bias"] = sd["density_linear.bias"] + np.float32(sigma_bias)
     return sd
+
+
+# "trained-like" synthetic weights: make_weights(seed, ins_num, **PEAKY)
+PEAKY = dict(gain=2.0, sigma_gain=100.0, sigma_bias=-10.0, head_gain=4.0)
 
 
 def mlp_forward(sd, x, input_ch_pts=63, input_ch_views=27, skips=(4,), D=8, return_acts=False):
@@ -483,3 +496,17 @@ def pose_spherical(theta, phi, radius):
     c2w = ry @ rx @ t
     c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ c2w
     return torch.from_numpy(c2w.astype(np.float32))
+
+
+def scannet_scene(H=480, W=640, ins_num=7):
+    """Synthetic ScanNet-form frame: a uniform-random image, a blocky label map with ``ins_num`` = unlabelled (what
+    ``ins_processor.load_semantic_instance`` produces, loader_scannet.py:128-137), the crop mask of ``crop_data``
+    (:24-29) for the shipped crop 640 x 480, the per-image labelled-pixel list of ``selected_pixels`` (:139-151)."""
+    gen = torch.Generator().manual_seed(1010)
+    rgb = torch.rand(H, W, 3, generator=gen)
+    rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    lab = (((rr // 60) * 3 + (cc // 80)) % (ins_num + 1)).astype(np.int8)            # 8 values; 7 = unlabelled
+    crop = np.zeros((H, W)); crop[0:H, 0:W] = 1; crop = crop.astype(np.int8)         # crop_width 640, crop_height 480
+    ins = lab.reshape(-1).copy(); ins[crop.reshape(-1) == 0] = ins_num
+    ins_index = np.where(ins != ins_num)[0]
+    return rgb, lab, crop, ins_index

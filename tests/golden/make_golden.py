@@ -420,6 +420,285 @@ def gen_penalizer():
     save("penalizer", **out)
 
 
+
+def gen_frame():
+    """One 640x480 pose through the per-pose body of ``render_test`` (networks/tester.py:58-77): ``z_val_sample(N_test,
+    near, far, N_samples)``, ``get_rays_k(H, W, K, torch.Tensor(c2w))``, rays reshaped to [-1, 3], chunks of ``N_test``
+    rays through ``dm_nerf`` with ``args.perturb = False`` (test_dmsr.py:86), ``rgb_fine`` / ``ins_fine`` kept.  Rays are
+    independent, so the reference is evaluated on a subset of the frame's pixels -- 2048 scattered ones plus the two
+    complete rows 137 and 479 -- in frame order, as one chunk.  Two weight sets: 'plain' (the bench's default-init class)
+    and 'peaky' (oracle.PEAKY: opaque surfaces in empty space; the first 1024 scattered pixels).  Stored per pixel:
+    rgb, depth, the object map and its argmax (what ``ins_eval`` consumes, evaluator.py:127-137)."""
+    torch.set_num_threads(8)
+    ins_num, H, W, N_test = 13, 480, 640, 4096
+    K = O.dmsr_intrinsics(H, W)
+    c2w = O.pose_spherical(110.0, -65.0, 7.0)
+    pe, _ = R_model.get_embedder(10, 0); ve, _ = R_model.get_embedder(4, 0)
+    rays_o, rays_d = R_helpers.get_rays_k(H, W, K, torch.Tensor(c2w))
+    rays_o = torch.reshape(rays_o, [-1, 3]).float(); rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    scattered = np.random.RandomState(8).choice(H * W, 2048, replace=False)
+    rows = np.concatenate([np.arange(137 * W, 138 * W), np.arange(479 * W, 480 * W)])
+    out = dict(c2w=c2w, K=K, HW=np.array([H, W]), ins_num=np.int64(ins_num), near_far=np.array([4.0, 15.0]))
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    for name, seeds, kw, pix in (("plain", (801, 802), dict(gain=1.7, sigma_bias=0.3), np.unique(np.concatenate([scattered, rows]))),
+                                 ("peaky", (803, 804), O.PEAKY, np.sort(scattered[:1024]))):
+        sd_c, sd_f = O.make_weights(seeds[0], ins_num, **kw), O.make_weights(seeds[1], ins_num, **kw)
+        mc, mf = ref_model(sd_c, ins_num), ref_model(sd_f, ins_num)
+        idx = torch.from_numpy(pix)
+        n = len(pix)
+        assert n <= N_test
+        z_val_coarse = R_helpers.z_val_sample(n, 4.0, 15.0, 64)            # the ragged-last-chunk form (tester.py:65-67)
+        batch_rays = torch.stack([rays_o[idx], rays_d[idx]], dim=0)
+        with torch.no_grad():
+            ref = R_render.dm_nerf(batch_rays, pe, ve, mc, mf, z_val_coarse, args)
+            ora = O.dm_nerf(batch_rays, sd_c, sd_f, z_val_coarse, perturb=0., N_importance=128)
+        for k in ("rgb_fine", "ins_fine", "depth_fine", "rgb_coarse", "ins_coarse"):
+            beq(ora[k], ref[k], f"frame {name} {k}")
+        w = R_render.render_train(ref['raw_fine'], ref['z_vals_fine'], batch_rays[1])[1]
+        print(f"  frame {name}: {n} pixels, labels {np.bincount(ref['ins_fine'].argmax(-1).numpy(), minlength=ins_num).tolist()}, "
+              f"mean opacity {float(w.sum(-1).mean()):.3f}, rgb std {float(ref['rgb_fine'].std()):.3f}")
+        out.update({f"{name}_pix": pix.astype(np.int64), f"{name}_seeds": np.array(seeds), f"{name}_rgb": ref['rgb_fine'],
+                    f"{name}_ins": ref['ins_fine'], f"{name}_label": ref['ins_fine'].argmax(-1), f"{name}_depth": ref['depth_fine'],
+                    f"{name}_rgb_coarse": ref['rgb_coarse'], f"{name}_label_coarse": ref['ins_coarse'].argmax(-1)})
+    save("frame", **out)
+    torch.set_num_threads(1)
+
+
+def gen_scannet_step():
+    """One optimisation step of train_scannet.py:24-64 at the shipped shape (configs/scannet/train/scene0010_00.txt:
+    N_train 3072, 64 + 128 samples, near 0, far 9.5, penalize, tolerance = deta_w = 0.05; ins_num 7 = scene0010_00's label
+    count in data/color_dict.json): ``get_select_crop`` under ``np.random.seed(0)`` -> ``N_ins`` -> ``dm_nerf`` with
+    ``perturb = 1`` (jitter drawn under ``torch.manual_seed(404)``) and the labelled-LAST slice (render.py:88-90) ->
+    img2mse + ins_criterion + ins_penalizer on both levels -> ``total_loss.backward()``.  Stored: the batch, the per-ray
+    outputs the losses consume, every loss term, and for each of the 60 parameter tensors the gradient's norm and its
+    values at 64 seeded positions.  The image / labels / jitter are regenerated from their seeds by the tests."""
+    import networks.evaluator as R_eval
+    torch.set_num_threads(8)
+    ins_num, H, W, N_train = 7, 480, 640, 3072
+    K = np.array([[577.590698, 0, 318.905426, 0], [0, 578.729797, 242.683609, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    c2w = O.pose_spherical(40.0, -30.0, 3.0)
+    rgb, lab, crop, ins_index = O.scannet_scene(H, W, ins_num)
+    gt_label = torch.Tensor(lab).type(torch.int16)                   # train_scannet.py:137
+    pose = c2w[:3, :4]
+    np.random.seed(0)
+    target_c, target_i, batch_rays, N_ins = R_helpers.get_select_crop(rgb, pose, K, gt_label, ins_index, crop, N_train)
+    next_rand = np.random.rand()
+    sd_c = O.make_weights(811, ins_num, gain=1.7, sigma_bias=0.3)
+    sd_f = O.make_weights(812, ins_num, gain=1.7, sigma_bias=0.3)
+    mc, mf = ref_model(sd_c, ins_num).train(), ref_model(sd_f, ins_num).train()
+    pe, _ = R_model.get_embedder(10, 0); ve, _ = R_model.get_embedder(4, 0)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=N_ins, ins_num=ins_num,
+                                 penalize=True, tolerance=0.05, deta_w=0.05)
+    z_val_coarse = R_helpers.z_val_sample(N_train, 0.0, 9.5, 64)
+    torch.manual_seed(404)
+    info = R_render.dm_nerf(batch_rays, pe, ve, mc, mf, z_val_coarse, args)
+    terms = {}
+    terms["rgb_coarse"] = R_eval.img2mse(info['rgb_coarse'], target_c)
+    ic = R_eval.ins_criterion(info['ins_coarse'], target_i, ins_num)
+    terms["rgb_fine"] = R_eval.img2mse(info['rgb_fine'], target_c)
+    i_f = R_eval.ins_criterion(info['ins_fine'], target_i, ins_num)
+    for lvl, t in (("coarse", ic), ("fine", i_f)):
+        for nm, v in zip(("ins", "valid_ce", "invalid_ce", "valid_siou"), t):
+            terms[f"{nm}_{lvl}"] = v
+    total = ic[0] + i_f[0] + terms["rgb_fine"] + terms["rgb_coarse"]
+    terms["pen_coarse"] = R_pen.ins_penalizer(info['raw_coarse'], info['z_vals_coarse'], info['depth_coarse'], batch_rays[1], args)
+    terms["pen_fine"] = R_pen.ins_penalizer(info['raw_fine'], info['z_vals_fine'], info['depth_fine'], batch_rays[1], args)
+    total = total + terms["pen_fine"] + terms["pen_coarse"]
+    terms["total"] = total
+    total.sum().backward()
+    # the oracle on the same draws (bit for bit, forward)
+    torch.manual_seed(404)
+    t_rand = torch.rand(N_train, 64); u = torch.rand(N_train, 128)
+    with torch.no_grad():
+        ora = O.dm_nerf(batch_rays, sd_c, sd_f, z_val_coarse, perturb=1.0, N_importance=128, is_train=True, N_ins=N_ins, t_rand=t_rand, u=u)
+    for k in ("rgb_fine", "ins_fine", "depth_fine", "rgb_coarse", "ins_coarse", "z_vals_fine"):
+        beq(ora[k], info[k], f"scannet_step {k}")
+    out = dict(K=K, c2w=c2w, HW=np.array([H, W]), ins_num=np.int64(ins_num), N=np.array([N_train, N_ins]), near_far=np.array([0.0, 9.5]),
+               seeds=np.array([811, 812, 404, 1010]), next_rand=np.float64(next_rand), ins_index_len=np.int64(len(ins_index)),
+               target_c=target_c, target_i=target_i.to(torch.int32), rays=batch_rays,
+               rgb_fine=info['rgb_fine'], rgb_coarse=info['rgb_coarse'], ins_fine=info['ins_fine'], ins_coarse=info['ins_coarse'],
+               depth_fine=info['depth_fine'], depth_coarse=info['depth_coarse'], z_vals_fine=info['z_vals_fine'])
+    for k, v in terms.items():
+        out["loss_" + k] = v.detach().float().reshape(-1)[:1]
+        print(f"  scannet_step {k}: {float(v.detach().float().reshape(-1)[0]):.6f}")
+    rs = np.random.RandomState(4040)
+    for tag, m in (("c", mc), ("f", mf)):
+        norms, samp, pos = [], [], []
+        for name, p in m.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            flat = g.reshape(-1)
+            ii = rs.randint(0, flat.numel(), size=64)
+            norms.append(float(flat.double().norm())); samp.append(flat[torch.from_numpy(ii)].numpy()); pos.append(ii)
+        out[f"gnorm_{tag}"] = np.array(norms); out[f"gsamp_{tag}"] = np.stack(samp); out[f"gpos_{tag}"] = np.stack(pos).astype(np.int64)
+    save("scannet_step", **out)
+    torch.set_num_threads(1)
+
+
+def gen_checkpoint_format():
+    """The checkpoint dict of train_dmsr.py:78-86 as the reference writes it: key names, tensor shapes and the optimizer
+    state's structure after one Adam step (json, no weights).  The tests build the same dict from dm_nerf_amd models and
+    compare the structure; loading goes through ``model.load_state_dict`` (test_dmsr.py:89-94)."""
+    import json
+    ins_num = 13
+    mc, mf = R_model.DM_NeRF(8, 256, 63, 27, [4], ins_num), R_model.DM_NeRF(8, 256, 63, 27, [4], ins_num)
+    grad_vars = list(mc.parameters()) + list(mf.parameters())
+    opt = torch.optim.Adam(params=grad_vars, lr=5e-4, betas=(0.9, 0.999))
+    for p in grad_vars:
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    ck = {'iteration': 0, 'network_coarse_state_dict': mc.state_dict(), 'network_fine_state_dict': mf.state_dict(),
+          'optimizer_state_dict': opt.state_dict()}
+    osd = ck['optimizer_state_dict']
+    fmt = {
+        "top_keys": list(ck.keys()),
+        "model_keys": [[k, list(v.shape)] for k, v in ck['network_coarse_state_dict'].items()],
+        "optimizer_keys": sorted(osd.keys()),
+        "param_group_keys": sorted(osd['param_groups'][0].keys()),
+        "n_params": len(osd['param_groups'][0]['params']),
+        "state_entry_keys": sorted(osd['state'][0].keys()),
+        "state_shapes": [list(osd['state'][i]['exp_avg'].shape) for i in range(len(grad_vars))],
+        "lr": osd['param_groups'][0]['lr'], "betas": list(osd['param_groups'][0]['betas']), "eps": osd['param_groups'][0]['eps'],
+    }
+    with open(os.path.join(HERE, "checkpoint_format.json"), "w") as f:
+        json.dump(fmt, f, indent=1)
+    print("  wrote checkpoint_format.json")
+
+
+
+def gen_manipulator_stages():
+    """Every intermediate of ONE run of the reference's ``manipulator`` (networks/manipulator.py:137-205; T = 2 moved
+    objects, 24 rays), captured by wrapping the module-level functions it calls (``manipulator_nerf``,
+    ``manipulator_render``, ``sample_pdf``, ``exchanger``) with recorders -- the reference code itself runs unmodified.
+    The tests pin each stage of the chain on these golden inputs (the whole chain is ill-conditioned: three inverse-CDF
+    resamplings and discrete label decisions)."""
+    from unittest.mock import MagicMock
+    for mod in ("imageio", "lpips", "cv2", "skimage", "skimage.metrics", "open3d", "matplotlib", "matplotlib.pyplot",
+                "matplotlib.cm", "h5py", "configargparse", "trimesh"):
+        sys.modules.setdefault(mod, MagicMock())
+    import networks.manipulator as R_mani
+    C = 8
+    ins_num = C - 1
+    labels = [2, 5]
+    sd_c, sd_f = O.make_weights(711, ins_num, **O.PEAKY), O.make_weights(712, ins_num, **O.PEAKY)
+    mc, mf = ref_model(sd_c, ins_num), ref_model(sd_f, ins_num)
+    pe, _ = R_model.get_embedder(10, 0); ve, _ = R_model.get_embedder(4, 0)
+    Nr = 24
+    K = O.dmsr_intrinsics(480, 640)
+    c2w = O.pose_spherical(110.0, -65.0, 7.0)
+    ro_, rd_ = R_helpers.get_rays_k(480, 640, K, c2w)
+    sel = torch.from_numpy(np.random.RandomState(19).choice(480 * 640, Nr, replace=False))
+    ori_rays = torch.stack([ro_.reshape(-1, 3)[sel], rd_.reshape(-1, 3)[sel]], 0)
+    tars = []
+    for k in range(2):
+        tr = ori_rays.clone()
+        tr[0] = tr[0] + torch.tensor([0.3 * (k + 1), -0.2, 0.1])
+        tars.append(tr)
+    log = {"nerf": [], "render": [], "pdf": [], "exch": []}
+    orig = {n: getattr(R_mani, n) for n in ("manipulator_nerf", "manipulator_render", "sample_pdf", "exchanger")}
+
+    def w_nerf(rays, p, v, model, N_samples=None, near=None, far=None, z_vals=None):
+        raw, z = orig["manipulator_nerf"](rays, p, v, model, N_samples, near, far, z_vals=z_vals)
+        log["nerf"].append(dict(rays=rays.clone(), fine=model is mf, z=z.clone(), raw=raw.clone()))
+        return raw, z
+
+    def w_render(raw, z, d):
+        r = orig["manipulator_render"](raw, z, d)
+        log["render"].append(dict(raw=raw.clone(), z=z.clone(), d=d.clone(), out=[t.clone() for t in r]))
+        return r
+
+    def w_pdf(bins, weights, N, det=False):
+        st = torch.get_rng_state()
+        r = orig["sample_pdf"](bins, weights, N, det)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st); u = torch.rand(list(weights.shape[:-1]) + [N]); torch.set_rng_state(after)
+        log["pdf"].append(dict(bins=bins.clone(), w=weights.clone(), u=u, out=r.clone()))
+        return r
+
+    def w_exch(ori_raw, tar_raws, ori_acc, tar_accs, lab):
+        rec = dict(ori_raw=ori_raw.clone(), tar_raws=[t.clone() for t in tar_raws], ori_acc=ori_acc.clone(), tar_accs=[t.clone() for t in tar_accs])
+        r = orig["exchanger"](ori_raw, tar_raws, ori_acc, tar_accs, lab)
+        rec.update(out_raw=r[0].clone(), out_ori_label=r[2].clone(), out_tar_label=r[3].clone())
+        log["exch"].append(rec)
+        return r
+
+    R_mani.manipulator_nerf, R_mani.manipulator_render, R_mani.sample_pdf, R_mani.exchanger = w_nerf, w_render, w_pdf, w_exch
+    try:
+        a = types.SimpleNamespace(N_samples=64, N_importance=128, near=4.0, far=15.0, target_labels=labels)
+        with torch.no_grad():
+            torch.manual_seed(731)
+            final_rgb, final_ins, tar_rgb, tar_ins_accum = R_mani.manipulator(pe, ve, mc, mf, ori_rays, tars, a)
+    finally:
+        for n, f in orig.items():
+            setattr(R_mani, n, f)
+    assert len(log["nerf"]) == 2 + 2 * 2 + 2 * 2 and len(log["pdf"]) == 4 and len(log["exch"]) == 2 and len(log["render"]) == 2 + 2 * 2 + 2
+    # the oracle reproduces the run bit for bit from the recorded draws
+    with torch.no_grad():
+        ora = O.manipulator(sd_c, sd_f, ori_rays, tars, 64, 128, 4.0, 15.0, labels, us=[p_["u"] for p_ in log["pdf"]])
+    for a_, b_, n_ in zip(ora, (final_rgb, final_ins, tar_rgb, tar_ins_accum), ("final_rgb", "final_ins", "tar_rgb", "tar_ins_accum")):
+        beq(a_, b_, f"manipulator stages {n_}")
+    for p_ in log["pdf"]:
+        beq(O.sample_pdf(p_["bins"], p_["w"], 128, u=p_["u"]), p_["out"], "recorded sample_pdf draw")
+    out = dict(ori_rays=ori_rays, tar_rays0=tars[0], tar_rays1=tars[1], seeds=np.array([711, 712]), ins_num=np.int64(ins_num),
+               labels=np.array(labels), final_rgb=final_rgb, final_ins=final_ins, tar_rgb=tar_rgb, tar_ins_accum=tar_ins_accum)
+    for i, p_ in enumerate(log["pdf"]):
+        out.update({f"pdf{i}_w": p_["w"], f"pdf{i}_u": p_["u"], f"pdf{i}_out": p_["out"]})
+    # step 2 (manipulator.py:179-203): the second exchanger call and what feeds / follows it
+    e1, e2 = log["exch"]
+    r_step2 = log["render"][-2]                    # manipulator_render(edited coarse raw, ori_z, d) -> weights for the 4th draw
+    r_final = log["render"][-1]
+    n_fin = [n for n in log["nerf"][-4:]]          # (ori fine, tar0 fine), (ori fine, tar1 fine) on the merged depths
+    out.update(ex1_ori_raw_in=e1["ori_raw"], ex1_tar_raw0=e1["tar_raws"][0], ex1_tar_raw1=e1["tar_raws"][1], ex1_ori_acc=e1["ori_acc"],
+               ex1_tar_acc0=e1["tar_accs"][0], ex1_tar_acc1=e1["tar_accs"][1], ex1_out_raw=e1["out_raw"],
+               s2_w=r_step2["out"][1], s2_z=r_step2["z"],
+               s2_ori_z_merged=n_fin[0]["z"], s2_ori_raw=n_fin[2]["raw"], s2_tar_z0=n_fin[1]["z"], s2_tar_z1=n_fin[3]["z"],
+               s2_tar_raw0=n_fin[1]["raw"], s2_tar_raw1=n_fin[3]["raw"],
+               ex2_out_raw=e2["out_raw"], ex2_out_ori_label=e2["out_ori_label"], ex2_out_tar_label=e2["out_tar_label"])
+    # (not stored twice: exchanger 2's inputs are s2_ori_raw / s2_tar_raw*, the final render's are ex2_out_raw / s2_ori_z_merged)
+    beq(e2["ori_raw"], n_fin[2]["raw"], "ex2 input"); beq(r_final["raw"], e2["out_raw"], "final raw"); beq(r_final["z"], n_fin[0]["z"], "final z")
+    ch = (e2["out_raw"] != e2["ori_raw"]).any(-1)
+    print(f"  manipulator stages: exchanger 2 rewrote {int(ch.sum())} of {ch.numel()} samples, "
+          f"{int((e2['out_raw'] == 0).all(-1).sum())} zeroed; final labels {np.bincount(final_ins.argmax(-1).numpy(), minlength=C).tolist()}")
+    save("manipulator_stages", **out)
+
+
+
+def gen_select_stream():
+    """The host RNG stream of the training loops over several iterations: the three draws of train_dmsr.py:25,
+    helpers.py:104 and train_dmsr.py:92 around the reference's own ``get_select_full`` (6 iterations, i_test every 3),
+    and the ScanNet loop's draws (train_scannet.py:25, helpers.py:76,82) around ``get_select_crop`` (4 iterations) --
+    what dm_nerf_amd.prefetch.SelectionStream must reproduce from a private RandomState(0)."""
+    H, W, N = 12, 16, 40
+    K = O.dmsr_intrinsics(H, W)
+    gen = torch.Generator().manual_seed(611)
+    n_img = 5
+    imgs = torch.rand(n_img, H, W, 3, generator=gen)
+    labs = torch.randint(0, 13, (n_img, H, W), generator=gen).to(torch.int16)
+    poses = torch.stack([O.pose_spherical(20.0 * k, -65.0, 7.0) for k in range(n_img)])
+    i_train, i_test = np.array([0, 1, 3, 4]), np.arange(12)
+    out = dict(imgs=imgs, labs=labs, poses=poses, K=K, HWN=np.array([H, W, N]), i_train=i_train, n_i_test=np.int64(len(i_test)))
+    np.random.seed(0)
+    for i in range(6):
+        img_i = np.random.choice(i_train)                                           # train_dmsr.py:25
+        tc, ti, rays = R_helpers.get_select_full(imgs[img_i], poses[img_i, :3, :4], K, labs[img_i], N)
+        out.update({f"full{i}_img": np.int64(img_i), f"full{i}_tc": tc, f"full{i}_ti": ti, f"full{i}_rays": rays})
+        if i % 3 == 0:
+            out[f"full{i}_pick"] = np.random.choice(len(i_test), size=[10], replace=False)   # train_dmsr.py:92
+    out["full_next_rand"] = np.float64(np.random.rand())
+    crop = np.zeros((H, W)); crop[2:H - 2, 3:W - 3] = 1; crop = crop.astype(np.int8)
+    inside = np.where(crop.reshape(-1) == 1)[0]
+    ins_indices = [np.sort(np.random.RandomState(70 + k).choice(inside, size=8 + 9 * k, replace=False)) for k in range(n_img)]
+    for k in range(n_img):
+        out[f"ins_index{k}"] = ins_indices[k]
+    out["crop"] = crop
+    np.random.seed(0)
+    for i in range(4):
+        img_i = np.random.choice(i_train)                                           # train_scannet.py:25
+        tc, ti, rays, n_ins = R_helpers.get_select_crop(imgs[img_i], poses[img_i, :3, :4], K, labs[img_i], ins_indices[img_i], crop, N)
+        out.update({f"crop{i}_img": np.int64(img_i), f"crop{i}_tc": tc, f"crop{i}_ti": ti, f"crop{i}_rays": rays, f"crop{i}_nins": np.int64(n_ins)})
+    out["crop_next_rand"] = np.float64(np.random.rand())
+    save("select_stream", **out)
+
+
 if __name__ == "__main__":
     print("reference:", REF, "| torch", torch.__version__)
     if len(sys.argv) > 1:                       # regenerate single fixtures: python make_golden.py select_crop ...
@@ -437,4 +716,9 @@ if __name__ == "__main__":
     gen_select_crop()
     gen_ins_criterion()
     gen_manipulator()
+    gen_frame()
+    gen_scannet_step()
+    gen_checkpoint_format()
+    gen_manipulator_stages()
+    gen_select_stream()
     print("all oracle == reference checks passed (bit-exact)")

@@ -49,6 +49,21 @@ def test_state_follows_branches_not_layout(tmp_path):
     assert _scan(tmp_path, body) == ["v_mov_b32_e32 v8, v4"]
 
 
+def test_shipped_kernels_use_no_scratch_and_spill_nothing():
+    """Every kernel of every translation unit: private segment 0 bytes, 0 spilled VGPRs, 0 spilled SGPRs (the
+    metadata the compiler writes next to the ISA that went into the shipped library)."""
+    import check_no_scratch as S
+    isa = sorted(glob.glob(os.path.join(ROOT, "dm_nerf_amd", "csrc", "build", "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    if not isa:
+        pytest.skip("no kernel ISA in the tree (the library was not built here)")
+    total = 0
+    for f in isa:
+        ks = S.kernels(f)
+        total += len(ks)
+        assert S.violations(f) == [], f
+    assert total >= 46
+
+
 def test_shipped_kernels_are_hazard_free():
     isa = sorted(glob.glob(os.path.join(ROOT, "dm_nerf_amd", "csrc", "build", "*-hip-amdgcn-amd-amdhsa-gfx950.s")))
     if not isa:

@@ -162,7 +162,7 @@ class _SD:
         return list(self.sd.values())
 
 
-def _train_two_steps():
+def _train_two_steps(penalize=True):
     import types
     K, c2w, sd_c, sd_f = _scene()
     o, d = O.get_rays_k(H, W, K, c2w)
@@ -176,7 +176,10 @@ def _train_two_steps():
     # (plain gradient steps: the update is proportional to the gradient, so parameter differences measure gradient
     # differences; Adam would turn float noise on near-zero gradients into +-lr steps)
     opt = torch.optim.SGD(mc.parameters() + mf.parameters(), lr=2e-2)
-    args = types.SimpleNamespace(perturb=1.0, N_importance=TIMP, is_train=True, N_ins=TNINS)
+    # args.penalize: the reference adds the emptiness term only under --penalize (train_dmsr.py:51; default off, tolerance /
+    # deta_w then None): with it off the step must not touch the penalizer at all
+    args = types.SimpleNamespace(perturb=1.0, N_importance=TIMP, is_train=True, N_ins=TNINS, penalize=penalize,
+                                 tolerance=0.05 if penalize else None, deta_w=0.05 if penalize else None)
     sizes = [D.ray_slice(TN, r, D.world_info()[1])[1] for r in range(D.world_info()[1])]
 
     def render(r, zz, a, tr, uu):
@@ -184,6 +187,7 @@ def _train_two_steps():
         return O.dm_nerf(r, mc.sd, mf.sd, zz, perturb=1., N_importance=TIMP, is_train=True, N_ins=None, t_rand=tr, u=uu)
 
     def penalizer(out, lvl, rays_d):                         # exact batch-global semantics through gather_batch
+        assert penalize, "the emptiness penalizer must only run under args.penalize"
         full = [D.gather_batch(t, sizes) for t in (out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl], rays_d)]
         return O.ins_penalizer(full[0], full[1], full[2], full[3], 0.05, 0.05)
 
@@ -198,28 +202,30 @@ def _train_two_steps():
     return losses, flat.numpy(), nbytes
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, penalize=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _train_two_steps())
+        q.put((rank,) + _train_two_steps(penalize))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_sharded_training_equals_single_process():
+@pytest.mark.parametrize("penalize", [True, False])
+def test_two_rank_sharded_training_equals_single_process(penalize):
     """Two gradient steps with jitter, a partially labelled batch (N_ins) and uneven slices: both ranks end with the
-    parameters a single process reaches on the whole batch (differences: f32 summation order of the all-reduce)."""
-    want_losses, want, nb0 = _train_two_steps()
+    parameters a single process reaches on the whole batch (differences: f32 summation order of the all-reduce).
+    With and without the optional emptiness term (``args.penalize``, train_dmsr.py:51-58)."""
+    want_losses, want, nb0 = _train_two_steps(penalize)
     assert nb0 == 0
     _, _, sd_c, sd_f = _scene()
     start = torch.cat([v.reshape(-1) for v in list(sd_c.values()) + list(sd_f.values())]).numpy()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, penalize)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in range(2)]

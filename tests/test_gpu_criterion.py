@@ -81,3 +81,24 @@ def test_ins_criterion_errors_are_loud(E):
         E.ins_criterion(torch.rand(8, 13), torch.zeros(8, dtype=torch.int64), 13)           # CPU tensors
     with pytest.raises(ValueError):
         E.ins_criterion(torch.rand(8, 12, device="cuda"), torch.zeros(8, dtype=torch.int64, device="cuda"), 13)
+
+
+def test_label_conditions_the_reference_raises_on_are_flagged(E):
+    """Where the reference raises (more distinct labels than channels: the one-hot column assignment of evaluator.py:24
+    fails; a label outside [0, ins_num]: F.one_hot / the indexing of :23 fails) the stream-resident loss cannot -- it
+    records the condition, and ``check=True`` turns it into the reference's behaviour at the price of one sync."""
+    g = torch.Generator().manual_seed(5)
+    ins_num, N = 5, 300
+    pred = torch.sigmoid(torch.randn(N, ins_num, generator=g)).cuda()
+    ok = torch.randint(0, ins_num, (N,), generator=g).cuda()
+    out = E.ins_criterion(pred, ok, ins_num, check=True)                       # clean batch: no flag, no raise
+    assert bool(torch.isfinite(out[0]))
+    many = torch.arange(N).cuda() % (ins_num + 1)                              # 6 distinct labels 0..5 for 5 channels
+    E.ins_criterion(pred, many, ins_num)                                       # default: keeps the first ins_num, no sync
+    with pytest.raises(ValueError, match="distinct labels"):
+        E.ins_criterion(pred, many, ins_num, check=True)
+    bad = ok.clone(); bad[17] = ins_num + 3; bad[40] = -1
+    with pytest.raises(ValueError, match="outside"):
+        E.ins_criterion(pred, bad, ins_num, check=True)
+    # the flagged rays joined no row: same result as dropping... their label rows only (they still count in the sums over all rays)
+    assert bool(torch.isfinite(E.ins_criterion(pred, bad, ins_num)[0]))

@@ -1,0 +1,226 @@
+"""GPU tests (-m gpu) of the shapes and call patterns the reference accepts beyond its shipped configs, and of the
+boundary's sharp edges: N_importance = 0, DM_NeRF.forward on pre-embedded rows in training mode, a frozen fine model,
+caller-supplied random draws of the wrong shape, in-place ``.data`` updates, a manipulation with the maximum number of
+moved objects, per-thread error messages."""
+import threading
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from dm_nerf_amd import _lib, autograd
+    from dm_nerf_amd.networks import dm_nerf as M, helpers as H, manipulator as MA, render as R
+    _lib.load()
+    return types.SimpleNamespace(M=M, H=H, R=R, G=autograd, MA=MA, lib=_lib)
+
+
+def cpu(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu()
+
+
+def maxrel(a, b):
+    return float(((a - b).abs() / (1 + b.abs())).max())
+
+
+def model_from(A, sd, ins_num, train=False):
+    m = A.M.DM_NeRF(8, 256, 63, 27, [4], ins_num)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    return m.train() if train else m.eval()
+
+
+def _rays(n, seed, theta=33.0):
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(theta, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(seed).choice(480 * 640, n, replace=False))
+    return torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+
+
+@pytest.mark.parametrize("perturb", [0.0, 1.0])
+def test_n_importance_zero(A, perturb):
+    """config.py:43 allows N_importance = 0: sample_pdf returns [N, 0], the merged depths are the coarse ones and the
+    fine network runs on them (render.py:66-83).  Whole dict against the oracle, inference and training mode."""
+    ins_num, N = 13, 50
+    sd_c, sd_f = O.make_weights(85, ins_num, gain=1.7, sigma_bias=0.3), O.make_weights(86, ins_num, gain=1.7, sigma_bias=0.3)
+    rays = _rays(N, 85)
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous()
+    t_rand = torch.rand(N, 64, generator=torch.Generator().manual_seed(1)) if perturb > 0 else None
+    args = types.SimpleNamespace(perturb=perturb, N_importance=0, is_train=False, N_ins=None)
+    with torch.no_grad():
+        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=perturb, N_importance=0, t_rand=t_rand)
+        mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+        got = A.R.dm_nerf(rays.cuda(), None, None, mc, mf, z.cuda(), args, t_rand=None if t_rand is None else t_rand.cuda())
+    assert set(got) == set(want)
+    assert got['raw_fine'].shape == (N, 64, 18) and got['z_vals_fine'].shape == (N, 64)
+    assert torch.equal(cpu(got['z_vals_fine']), want['z_vals_fine']) and torch.equal(cpu(got['z_vals_coarse']), want['z_vals_coarse'])
+    for k in ('raw_coarse', 'raw_fine'):
+        assert maxrel(cpu(got[k]), want[k]) <= 1e-5, k
+    for k in ('rgb_coarse', 'rgb_fine', 'ins_coarse', 'ins_fine', 'depth_coarse', 'depth_fine'):
+        assert torch.allclose(cpu(got[k]), want[k], rtol=2e-6, atol=2e-6), k
+    # training mode: same values, gradients reach both models
+    mc, mf = model_from(A, sd_c, ins_num, True), model_from(A, sd_f, ins_num, True)
+    targs = types.SimpleNamespace(perturb=perturb, N_importance=0, is_train=True, N_ins=None)
+    out = A.R.dm_nerf(rays.cuda(), None, None, mc, mf, z.cuda(), targs, t_rand=None if t_rand is None else t_rand.cuda())
+    assert torch.allclose(cpu(out['rgb_fine']), want['rgb_fine'], rtol=2e-6, atol=2e-6)
+    (out['rgb_fine'].sum() + out['rgb_coarse'].sum()).backward()
+    assert float(mc.mlps[0].weight.grad.abs().max()) > 0 and float(mf.mlps[0].weight.grad.abs().max()) > 0
+
+
+def test_model_forward_on_embedded_rows_is_differentiable(A):
+    """``DM_NeRF.forward`` called directly on [M, 90] rows in training mode (dm_nerf.py:80-106): values equal the
+    inference kernel bit for bit, parameter gradients equal PyTorch autograd of the oracle; leading dims preserved."""
+    for ins_num, seed, M_rows in ((13, 7, 200), (59, 8, 45)):
+        sd = O.make_weights(seed, ins_num, gain=1.7)
+        g = torch.Generator().manual_seed(seed)
+        pts = (torch.rand(M_rows, 3, generator=g) * 2 - 1) * 6.0
+        dirs = torch.nn.functional.normalize(torch.randn(M_rows, 3, generator=g), dim=-1)
+        x = torch.cat([O.embed(pts, 10), O.embed(dirs, 4)], -1)
+        cot = torch.randn(M_rows, 4 + ins_num + 1, generator=g)
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        want = O.mlp_forward(sdg, x)
+        (want * cot).sum().backward()
+        m = model_from(A, sd, ins_num, train=True)
+        y = m(x.cuda())
+        assert y.requires_grad and y.shape == want.shape
+        assert maxrel(cpu(y), want.detach()) <= 1e-5
+        (y * cot.cuda()).sum().backward()
+        for k, p in m.named_parameters():
+            assert p.grad is not None, k
+            err = float((p.grad.cpu().double() - sdg[k].grad.double()).abs().max())
+            assert err <= 2e-4 * float(sdg[k].grad.abs().max()) + 1e-7, (k, err)
+        with torch.no_grad():
+            assert torch.equal(m(x.cuda()), y.detach())                     # inference kernel == training forward
+        assert m(x.cuda().reshape(5, M_rows // 5, 90)).shape == (5, M_rows // 5, 4 + ins_num + 1)
+    with pytest.raises(NotImplementedError):                                 # no gradient for the embedded input itself
+        m(x.cuda().requires_grad_(True))
+
+
+def test_frozen_fine_model_still_trains_the_coarse_one(A):
+    """Training is decided from the parameters of BOTH models: with model_fine frozen, a loss on the coarse level must
+    still produce gradients for model_coarse (it used to take the non-differentiable path)."""
+    ins_num, N = 13, 24
+    mc = model_from(A, O.make_weights(87, ins_num, gain=1.7, sigma_bias=0.3), ins_num, True)
+    mf = model_from(A, O.make_weights(88, ins_num, gain=1.7, sigma_bias=0.3), ins_num, True)
+    for p in mf.parameters():
+        p.requires_grad_(False)
+    args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None)
+    out = A.R.dm_nerf(_rays(N, 87).cuda(), None, None, mc, mf, A.H.z_val_sample(N, 4.0, 15.0, 64), args)
+    assert out['rgb_coarse'].requires_grad
+    (out['rgb_coarse'].sum() + out['rgb_fine'].sum()).backward()
+    assert float(mc.mlps[3].weight.grad.abs().max()) > 0
+    assert all(p.grad is None for p in mf.parameters())
+
+
+def test_wrong_shaped_random_draws_are_refused(A):
+    """Caller-supplied t_rand / u reach the kernels as raw pointers: a wrong shape must raise, not read out of bounds."""
+    ins_num, N = 13, 16
+    mc, mf = model_from(A, O.make_weights(1, ins_num), ins_num), model_from(A, O.make_weights(2, ins_num), ins_num)
+    rays, z = _rays(N, 3).cuda(), A.H.z_val_sample(N, 4.0, 15.0, 64)
+    jit = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=False, N_ins=None)
+    det = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        with pytest.raises(ValueError, match="t_rand"):
+            A.R.dm_nerf(rays, None, None, mc, mf, z, jit, t_rand=torch.rand(N, 32, device="cuda"))
+        with pytest.raises(ValueError, match="u must"):
+            A.R.dm_nerf(rays, None, None, mc, mf, z, jit, u=torch.rand(N, 64, device="cuda"))
+        with pytest.raises(ValueError, match="u must"):
+            A.R.dm_nerf(rays, None, None, mc, mf, z, det, u=torch.rand(N - 1, 128, device="cuda"))
+        with pytest.raises(ValueError, match="u must"):
+            A.H.importance_resample(z, torch.rand(N, 64, device="cuda"), 128, u=torch.rand(64, device="cuda"))
+        with pytest.raises(ValueError):
+            A.H.stratify(z, torch.rand(N, 63, device="cuda"))
+        # the legal forms: a 1-D grid shared by all rays (det), a full [N, n_imp] draw (with jitter)
+        a = A.R.dm_nerf(rays, None, None, mc, mf, z, det, u=torch.linspace(0., 1., 128).cuda())
+        b = A.R.dm_nerf(rays, None, None, mc, mf, z, det)
+        assert torch.equal(a['z_vals_fine'], b['z_vals_fine'])
+        # a 1-D u together with jitter: accepted, stride 0 (every ray uses the same grid)
+        c = A.R.dm_nerf(rays, None, None, mc, mf, z, jit, t_rand=torch.rand(N, 64, device="cuda"), u=torch.linspace(0., 1., 128).cuda())
+        assert bool(torch.isfinite(c['rgb_fine']).all())
+    mc.train(); mf.train()
+    with pytest.raises(ValueError, match="u must"):                          # the training path validates too
+        A.R.dm_nerf(rays, None, None, mc, mf, z, jit, u=torch.rand(N, 64, device="cuda"))
+
+
+def test_invalidate_blobs_after_a_data_update(A):
+    """An in-place op on the parameter bumps ``_version`` and refreshes the packed weights by itself; an update THROUGH
+    ``.data`` does not (no version bump) -- ``invalidate_blobs()`` is the documented way to make it visible."""
+    m = model_from(A, O.make_weights(4, 13, gain=1.7), 13)
+    x = torch.randn(64, 90).cuda()
+    with torch.no_grad():
+        y0 = m(x)
+        m.density_linear.bias.data.add_(1.0)
+        y_stale = m(x)
+        m.invalidate_blobs()
+        y1 = m(x)
+    assert torch.equal(y_stale, y0)                                           # the documented pitfall
+    assert torch.allclose(y1[:, 3], y0[:, 3] + 1.0, atol=1e-5) and torch.equal(y1[:, :3], y0[:, :3])
+
+
+def test_manipulation_with_the_maximum_number_of_moved_objects_composites(A):
+    """T = 8 moved objects (the exchanger's limit): the final render composites 64 + 128 + 8 x 128 = 1216 samples per ray;
+    the per-ray staging of the compositing kernels covers it (it was 1024: T = 7 was accepted by the exchanger and then
+    refused by the render).  Compositing at S = 1216 against the oracle; S beyond the limit still fails loudly."""
+    g = torch.Generator().manual_seed(12)
+    N, S, C = 5, 1216, 8
+    raw = torch.randn(N, S, 4 + C, generator=g)
+    raw[..., 3] = raw[..., 3] * 2 + 0.2
+    z = torch.sort(torch.rand(N, S, generator=g) * 11 + 4, -1)[0]
+    d = torch.randn(N, 3, generator=g)
+    want = O.manipulator_render(raw, z, d)
+    got = A.MA.manipulator_render(raw.cuda(), z.cuda(), d.cuda())
+    for a_, b_ in zip(got, want):
+        assert torch.allclose(cpu(a_), b_, rtol=2e-6, atol=2e-6)
+    want = O.render_train(raw, z, d)
+    got = A.R.render_train(raw.cuda(), z.cuda(), d.cuda())
+    for a_, b_ in zip(got, want):
+        assert torch.allclose(cpu(a_), b_, rtol=2e-6, atol=2e-6)
+    r1 = raw.cuda().requires_grad_(True)
+    o = A.R.render_train(r1, z.cuda(), d.cuda())
+    gr, = torch.autograd.grad(o[0].sum() + o[3].sum(), r1)
+    r0 = raw.clone().requires_grad_(True)
+    o = O.render_train(r0, z, d)
+    gw, = torch.autograd.grad(o[0].sum() + o[3].sum(), r0)
+    assert float((cpu(gr) - gw).abs().max()) <= 2e-4 * float(gw.abs().max()) + 1e-7
+    with pytest.raises(RuntimeError):
+        A.R.render_train(torch.zeros(2, 1300, 8, device="cuda"), torch.zeros(2, 1300, device="cuda"), torch.ones(2, 3, device="cuda"))
+    # the exchanger itself with T = 8 target sets
+    T = 8
+    ori = torch.randn(N, 40, 4 + C, generator=g).cuda()
+    tars = [torch.randn(N, 40, 4 + C, generator=g).cuda() for _ in range(T)]
+    accs = [torch.rand(N, C, generator=g).cuda() for _ in range(T)]
+    ori_acc = torch.rand(N, C, generator=g).cuda()
+    want = O.exchanger(ori.cpu().clone(), [t.cpu().clone() for t in tars], ori_acc.cpu(), [t.cpu() for t in accs], list(range(T)))
+    out = A.MA.exchanger(ori, tars, ori_acc, accs, list(range(T)))
+    assert torch.equal(cpu(out[0]), want[0]) and torch.equal(cpu(out[2]), want[2])
+    with pytest.raises(RuntimeError):
+        A.MA.exchanger(ori, tars + tars[:1], ori_acc, accs + accs[:1], list(range(T + 1)))
+
+
+def test_error_messages_are_per_thread(A):
+    """``dmnerf_last_error()`` is thread-local: two host threads failing with different messages each read their own."""
+    lib = A.lib.load()
+    seen = {}
+
+    def fail(tag, S):
+        rc = lib.dmnerf_composite_fwd(None, None, None, 4, S, 14, None, None, None, None, None)
+        for _ in range(200):                                                  # give the other thread every chance to interfere
+            lib.dmnerf_composite_fwd(None, None, None, 4, S, 14, None, None, None, None, None)
+        seen[tag] = (rc, A.lib.last_error())
+
+    ts = [threading.Thread(target=fail, args=("a", 5000)), threading.Thread(target=fail, args=("b", 64))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen["a"][0] == -1 and "S=5000" in seen["a"][1]
+    assert seen["b"][0] == -1 and "null" in seen["b"][1]

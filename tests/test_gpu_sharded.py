@@ -35,7 +35,7 @@ def _two_steps():
     target = torch.rand(N, 3, generator=g).cuda()
     labels = torch.randint(0, 7, (N_INS,), generator=g).cuda()
     opt = torch.optim.SGD([p for m in models for p in m.parameters()], lr=2e-2)
-    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=N_INS, tolerance=0.05, deta_w=0.05)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=N_INS, penalize=True, tolerance=0.05, deta_w=0.05)
     torch.manual_seed(7)
     torch.cuda.manual_seed(7)                               # the jitter stream: identical on every rank
     losses = []
@@ -43,7 +43,11 @@ def _two_steps():
         loss, nbytes = D.sharded_train_step(rays, z, target, labels, models, args, opt, INS)
         losses.append(float(loss))
     flat = torch.cat([p.detach().reshape(-1) for m in models for p in m.parameters()]).cpu().numpy()
-    return losses, flat, nbytes
+    # multi-rank: the gradients of BOTH models live in one arena that was all-reduced in place (no cat / copy_)
+    arena = getattr(models[0], "_grad_arena", None)
+    in_place = None if arena is None else bool(arena[0].resident() and arena[0].flat.numel() * 4 == nbytes
+                                               and models[1].mlps[0].weight.grad.data_ptr() == arena[0].slots[1].data_ptr())
+    return losses, flat, nbytes, in_place
 
 
 def _worker(rank, world, port, q):
@@ -59,8 +63,8 @@ def _worker(rank, world, port, q):
 @pytest.mark.timeout(600)
 def test_two_rank_sharded_training_step_equals_single_process():
     assert torch.cuda.is_available(), "GPU tests need a MI355X"
-    want_losses, want, nb0 = _two_steps()
-    assert nb0 == 0
+    want_losses, want, nb0, in_place0 = _two_steps()
+    assert nb0 == 0 and in_place0 is None
     start = torch.cat([v.reshape(-1) for seed in (71, 72) for v in O.make_weights(seed, INS, gain=1.7, sigma_bias=0.3).values()]).numpy()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -74,9 +78,45 @@ def test_two_rank_sharded_training_step_equals_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, losses, flat, nbytes in res:
+    for rank, losses, flat, nbytes, in_place in res:
+        assert in_place is True
         assert nbytes == 4 * want.size
         assert np.allclose(losses, want_losses, rtol=2e-5), (losses, want_losses)
         assert np.abs(flat - want).max() <= 2e-6, np.abs(flat - want).max()
     assert np.abs(want - start).max() >= 1e-3
     assert np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_code_path_prints_a_valid_line(scaling):
+    """The driver's SCALE run launches ``bench.py --gpus N`` under torch.distributed.run on an 8-GPU node this build never
+    sees: exercise that exact code path here with two ranks sharing the box's one GPU over gloo
+    (DMNERF_BENCH_ONE_DEVICE / DMNERF_BENCH_BACKEND) and validate the JSON line -- per-frame band gather, sharded training
+    step with the in-place gradient arena, max-over-ranks timing, both scaling modes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DMNERF_BENCH_ONE_DEVICE="1", DMNERF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--train-steps", "1", "--scaling", scaling]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.strip().split("\n") if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 1 and r["unit"] == "rays/s" and r["scaling"] == scaling
+    per_rank = 4096 if scaling == "weak" else 2048
+    assert r["config"]["rays_per_step_per_gpu"] == per_rank
+    assert abs(r["value"] - 2 * per_rank * 4 / (r["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * r["value"]
+    assert "all-gather of the rank's band per frame" in r["config"]["parallelism"]
+    assert r["roofline"]["bound"] == "mfma" and 0.0 < r["roofline"]["frac"] <= 1.0
+    assert "cpu_baseline" not in r                                  # rank 0 at N = 1 only
+    t = r["train"]
+    assert "error" not in t, t
+    assert t["batch_rays"] == (8192 if scaling == "weak" else 4096) and t["rays_per_s"] > 0 and np.isfinite(t["final_loss"])
+    assert t["roofline"]["samples_per_launch"] == t["batch_rays"] // 2 * 192

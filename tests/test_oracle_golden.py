@@ -123,3 +123,95 @@ def test_ins_criterion_golden(golden):
         assert torch.equal(pred.grad, g[f"{name}_grad"]), name
         cc, cs, valid = O.ins_cost_matrices(g[f"{name}_pred"], g[f"{name}_lab"].long(), ins_num)
         assert torch.equal(cc[:valid], g[f"{name}_cost_ce"]) and torch.equal(cs[:valid], g[f"{name}_cost_siou"])
+
+
+def test_frame_pixels(golden):
+    """640 x 480 frame fixture (tester.py:58-77 on 3319 + 1024 pixels of one pose): the oracle on a slice of both weight sets."""
+    g = golden("frame")
+    H, W = [int(v) for v in g["HW"]]
+    ins_num = int(g["ins_num"])
+    ro, rd = O.get_rays_k(H, W, g["K"].numpy(), g["c2w"])
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    for name, kw, tol in (("plain", dict(gain=1.7, sigma_bias=0.3), 2e-4), ("peaky", O.PEAKY, 5e-2)):
+        s_c, s_f = [int(v) for v in g[f"{name}_seeds"]]
+        pix = g[f"{name}_pix"][:96]
+        rays = torch.stack([ro[pix], rd[pix]], 0)
+        z = O.z_val_sample(len(pix), 4.0, 15.0, 64)
+        with torch.no_grad():
+            out = O.dm_nerf(rays, O.make_weights(s_c, ins_num, **kw), O.make_weights(s_f, ins_num, **kw), z, perturb=0.)
+        close(out['rgb_coarse'], g[f"{name}_rgb_coarse"][:96], rtol=1e-5, atol=1e-5)
+        assert float((out['rgb_fine'] - g[f"{name}_rgb"][:96]).abs().max()) <= tol
+        assert float((out['ins_fine'].argmax(-1) != g[f"{name}_label"][:96]).float().mean()) <= 0.03
+    assert len(np.unique(g["peaky_label"].numpy())) >= 6                  # the peaky frame has a varied label map
+
+
+def test_scannet_step_forward_slice(golden):
+    """ScanNet-form step fixture (train_scannet.py:24-64, 3072 rays): batch selection re-derived from the seeds, and the oracle's
+    forward on the first 64 and the labelled last 64 rays with the recorded jitter."""
+    g = golden("scannet_step")
+    H, W = [int(v) for v in g["HW"]]
+    ins_num = int(g["ins_num"])
+    N, N_ins = [int(v) for v in g["N"]]
+    rgb, lab, crop, ins_index = O.scannet_scene(H, W, ins_num)
+    assert len(ins_index) == int(g["ins_index_len"]) and N_ins == int(N * 0.3)
+    # get_select_crop's draws (helpers.py:64-95) on the recorded numpy stream
+    np.random.seed(0)
+    labeled = ins_index[np.random.choice(ins_index.shape[0], size=[N_ins], replace=False)]
+    crop_idx = np.where(crop.reshape(-1) == 1)[0]
+    unl = crop_idx[np.random.choice(len(set(crop_idx.tolist()) - set(labeled.tolist())), size=[N - N_ins], replace=False)]
+    assert np.random.rand() == float(g["next_rand"])
+    flat = np.concatenate([unl, labeled])
+    assert torch.equal(rgb.reshape(-1, 3)[flat], g["target_c"])
+    assert torch.equal(torch.from_numpy(lab.reshape(-1)[labeled].astype(np.int32)), g["target_i"])
+    ro, rd = O.get_rays_k(H, W, g["K"].numpy(), g["c2w"][:3, :4])
+    close(rd.reshape(-1, 3)[flat], g["rays"][1], rtol=1e-6, atol=1e-7)
+    s_c, s_f, s_jit, _ = [int(v) for v in g["seeds"]]
+    torch.manual_seed(s_jit)
+    t_rand, u = torch.rand(N, 64), torch.rand(N, 128)
+    sel = torch.cat([torch.arange(64), torch.arange(N - 64, N)])
+    z = O.z_val_sample(128, 0.0, 9.5, 64)
+    with torch.no_grad():
+        out = O.dm_nerf(g["rays"][:, sel], O.make_weights(s_c, ins_num, gain=1.7, sigma_bias=0.3), O.make_weights(s_f, ins_num, gain=1.7, sigma_bias=0.3),
+                        z, perturb=1.0, is_train=True, N_ins=64, t_rand=t_rand[sel], u=u[sel])
+    close(out['rgb_coarse'], g["rgb_coarse"][sel], rtol=1e-5, atol=1e-5)
+    close(out['ins_coarse'], g["ins_coarse"][-64:], rtol=1e-5, atol=1e-5)
+    close(out['z_vals_fine'], g["z_vals_fine"][sel], rtol=0, atol=5e-2)
+    assert float(((out['z_vals_fine'] - g["z_vals_fine"][sel]).abs() > 1e-4).float().mean()) <= 2e-3
+    close(out['rgb_fine'], g["rgb_fine"][sel], rtol=1e-3, atol=1e-3)
+
+
+def test_manipulator_stages(golden):
+    """Recorded intermediates of one run of the reference's manipulator(): the oracle's stages on the golden inputs."""
+    g = golden("manipulator_stages")
+    labels = [int(v) for v in g["labels"]]
+    # first exchanger call: exact
+    out = O.exchanger(g["ex1_ori_raw_in"].clone(), [g["ex1_tar_raw0"].clone(), g["ex1_tar_raw1"].clone()], g["ex1_ori_acc"],
+                      [g["ex1_tar_acc0"], g["ex1_tar_acc1"]], labels)
+    assert torch.equal(out[0], g["ex1_out_raw"])
+    # step 2: weights of the edited coarse field, the fourth resampling, the merged depths, the second exchanger, the final render
+    _, w, _, _ = O.manipulator_render(g["ex1_out_raw"], g["s2_z"], g["ori_rays"][1])
+    close(w, g["s2_w"])
+    assert torch.equal(g["s2_w"][..., 1:-1], g["pdf3_w"])
+    mid = .5 * (g["s2_z"][..., 1:] + g["s2_z"][..., :-1])
+    close(O.sample_pdf(mid, g["pdf3_w"], 128, u=g["pdf3_u"]), g["pdf3_out"], rtol=1e-5, atol=1e-5)
+    merged = torch.sort(torch.cat([g["s2_z"], g["pdf3_out"], g["pdf1_out"], g["pdf2_out"]], -1), -1)[0]
+    assert torch.equal(merged, g["s2_ori_z_merged"])
+    out = O.exchanger(g["s2_ori_raw"].clone(), [g["s2_tar_raw0"].clone(), g["s2_tar_raw1"].clone()], g["ex1_ori_acc"],
+                      [g["ex1_tar_acc0"], g["ex1_tar_acc1"]], labels)
+    assert torch.equal(out[0], g["ex2_out_raw"]) and torch.equal(out[2], g["ex2_out_ori_label"]) and torch.equal(out[3], g["ex2_out_tar_label"])
+    rgb, _, _, ins = O.manipulator_render(g["ex2_out_raw"], g["s2_ori_z_merged"], g["ori_rays"][1])
+    close(rgb, g["final_rgb"]); close(ins, g["final_ins"])
+
+
+def test_checkpoint_format_matches_the_module():
+    """The checkpoint structure the reference writes (train_dmsr.py:78-86; checkpoint_format.json was produced from the
+    reference's own DM_NeRF + Adam) against the drop-in module's state_dict -- no GPU needed for key names and shapes."""
+    import json
+    import os
+    from dm_nerf_amd.networks.dm_nerf import DM_NeRF
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_format.json")) as f:
+        fmt = json.load(f)
+    m = DM_NeRF(8, 256, 63, 27, [4], 13)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == fmt["model_keys"]
+    assert fmt["top_keys"] == ['iteration', 'network_coarse_state_dict', 'network_fine_state_dict', 'optimizer_state_dict']
+    assert fmt["state_shapes"][:2] == [[256, 63], [256]] and fmt["n_params"] == 60
