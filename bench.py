@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--no-train", action="store_true", help="skip the training-step measurements")
     p.add_argument("--no-extras", action="store_true", help="skip the frame / train_loop / opt-in inference legs")
     p.add_argument("--train-steps", type=int, default=5)
-    p.add_argument("--cpu-seconds", type=float, default=60.0,
+    p.add_argument("--cpu-seconds", type=float, default=80.0,
                    help="budget of the CPU baseline per leg: BASELINE.md section 4 asks for N=4096 render / N=1024 train, median "
                         "of 3 after a warm-up; repetitions and, on a slow host, the sample shrink to stay inside it")
     p.add_argument("--ins-num", type=int, default=INS_NUM,
@@ -294,7 +294,7 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
     t_small = one(128); t_small = one(128)                # warm-up (thread pools, allocator) + calibration
     n = 1024
     est = t_small * n / 128 * 1.3                         # the step grows a little faster than linearly with the batch
-    reps = 3 if est * 4.5 <= seconds else (1 if est * 2.2 <= seconds else 0)
+    reps = 3 if est * 4.2 <= seconds else (1 if est * 2.2 <= seconds else 0)
     if reps == 0:
         n = int(max(128, min(1024, (seconds / 2.2) / (t_small * 1.3 / 128) // 128 * 128)))
         reps = 1
@@ -351,10 +351,11 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
             o = O.dm_nerf(rays_cpu[:, :n], sd_c, sd_f, z_cpu[:n], perturb=0.)
         return time.perf_counter() - t0, o
 
-    t_small, _ = one(512)                                 # warm-up + calibration
+    one(512)                                              # warm-up (thread pools, page faults)
+    t_small, _ = one(512)                                 # calibration
     n = N_RAYS
     est = t_small * n / 512
-    reps = 3 if est * 3.3 <= seconds else (1 if est * 1.1 <= seconds else 0)
+    reps = 3 if est * 3.1 <= seconds else (1 if est * 1.1 <= seconds else 0)
     if reps == 0:
         n = int(max(512, min(N_RAYS, seconds / (t_small / 512) // 512 * 512)))
         reps = 1

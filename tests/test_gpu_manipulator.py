@@ -88,11 +88,27 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
     _, w, _, _ = A.MA.manipulator_render(g["ex1_out_raw"].cuda(), g["s2_z"].cuda(), d)
     w = cpu(w)
     assert torch.allclose(w, g["s2_w"], rtol=2e-6, atol=2e-6)
-    # the 4th resampling on the reference's weights and draw: samples equal wherever the bin index agrees (>= 99.9 %)
+    # the 4th resampling (manipulator.py:186-187), on the reference's weights and draw.
+    # (i) identical (cdf, u) -> identical bin indices, exactly, and samples to roundoff (the contract's "inds exact")
+    mid = .5 * (g["s2_z"][..., 1:] + g["s2_z"][..., :-1])
+    _, cdf_o, _ = O.sample_pdf(mid, g["pdf3_w"], 128, u=g["pdf3_u"], return_aux=True)
+    s_o, inds_o = O.sample_from_cdf(mid, cdf_o, g["pdf3_u"])
+    s_d, inds_d = H.sample_from_cdf(mid.cuda(), cdf_o.cuda(), g["pdf3_u"].cuda())
+    assert torch.equal(cpu(inds_d), inds_o)
+    assert torch.allclose(cpu(s_d), s_o, rtol=1e-6, atol=1e-6)
+    # (ii) from the weights: with 'trained-like' weights most bins are EMPTY, i.e. carry exactly the 1e-5 the reference adds
+    # (helpers.py:125), their pdf is 1e-5 / (1 + 62e-5) = 0.9994e-5 -- 6e-9 below the `denom < 1e-5 -> 1` threshold of
+    # helpers.py:150-151, closer than one f32 ulp of the cdf (6e-8): which side a bin falls on is decided by the rounding
+    # of the cdf sums, in the reference as much as here.  Such threshold-critical draws (they sample empty space; the
+    # render does not see them) are set aside, every other draw must agree.
+    below, above = (inds_o - 1).clamp(min=0), inds_o.clamp(max=cdf_o.shape[-1] - 1)
+    denom = torch.gather(cdf_o, 1, above) - torch.gather(cdf_o, 1, below)
+    critical = (denom - 1e-5).abs() <= 2.4e-7                                      # within 4 ulp of the cdf
     _, zs = H.importance_resample(g["s2_z"].cuda(), g["s2_w"].cuda(), 128, u=g["pdf3_u"].cuda(), return_samples=True)
     zs = cpu(zs)
     same = (zs - g["pdf3_out"]).abs() <= 1e-5 * (1 + g["pdf3_out"].abs())
-    assert float(same.float().mean()) >= 0.999, float(same.float().mean())
+    frac_crit, agree = float(critical.float().mean()), float(same[~critical].float().mean())
+    assert agree >= 0.999 and float(same.float().mean()) >= 0.99, (agree, frac_crit, float(same.float().mean()))
     # merged depths: a pure permutation, exact
     merged = A.MA.sort_rows(torch.cat([g["s2_z"], g["pdf3_out"], g["pdf1_out"], g["pdf2_out"]], -1).cuda())
     assert torch.equal(cpu(merged), g["s2_ori_z_merged"])
@@ -123,7 +139,8 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
     assert torch.allclose(cpu(rgb), g["final_rgb"], rtol=2e-6, atol=2e-6) and torch.allclose(cpu(ins), g["final_ins"], rtol=2e-6, atol=2e-6)
     assert torch.equal(cpu(ins).argmax(-1), g["final_ins"].argmax(-1))
     with capsys.disabled():
-        print("\n[manipulator stages] fine network max |d raw|/(1+|raw|) [rgb, sigma, ins]: " + str(worst))
+        print(f"\n[manipulator stages] resampling: {frac_crit:.3f} of the draws threshold-critical, agreement on the others {agree:.5f}, overall "
+              f"{float(same.float().mean()):.5f}; fine network max |d raw|/(1+|raw|) [rgb, sigma, ins]: " + str(worst))
 
 
 def test_manipulator_whole_chain_smoke(A, golden):
