@@ -68,7 +68,8 @@ SIGNATURES = {
     "dmnerf_penalizer_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan_sizes": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
-    "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_head_product": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "dmnerf_wgrad_set_trace": (c_int, [c_vp]),
     "dmnerf_blob_split_words": (c_i64, [c_int]),
     "dmnerf_build_pack_index_split": (c_int, [c_int, c_vp, c_i64]),

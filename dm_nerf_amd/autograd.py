@@ -55,7 +55,7 @@ def _views(buf, M):
     Mp = _row_len(M)
     o = 0
     out = {}
-    for name, rows, n in (("pe", 63, 1), ("de", 27, 1), ("h", W, 8), ("f", W, 1), ("q", W, 1), ("g1", HW, 1), ("g2", HW, 1)):
+    for name, rows, n in (("pe", 63, 1), ("de", 27, 1), ("h", W, 8), ("g1", HW, 1), ("g2", HW, 1)):
         ts = []
         for _ in range(n):
             t = buf[o:o + rows * Mp].view(Mp // 32, rows, 32).permute(1, 0, 2).reshape(rows, Mp)
@@ -176,7 +176,7 @@ class MLPRaysFunction(torch.autograd.Function):
             _lib.check(lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(blob), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
                                                      N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
         ctx.model, ctx.M, ctx.save = model, M, save
-        ctx.blob, ctx.blob_t = model.blob(), model.blob_t()      # the weights this forward used
+        ctx.blob, ctx.blob_t, ctx.flat = blob, model.blob_t(), model.flat()      # the weights this forward used
         return raw
 
     @staticmethod
@@ -207,8 +207,8 @@ def _mlp_backward(ctx, g_raw):
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)
     with _timed("mlp_bwd_weights", M):
         _lib.check(lib.dmnerf_mlp_bwd_weights(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs,
-                                              _lib.ptr(outs), n_outs, _lib.ptr(part), _lib.ptr(flat), _lib.stream()),
-                   "dmnerf_mlp_bwd_weights")
+                                              _lib.ptr(outs), n_outs, _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat),
+                                              _lib.stream()), "dmnerf_mlp_bwd_weights")
     ctx.save = None
     return tuple(split_flat_grads(model, flat))
 
@@ -227,7 +227,7 @@ class MLPEmbeddedFunction(torch.autograd.Function):
         _lib.check(lib.dmnerf_mlp_fwd_embedded_train(_lib.ptr(model.blob()), ins_num, _lib.ptr(x), M, _lib.ptr(raw), _lib.ptr(save),
                                                      _lib.stream()), "dmnerf_mlp_fwd_embedded_train")
         ctx.model, ctx.M, ctx.save = model, M, save
-        ctx.blob, ctx.blob_t = model.blob(), model.blob_t()
+        ctx.blob, ctx.blob_t, ctx.flat = model.blob(), model.blob_t(), model.flat()
         return raw
 
     @staticmethod

@@ -160,17 +160,24 @@ DMN_HD inline SplitLayout make_split_layout(int ins_num) {
 
 // Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
 //   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
-constexpr int NSTAGE_T = 8;   // rgb_feature^T, mlps.7^T .. mlps.1^T (mlps.5: its 256 h-columns)
+//
+// The two feature linears have no activation (dm_nerf.py:89,96), so the backward never materialises their
+// gradients (heads.hip):  with A = rgb_feature_linears.0.weight[:, :256] and F = A . W_rgb_feature (128 x 256, formed
+// once per weight update by head_product_kernel and appended to the flat parameter vector),
+//     d h_7 (rgb branch) = W_rf^T (A^T dg1) = F^T dg1        -- ONE 128 -> 256 GEMM instead of 128 -> 256 -> 256,
+// and the ins branch, whose input is h.detach() (:95), sends nothing to h_7 at all.  The weight gradients of the four
+// linears follow from G = dg1 . h_7^T and Q = dg2 . h_7^T (wgrad.hip / heads.hip::head_unfuse_kernel).
+constexpr int NSTAGE_T = 7;   // mlps.7^T .. mlps.1^T (mlps.5: its 256 h-columns)
 constexpr int TAB_T_FLOATS = 1024;       // table of the backward blob: the two VALU heads (4 KiB)
+constexpr int HEAD_F_FLOATS = HW * W;    // F = A . W_rgb_feature, row-major [128][256], stored behind the flat parameters
 // Backward blob = [table: w_rgbo [c][half][64] | w_den [half][128]] [stream: ins_linear^T (1 padded quarter) |
-// ins_feature_linears.0^T (2) | rgb_feature_linears.0^T (2) | 8 stages x 4] [2 dummy quarters].
+// F^T (2) | 7 stages x 4] [2 dummy quarters].
 struct BlobTLayout {
     int C, OBI;
     int64_t w_rgbo, w_den;   // table
     int64_t stream;
-    int64_t t_inso;     // ins_linear^T:            K = 32*OBI logits (NKG = 4*OBI), rows 128 (OB = 4)
-    int64_t t_insh;     // ins_feature_linears.0^T: K = 128 (NKG = 16), rows 256 (OB = 8)
-    int64_t t_rgbh;     // rgb_feature_linears.0^T: K = 128 (NKG = 16), rows 256 = the rgb_feature columns (OB = 8)
+    int64_t t_inso;     // ins_linear^T:  K = 32*OBI logits (NKG = 4*OBI), rows 128 (OB = 4)
+    int64_t t_rgbf;     // F^T:           K = 128 (NKG = 16), rows 256 = the h_7 features (OB = 8)
     int64_t t_stage;    // NSTAGE_T x (NKG = 32, OB = 8)
     int64_t total;
 };
@@ -183,8 +190,7 @@ DMN_HD inline BlobTLayout make_layout_t(int ins_num) {
     int64_t o = TAB_T_FLOATS;
     L.stream = o;
     L.t_inso = o; o += QUARTER_FLOATS;
-    L.t_insh = o; o += seg_floats(16, 8);
-    L.t_rgbh = o; o += seg_floats(16, 8);
+    L.t_rgbf = o; o += seg_floats(16, 8);
     L.t_stage = o; o += NSTAGE_T * seg_floats(32, 8);
     o += 2 * QUARTER_FLOATS;
     L.total = o;
@@ -196,11 +202,11 @@ DMN_HD inline BlobTLayout make_layout_t(int ins_num) {
 // 1-bit ReLU masks: per 32-sample block [8 layers][64 lanes][4 words] + [g1][64][2] + [g2][64][2] words;
 // word (p >> 5) bit (p & 31) of a lane = (activation register p of that lane > 0), p = 16 b + r.
 constexpr int BITS_WORDS_PER_BLOCK = 8 * 64 * 4 + 2 * 64 * 2;          // 2304 = 72 per sample
-constexpr int SAVE_ROWS = POS_CH + DIR_CH + 8 * W + W + W + HW + HW + BITS_WORDS_PER_BLOCK / 32;   // 2978
+constexpr int SAVE_ROWS = POS_CH + DIR_CH + 8 * W + HW + HW + BITS_WORDS_PER_BLOCK / 32;   // 2466
 struct SaveLayout {
     int64_t pe, de;      // embed(pts) [63][M], embed(viewdirs) [27][M]
     int64_t h;           // relu outputs of mlps.0..7: [8][256][M]
-    int64_t f, q;        // rgb_feature / ins_feature (no activation): [256][M] each
+    // (rgb_feature / ins_feature are NOT saved: their weight gradients come from G = dg1 . h_7^T, Q = dg2 . h_7^T)
     int64_t g1, g2;      // relu outputs of rgb_feature_linears.0 / ins_feature_linears.0: [128][M] each
     int64_t bits;        // ReLU bit masks, BITS_WORDS_PER_BLOCK words per block (forward workspace only)
     int64_t total;
@@ -220,8 +226,6 @@ DMN_HD inline SaveLayout make_save_layout(int64_t M_samples) {
     s.pe = o; o += POS_CH * M;
     s.de = o; o += DIR_CH * M;
     s.h = o; o += 8 * (int64_t)W * M;
-    s.f = o; o += (int64_t)W * M;
-    s.q = o; o += (int64_t)W * M;
     s.g1 = o; o += (int64_t)HW * M;
     s.g2 = o; o += (int64_t)HW * M;
     s.bits = o; o += (int64_t)(BITS_WORDS_PER_BLOCK / 32) * M;

@@ -10,7 +10,8 @@
 // Gradient barriers of the reference are honoured structurally:
 //   * ins branch input is h.detach() (dm_nerf.py:95): dq is NOT added to dh_7;
 //   * no gradient flows to the encodings (rays / depths are not parameters).
-// 9280 MFMAs per 32 samples at C=14 (dgrad MACs = fwd MACs - 101 248).
+// 7744 MFMAs per 32 samples at C=14: the reference's dgrad is fwd MACs - 101 248 = 592 256 MAC per sample (SURVEY.md 8
+// a-12); folding the activation-free feature linears (layout.h, BlobTLayout) leaves 494 080 + the 1 / 3-row VALU heads.
 #include <hip/hip_runtime.h>
 
 #include "../../include/dmnerf_hip.h"
@@ -129,21 +130,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
     DMN_STAMP(1);
     f32x16 d[8], acc[8];
     {
-        // ---- ins branch: dg2 = relu'(g2) . (W_io^T g_ins);  dq = W_ih^T dg2 ----------------------
-        f32x16 t4[4], d4[4];
+        // ---- heads.  ins branch: dg2 = relu'(g2) . (W_io^T g_ins); it sends nothing to h_7 (h.detach(), dm_nerf.py:95) and
+        // d ins_feature is never formed (its weight gradients come from Q = dg2 . h_7^T, heads.hip)
+        f32x16 t4[4], dg2[4], dg1[4];
         ws_prime<4>(ws, lane);
         gemm_quarter<0, 4 * OBI, 4, 8, true>(ws, gi, t4, lane);
-        apply_mask<4>(d4, g2bits, t4);
-        // dg2 is saved while it is the B operand of the two quarters that produce dq (32 + 32 spread stores)
-        const RowIO g2io = make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane);
-        auto st_g2 = [&](int k0) { return [&, k0](int k) { store_row_one(g2io, d4, k0 + k); }; };
-        gemm_quarter<0, 8, 8, 8, true, 32>(ws, d4, acc, lane, st_g2(0));
-        gemm_quarter<8, 8, 8, 8, false, 32>(ws, d4, acc, lane, st_g2(32));
-        // acc = dq (ins_feature has no activation): saved under the rgb branch's two quarters below, which
-        // accumulate df directly into d
+        apply_mask<4>(dg2, g2bits, t4);
 
         DMN_STAMP(2);
-        // ---- rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU;  df = (W_rh^T dg1)[:256] ----
+        // rgb branch: dg1 = relu'(g1) . (W_ro^T g_rgb) on the VALU
         zero<4>(t4);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -158,46 +153,47 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
                 }
             }
         }
-        apply_mask<4>(d4, g1bits, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), d4);       // burst (once per block)
-        const RowIO qio = make_rowio(a.dsave + SL.q, 256, srows * MP, blk, lane);
-        auto st_q = [&](int k0) { return [&, k0](int k) { store_row_one(qio, acc, k0 + k); }; };
-        store_rows_part<126, 2>(qio, acc);
-        gemm_quarter<0, 8, 8, 8, true, 63>(ws, d4, d, lane, st_q(0));                     // df (rgb_feature has no activation)
-        gemm_quarter<8, 8, 8, 8, false, 63>(ws, d4, d, lane, st_q(63));
+        apply_mask<4>(dg1, g1bits, t4);
+        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), dg1);      // burst (once per block)
+        // d h_7 (rgb branch) = F^T dg1, F = rgb_hidden[:, :256] . rgb_feature (layout.h): one 128 -> 256 GEMM, two
+        // quarters; dg2 is saved meanwhile (32 + 32 spread stores)
+        const RowIO g2io = make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane);
+        auto st_g2 = [&](int k0) { return [&, k0](int k) { store_row_one(g2io, dg2, k0 + k); }; };
+        gemm_quarter<0, 8, 8, 8, true, 32>(ws, dg1, acc, lane, st_g2(0));
+        gemm_quarter<8, 8, 8, 8, false, 32>(ws, dg1, acc, lane, st_g2(32));
+    }
+    {
+        // density_linear (dm_nerf.py:101): dh_7 += w_d * g_sigma;  dy_7 = dh_7 . relu'(h_7)
+        const f32x4* wd = reinterpret_cast<const f32x4*>(tab + LT.w_den + half * 128);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const f32x4 w = wd[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = 4 * i + j;
+                acc[p >> 4][p & 15] = fmaf(w[j], g_sigma, acc[p >> 4][p & 15]);
+            }
+        }
+        apply_mask<8>(d, hbits[7], acc);
     }
 
     DMN_STAMP(3);
-    // ---- trunk: st = 0: dh_7 = W_rf^T df + w_d g_sigma;  st = k: dh_{7-k} = W_{8-k}^T dy_{8-k} -----
-    // The stage's input d (df, then dy_7 .. dy_1) is saved while it is consumed.
+    // ---- trunk: st = k: dh_{7-k} = W_{8-k}^T dy_{8-k}, k = 1..7.  The stage's input d (dy_7 .. dy_1) is saved while it
+    // is consumed: 43 + 43 + 42 TID-addressed stores in the MFMA gaps of quarters 1..3.
 #pragma nounroll
-    for (int st = 0; st < NSTAGE_T; ++st) {
-        const RowIO dio = make_rowio(st == 0 ? a.dsave + SL.f : a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
-        // dy is saved while it is consumed: 43 + 43 + 42 TID-addressed stores in the MFMA gaps of quarters 1..3
+    for (int st = 1; st <= NSTAGE_T; ++st) {
+        const RowIO dio = make_rowio(a.dsave + SL.h + (int64_t)(8 - st) * 256 * MP, 256, srows * MP, blk, lane);
         auto st_d = [&](int k0) { return [&, k0](int k) { store_row_one(dio, d, k0 + k); }; };
         gemm_quarter<0, 8, 8, 8, true>(ws, d, acc, lane);
         gemm_quarter<8, 8, 8, 8, false, 43>(ws, d, acc, lane, st_d(0));
         gemm_quarter<16, 8, 8, 8, false, 43>(ws, d, acc, lane, st_d(43));
         gemm_quarter<24, 8, 8, 8, false, 42>(ws, d, acc, lane, st_d(86));   // (the last stage prefetches from the landing zone)
-        if (st == 0) {
-            // density_linear (dm_nerf.py:101): dh_7 += w_d * g_sigma
-            const f32x4* wd = reinterpret_cast<const f32x4*>(tab + LT.w_den + half * 128);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const f32x4 w = wd[i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int p = 4 * i + j;
-                    acc[p >> 4][p & 15] = fmaf(w[j], g_sigma, acc[p >> 4][p & 15]);
-                }
-            }
-        }
         // dy_l = dh_l . relu'(h_l), l = 7 - st: the bit masks were loaded up front; select the layer with a
         // wave-uniform switch (register arrays cannot be indexed dynamically)
         unsigned mb[4];
         switch (7 - st) {
 #define DMN_PICK(l_) case l_: mb[0] = hbits[l_][0]; mb[1] = hbits[l_][1]; mb[2] = hbits[l_][2]; mb[3] = hbits[l_][3]; break;
-            DMN_PICK(0) DMN_PICK(1) DMN_PICK(2) DMN_PICK(3) DMN_PICK(4) DMN_PICK(5) DMN_PICK(6) default: DMN_PICK(7)
+            DMN_PICK(0) DMN_PICK(1) DMN_PICK(2) DMN_PICK(3) DMN_PICK(4) DMN_PICK(5) default: DMN_PICK(6)
 #undef DMN_PICK
         }
         apply_mask<8>(d, mb, acc);

@@ -221,22 +221,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     // FUSED: rgb_feature_linear is folded into rgb_feature_linears.0 (blob built by the caller): h feeds the hidden layer directly
     if constexpr (!FUSED) stage(7, Next4{}, std::true_type{});
     {
-        RowIO fio;
-        if constexpr (SAVE) fio = make_rowio(a.save + SL.f, 256, srows * MP, blk, lane);
         f32x16 hid[4];
         init_bias_lds<4>(tab + L.b_rgbh, hid, half);
-        // training: rgb_feature (acc) is saved while it is this GEMM's B operand: 63 + 63 + 2 spread stores
-        auto st_f = [&](int k0) { return [&, k0](int k) { store_row_one(fio, acc, k0 + k); }; };
+        // (training does not save rgb_feature / ins_feature: the backward folds the activation-free feature linears,
+        // layout.h::BlobTLayout -- their weight gradients come from G = dg1 . h_7^T and Q = dg2 . h_7^T)
         auto& fsrc = *(FUSED ? &h : &acc);                             // the hidden layer's input: rgb_feature, or h itself when fused
-        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, fsrc, hid, lane, st_f(0));
-        gemm_quarter<16, 16, 4, 4, false, SAVE ? 63 : 0>(ws, fsrc, hid, lane, st_f(63));
+        gemm_quarter<0, 16, 4, 4>(ws, fsrc, hid, lane);
+        gemm_quarter<16, 16, 4, 4>(ws, fsrc, hid, lane);
         f32x16 dpk[1];                                                 // the parked direction encoding comes back for its one quarter
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = park()[q * 64];
             dpk[0][4 * q + 0] = v[0]; dpk[0][4 * q + 1] = v[1]; dpk[0][4 * q + 2] = v[2]; dpk[0][4 * q + 3] = v[3];
         }
-        gemm_quarter<0, 4, 4, 8, false, SAVE ? 2 : 0>(ws, dpk, hid, lane, st_f(126));
+        gemm_quarter<0, 4, 4, 8>(ws, dpk, hid, lane);
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
         if constexpr (SAVE) {
@@ -268,23 +266,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     // ---- ins branch: acc = ins_feature (input h.detach(), dm_nerf.py:95-96); hidden = relu(W ins_feature) (:97-99)
     if constexpr (!FUSED) stage(8, Next4{}, std::false_type{});          // re-reads h_7: already saved
     {
-        RowIO qio;
-        if constexpr (SAVE) qio = make_rowio(a.save + SL.q, 256, srows * MP, blk, lane);
         f32x16 hid[4];
         init_bias_lds<4>(tab + L.b_insh, hid, half);
-        // training: ins_feature (acc) saved while it is the B operand (63 + 63), its last two registers and the first
-        // part of the hidden layer (g2) under the ins_linear quarter, the rest of g2 as one short burst
-        auto st_q = [&](int k0) { return [&, k0](int k) { store_row_one(qio, acc, k0 + k); }; };
         auto& qsrc = *(FUSED ? &h : &acc);
-        gemm_quarter<0, 16, 4, 4, false, SAVE ? 63 : 0>(ws, qsrc, hid, lane, st_q(0));
-        gemm_quarter<16, 16, 4, OBI, false, SAVE ? 63 : 0>(ws, qsrc, hid, lane, st_q(63));
+        gemm_quarter<0, 16, 4, 4>(ws, qsrc, hid, lane);
+        gemm_quarter<16, 16, 4, OBI>(ws, qsrc, hid, lane);
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
+        // training: the hidden layer (g2) is saved under the ins_linear quarter (43 / 63 spread stores), the rest as one short burst
         constexpr int NS3 = SAVE ? (OBI == 1 ? 43 : 63) : 0;          // side slots of the ins_linear quarter
         RowIO g2io;
         if constexpr (SAVE) {
             g2io = make_rowio(a.save + SL.g2, 128, srows * MP, blk, lane);
-            store_rows_part<NS3 - 2, 64 - (NS3 - 2)>(g2io, hid);
+            store_rows_part<NS3, 64 - NS3>(g2io, hid);
             unsigned m[2];
             pack_mask<4>(hid, m);
             __builtin_amdgcn_raw_buffer_store_b32(m[0], bits_rs, (int)((blk * BITS_WORDS_PER_BLOCK + 2176 + lane * 2) * 4), 0, 0);
@@ -292,7 +286,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         }
         f32x16 io[OBI];
         init_bias_lds<OBI>(tab + L.b_inso, io, half);
-        auto st_3 = [&](int k) { if (k < 2) store_row_one(qio, acc, 126 + k); else store_row_one(g2io, hid, k - 2); };
+        auto st_3 = [&](int k) { store_row_one(g2io, hid, k); };
         gemm_quarter<0, 16, OBI, 0, false, NS3>(ws, hid, io, lane, st_3);   // ins_linear (:103); its fetch runs into the zero-filled landing zone
         const int64_t ms = sample_of_lane();
         const int hf = fresh(half);

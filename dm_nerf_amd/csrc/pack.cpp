@@ -6,43 +6,11 @@
 #include "../../include/dmnerf_hip.h"
 #include "common.h"
 #include "layout.h"
+#include "params.h"
 
 using namespace dmn;
 
 namespace {
-
-// One reference nn.Linear in the flat parameter vector (weight [out,in] row-major, then bias).
-struct Lin {
-    int64_t w_off, b_off;
-    int out, in;
-    int64_t w(int o, int i) const { return (o < out && i >= 0 && i < in) ? w_off + (int64_t)o * in + i : -1; }
-    int64_t b(int o) const { return o < out ? b_off + o : -1; }
-};
-
-struct Params {
-    Lin mlps[8], rgb_feature, ins_feature, rgb_hidden, ins_hidden, density, ins_out, rgb_out;
-    int64_t total;
-};
-
-// DM_NeRF.__init__ order (networks/dm_nerf.py:59-78)
-Params make_params(int ins_num) {
-    Params P;
-    int64_t o = 0;
-    auto add = [&](Lin& l, int out, int in) {
-        l.out = out; l.in = in; l.w_off = o; o += (int64_t)out * in; l.b_off = o; o += out;
-    };
-    add(P.mlps[0], W, POS_CH);
-    for (int i = 1; i < 8; ++i) add(P.mlps[i], W, i == 5 ? W + POS_CH : W);
-    add(P.rgb_feature, W, W);
-    add(P.ins_feature, W, W);
-    add(P.rgb_hidden, HW, W + DIR_CH);
-    add(P.ins_hidden, HW, W);
-    add(P.density, 1, W);
-    add(P.ins_out, ins_num + 1, HW);
-    add(P.rgb_out, 3, HW);
-    P.total = o;
-    return P;
-}
 
 enum KMap { K_ACC, K_POS, K_DIR };
 
@@ -197,10 +165,13 @@ extern "C" int dmnerf_build_pack_index_t(int ins_num, int32_t* idx, int64_t n_id
     const Params P = make_params(ins_num);
     for (int64_t i = 0; i < L.total; ++i) idx[i] = -1;
     fill_seg_t(idx, L.t_inso, P.ins_out, 4 * L.OBI, 4);
-    fill_seg_t(idx, L.t_insh, P.ins_hidden, 16, 8);
-    fill_seg_t(idx, L.t_rgbh, P.rgb_hidden, 16, 8);          // rows 0..255 = the rgb_feature columns; dirs get no gradient
-    const Lin* stage[NSTAGE_T] = {&P.rgb_feature, &P.mlps[7], &P.mlps[6], &P.mlps[5], &P.mlps[4],
-                                  &P.mlps[3], &P.mlps[2], &P.mlps[1]};
+    // F = rgb_feature_linears.0.weight[:, :256] . rgb_feature_linear.weight: a [128][256] matrix that
+    // dmnerf_head_product writes BEHIND the flat parameters (indices >= param_count); as a "layer" it maps the 256 h_7
+    // features to the 128 hidden units, and its transpose carries dg1 back to h_7 in one GEMM (layout.h)
+    Lin F;
+    F.w_off = P.total; F.b_off = -1; F.out = HW; F.in = W;
+    fill_seg_t(idx, L.t_rgbf, F, 16, 8);
+    const Lin* stage[NSTAGE_T] = {&P.mlps[7], &P.mlps[6], &P.mlps[5], &P.mlps[4], &P.mlps[3], &P.mlps[2], &P.mlps[1]};
     for (int s = 0; s < NSTAGE_T; ++s) fill_seg_t(idx, L.t_stage + s * seg_floats(32, 8), *stage[s], 32, 8);
     // table: the VALU heads in accumulator order (same packing as the forward table)
     for (int c = 0; c < 3; ++c)

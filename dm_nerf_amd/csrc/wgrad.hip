@@ -30,6 +30,9 @@
 #include "common.h"
 #include "layout.h"
 #include "mlp_common.h"
+#include "params.h"
+
+int dmn_head_unfuse(const float* d_flat, int ins_num, const float* d_G, const float* d_Q, float* d_grad, hipStream_t stream);   // heads.hip
 
 using namespace dmn;
 
@@ -61,7 +64,8 @@ struct WgOut {
     int64_t out_off, bias_out_off;    // float offsets into the flat gradient vector (reference order); bias -1 = none
     int n_slices, rowsA, rowsB, ldp;  // ldp = NBB*32
     int ld_out, col_off, bias_sub, ldb;        // bias_sub shares per slice, ldb = NBA*32 apart
-    int perm_a, perm_b, pad0, pad1;            // operand rows are in the accumulator-layout memory order (layout.h::row_feature)
+    int perm_a, perm_b, to_scratch, pad1;      // operand rows are in the accumulator-layout memory order (layout.h::row_feature);
+                                               // to_scratch: out_off addresses the head of the partials workspace (G / Q of heads.hip)
 };
 
 struct WgArgs {
@@ -265,9 +269,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
 }
 
 // Adds the per-slice partials in slice order into the flat gradient vector.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const WgOut* __restrict__ outs, int n_outs,
-                                    float* __restrict__ grad) {
+__global__ void wgrad_reduce_kernel(float* __restrict__ part, const WgOut* __restrict__ outs, int n_outs,
+                                    float* __restrict__ grad_flat) {
     const WgOut o = outs[blockIdx.y];
+    float* __restrict__ grad = o.to_scratch ? part : grad_flat;        // (the bias of a scratch output still goes to the gradient)
     const int64_t n_w = (int64_t)o.rowsA * o.rowsB;
     const int64_t n_all = n_w + (o.bias_out_off >= 0 ? o.rowsA : 0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_all; e += (int64_t)gridDim.x * blockDim.x) {
@@ -283,7 +288,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const WgOut*
             const float* p = part + o.bias_part_off + r;
             for (int k = 0; k < o.n_slices; ++k)
                 for (int q = 0; q < o.bias_sub; ++q) s += p[k * o.bias_slice_stride + (int64_t)q * o.ldb];
-            grad[o.bias_out_off + (o.perm_a ? row_feature(r) : r)] = s;
+            grad_flat[o.bias_out_off + (o.perm_a ? row_feature(r) : r)] = s;
         }
     }
 }
@@ -318,15 +323,16 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
     const int64_t Mp = save_row_len(M);
     const int nchunks = (int)(Mp / KT);
     // row indices inside the SaveLayout buffers
-    const int64_t R_pe = 0, R_de = POS_CH, R_h = POS_CH + DIR_CH, R_f = R_h + 8 * W, R_q = R_f + W, R_g1 = R_q + W, R_g2 = R_g1 + HW;
+    const int64_t R_pe = 0, R_de = POS_CH, R_h = POS_CH + DIR_CH, R_g1 = R_h + 8 * W, R_g2 = R_g1 + HW;
     // flat gradient offsets
-    int64_t off = 0;
-    auto lin = [&](int out, int in, int64_t& w_off, int64_t& b_off) { w_off = off; off += (int64_t)out * in; b_off = off; off += out; };
-    int64_t w_m[8], b_m[8], w_rf, b_rf, w_if, b_if, w_rh, b_rh, w_ih, b_ih, w_d, b_d, w_io, b_io, w_ro, b_ro;
-    lin(W, POS_CH, w_m[0], b_m[0]);
-    for (int l = 1; l < 8; ++l) lin(W, l == 5 ? W + POS_CH : W, w_m[l], b_m[l]);
-    lin(W, W, w_rf, b_rf); lin(W, W, w_if, b_if); lin(HW, W + DIR_CH, w_rh, b_rh); lin(HW, W, w_ih, b_ih);
-    lin(1, W, w_d, b_d); lin(C, HW, w_io, b_io); lin(3, HW, w_ro, b_ro);
+    const Params PP = make_params(ins_num);
+    int64_t w_m[8], b_m[8];
+    for (int l = 0; l < 8; ++l) { w_m[l] = PP.mlps[l].w_off; b_m[l] = PP.mlps[l].b_off; }
+    const int64_t w_rh = PP.rgb_hidden.w_off, b_rh = PP.rgb_hidden.b_off, b_ih = PP.ins_hidden.b_off;
+    const int64_t w_d = PP.density.w_off, b_d = PP.density.b_off, w_io = PP.ins_out.w_off, b_io = PP.ins_out.b_off;
+    const int64_t w_ro = PP.rgb_out.w_off, b_ro = PP.rgb_out.b_off;
+    // scratch outputs at the head of the partials workspace: G = dg1 . h_7^T and Q = dg2 . h_7^T, [128][256] each (heads.hip)
+    const int64_t S_G = 0, S_Q = HEAD_F_FLOATS;
 
     std::vector<JobDesc> d;
     // src ids: 0 = save (x), 1 = dsave (dy), 2 = transposed d raw [blk][4+C][32]
@@ -337,11 +343,12 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
         d.push_back({1, R_h + (int64_t)l * W, W, 0, 0, R_h + (int64_t)(l - 1) * W, W, 0, W, W, 0, w_m[l], ld, 0, b_m[l]});
         if (l == 5) d.push_back({1, R_h + 5 * W, W, 0, 0, R_pe, POS_CH, 0, W, POS_CH, 0, w_m[5], ld, W, -1});   // cat[h, pts] (dm_nerf.py:87)
     }
-    d.push_back({1, R_f, W, 0, 0, R_h + 7 * W, W, 0, W, W, 0, w_rf, W, 0, b_rf});
-    d.push_back({1, R_q, W, 0, 0, R_h + 7 * W, W, 0, W, W, 0, w_if, W, 0, b_if});
-    d.push_back({1, R_g1, HW, 0, 0, R_f, W, 0, HW, W, 0, w_rh, W + DIR_CH, 0, b_rh});
+    // the four linears around the activation-free feature layers: G and Q (scratch) + the two hidden bias gradients here,
+    // d rgb_feature_linear(s), d ins_feature_linear(s) from them in head_unfuse_kernel
+    const size_t i_G = d.size();
+    d.push_back({1, R_g1, HW, 0, 0, R_h + 7 * W, W, 0, HW, W, 0, S_G, W, 0, b_rh});
+    d.push_back({1, R_g2, HW, 0, 0, R_h + 7 * W, W, 0, HW, W, 0, S_Q, W, 0, b_ih});
     d.push_back({1, R_g1, HW, 0, 0, R_de, DIR_CH, 0, HW, DIR_CH, 0, w_rh, W + DIR_CH, W, -1});                 // cat[rgb_feature, dirs] (:90)
-    d.push_back({1, R_g2, HW, 0, 0, R_q, W, 0, HW, W, 0, w_ih, W, 0, b_ih});
     d.push_back({2, 0, GT, 3, 0, R_h + 7 * W, W, 0, 1, W, 0, w_d, W, 0, b_d});                                  // density_linear
     d.push_back({2, 0, GT, 4, 0, R_g2, HW, 0, C, HW, 0, w_io, HW, 0, b_io});                                   // ins_linear
     d.push_back({2, 0, GT, 0, 0, R_g1, HW, 0, 3, HW, 0, w_ro, HW, 0, b_ro});                                   // rgb_linear
@@ -371,6 +378,7 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
     }
 
     Plan P;
+    P.part_floats = 2 * HEAD_F_FLOATS;                                       // G | Q first, the per-slice partials behind them
     for (size_t jk = 0; jk < d.size(); ++jk) {
         auto& j = d[jk];
         const int nba = CLS_NBA[j.cls], nbb = CLS_NBB[j.cls];
@@ -383,8 +391,9 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
         o.out_off = j.out_off; o.bias_out_off = j.bias_out_off;
         o.n_slices = ns; o.rowsA = j.rowsA; o.rowsB = j.rowsB; o.ldp = nbb * 32; o.ld_out = j.ld_out; o.col_off = j.col_off;
         o.bias_sub = nshare; o.ldb = nba * 32;
+        o.to_scratch = (jk == i_G || jk == i_G + 1) ? 1 : 0;
         o.perm_a = j.a_src == 1;                                            // dy tensors of the dgrad pass
-        o.perm_b = !(j.b_base == R_pe || j.b_base == R_de);                 // saved h / f / q / g1 / g2 (not the encodings)
+        o.perm_b = !(j.b_base == R_pe || j.b_base == R_de);                 // saved h / g1 / g2 (not the encodings)
         P.outs.push_back(o);
         for (int s = 0; s < ns; ++s) {
             WgJob g{};
@@ -434,9 +443,10 @@ extern "C" int dmnerf_wgrad_set_trace(int64_t* d_ticks) {
 
 extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                                       const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
-                                      float* d_part, float* d_grad_flat, void* stream) {
-    if (!d_save || !d_dsave || !d_graw_t || !d_jobs || !d_outs || !d_part || !d_grad_flat || M < 1 || n_jobs < 1 || n_outs < 1)
+                                      const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream) {
+    if (!d_save || !d_dsave || !d_graw_t || !d_jobs || !d_outs || !d_params_flat || !d_part || !d_grad_flat || M < 1 || n_jobs < 1 || n_outs < 1)
         return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights: bad argument");
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights: ins_num %d unsupported", ins_num);
     WgArgs a{};
     a.src[0] = d_save; a.src[1] = d_dsave; a.src[2] = d_graw_t;
     a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_wgrad_trace;
@@ -450,5 +460,8 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, (unsigned)n_outs), dim3(256), 0, (hipStream_t)stream,
                        d_part, (const WgOut*)d_outs, n_outs, d_grad_flat);
-    return dmn_check_launch("mlp_bwd_weights: reduce");
+    rc = dmn_check_launch("mlp_bwd_weights: reduce");
+    if (rc) return rc;
+    // rgb_feature_linear(s) / ins_feature_linear(s) from G, Q and the hidden layers' bias gradients (heads.hip)
+    return dmn_head_unfuse(d_params_flat, ins_num, d_part, d_part + HEAD_F_FLOATS, d_grad_flat, (hipStream_t)stream);
 }

@@ -80,8 +80,8 @@ class DM_NeRF(nn.Module):
         self._blob_key = None
         self._blob_t = None
         self._blob_t_key = None
-        self._blob_f = self._blob_s = None
-        self._blob_f_key = self._blob_s_key = None
+        self._blob_f = self._blob_s = self._flat = None
+        self._blob_f_key = self._blob_s_key = self._flat_key = None
 
     # -- kernel-layout weights --------------------------------------------------------------
     def _check_supported(self):
@@ -98,8 +98,19 @@ class DM_NeRF(nn.Module):
         ``optimizer.step()``, ``load_state_dict`` and any in-place op on the parameter itself.  Updates made THROUGH
         ``.data`` (``p.data.add_(...)``, hand-written optimizers, EMA / weight-clipping code) do not bump ``_version``:
         call this after them, or the kernels keep using the stale copy."""
-        self._blob_key = self._blob_t_key = None
+        self._blob_key = self._blob_t_key = self._flat_key = None
         self._blob_f_key = self._blob_s_key = None
+
+    def flat(self):
+        """The parameters as ONE flat f32 vector in state_dict order (what the packers gather from and what the backward's
+        head kernels read, csrc/heads.hip); a NEW tensor whenever a parameter changed, so a pending backward keeps the
+        vector its forward used."""
+        state = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in state.values())
+        if getattr(self, "_flat", None) is None or key != self._flat_key:
+            self._flat = weights.flat_params(state)
+            self._flat_key = key
+        return self._flat
 
     def blob(self):
         """Kernel-layout weights, refreshed if any parameter was updated in place or replaced (see ``invalidate_blobs``)."""
@@ -107,7 +118,7 @@ class DM_NeRF(nn.Module):
         state = dict(self.named_parameters())
         key = tuple((p.data_ptr(), p._version) for p in state.values())
         if self._blob is None or key != self._blob_key:
-            self._blob = weights.pack_blob(state, self.ins_num, out=self._blob if self._blob is not None
+            self._blob = weights.pack_blob(state, self.ins_num, flat=self.flat(), out=self._blob if self._blob is not None
                                            and self._blob.device == next(iter(state.values())).device else None)
             self._blob_key = key
         return self._blob
@@ -139,7 +150,7 @@ class DM_NeRF(nn.Module):
         state = dict(self.named_parameters())
         key = tuple((p.data_ptr(), p._version) for p in state.values())
         if self._blob_t is None or key != self._blob_t_key:
-            self._blob_t = weights.pack_blob(state, self.ins_num, transposed=True)
+            self._blob_t = weights.pack_blob(state, self.ins_num, transposed=True, flat=self.flat())
             self._blob_t_key = key
         return self._blob_t
 

@@ -101,16 +101,26 @@ def pack_blob_split(state, ins_num):
     return blob
 
 
-def pack_blob(state, ins_num, out=None, transposed=False, fused=False):
+HEAD_F_FLOATS = 128 * 256        # layout.h::HEAD_F_FLOATS
+
+
+def pack_blob(state, ins_num, out=None, transposed=False, fused=False, flat=None):
     """Build (or refresh in place) the kernel blob for one DM_NeRF model (``transposed``: the W^T
     blob of the backward data-gradient kernel; ``fused``: the inference blob with the feature linears folded
-    into the hidden layers)."""
+    into the hidden layers).  ``flat``: the flat parameter vector if the caller already has it."""
     lib = _lib.load()
-    flat = flat_params(fuse_heads(state) if fused else state)
+    flat = flat_params(fuse_heads(state) if fused else state) if flat is None else flat
     if flat.numel() != lib.dmnerf_param_count(ins_num):
         raise ValueError(f"parameter count {flat.numel()} != {lib.dmnerf_param_count(ins_num)} "
                          f"(only D=8, W=256, skips=[4], 63+27 input channels are supported)")
     _lib.require_gpu(flat)
+    if transposed:
+        # the W^T blob also carries F = rgb_feature_linears.0.weight[:, :256] . rgb_feature_linear.weight (csrc/heads.hip):
+        # formed on the device behind the flat parameters, gathered like any other weight
+        ext = torch.empty(flat.numel() + HEAD_F_FLOATS, dtype=torch.float32, device=flat.device)
+        ext[:flat.numel()] = flat
+        _lib.check(lib.dmnerf_head_product(_lib.ptr(flat), ins_num, _lib.ptr(ext[flat.numel():]), _lib.stream()), "dmnerf_head_product")
+        flat = ext
     idx = pack_index(ins_num, flat.device, transposed, fused)
     n = idx.numel()
     if out is None:

@@ -136,8 +136,9 @@ int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const float* d_ra
 /* Training forward of dmnerf_mlp_fwd_rays: additionally saves every layer input / relu output into
  * d_save (dmnerf_train_save_floats(M) floats, M = N*S, Mp = M rounded up to 32).  Each tensor with R
  * rows is stored block-major: addr(sample m, row) = ((m/32 * R + row) * 32 + m%32); tensors in order:
- *   embed(pts) R=63 | embed(dirs) R=27 | h_0..h_7 8 x R=256 | rgb_feature 256 | ins_feature 256 |
- *   rgb hidden 128 | ins hidden 128, each R*Mp floats, then the 1-bit ReLU masks.
+ *   embed(pts) R=63 | embed(dirs) R=27 | h_0..h_7 8 x R=256 | rgb hidden 128 | ins hidden 128,
+ *   each R*Mp floats, then the 1-bit ReLU masks.  (rgb_feature / ins_feature are not saved: they have no
+ *   activation, dm_nerf.py:89,96, and the backward re-associates around them -- see dmnerf_head_product.)
  * In the 256- and 128-row tensors (not the two encodings) memory row rho holds feature
  * (rho & ~7) | ((rho & 7) >> 1) | ((rho & 1) << 2), i.e. inside each group of 8 features the rows are
  * 0,4,1,5,2,6,3,7 (the kernels' TID-addressed stores; only dmnerf_mlp_bwd_* read these buffers, and the
@@ -154,13 +155,19 @@ int dmnerf_mlp_fwd_embedded_train(const float* d_blob, int ins_num, const float*
                                   float* d_save, void* stream);
 
 /* Backward blob (W^T as MFMA A operand) and the data-gradient pass: dL/draw [M,4+C] + d_save ->
- * d_dsave (same layout as d_save): dy of mlps.0..7 in the h rows, d rgb_feature, d ins_feature,
- * d(rgb hidden pre-act), d(ins hidden pre-act).  Weight gradients are dW = dy . x^T over M.
+ * d_dsave (same layout as d_save): dy of mlps.0..7 in the h rows, d(rgb hidden pre-act), d(ins hidden pre-act).
+ * Weight gradients are dW = dy . x^T over M.
  * d_graw_t (nullable): receives dL/draw in block-major form [block][4+C][32] (zero padding columns),
  * the third operand of dmnerf_mlp_bwd_weights.
- * Gradient barriers: h.detach() on the ins branch (dm_nerf.py:95); none to the encodings.     */
+ * Gradient barriers: h.detach() on the ins branch (dm_nerf.py:95); none to the encodings.
+ * The two feature linears carry no activation, so their gradients are never materialised: with
+ * A = rgb_feature_linears.0.weight[:, :256] and F = A . rgb_feature_linear.weight [128,256], d h_7 = F^T dg1 is ONE
+ * GEMM (instead of 128 -> 256 -> 256).  dmnerf_head_product forms F (f32 fmaf chain, k ascending) from the flat
+ * parameter vector; the W^T blob gathers from [flat parameters | F]: the index of dmnerf_build_pack_index_t addresses
+ * dmnerf_param_count(ins_num) + 32768 source floats.                                             */
 int64_t dmnerf_blob_t_floats(int ins_num);
 int dmnerf_build_pack_index_t(int ins_num, int32_t* h_idx, int64_t n_idx);
+int dmnerf_head_product(const float* d_params_flat, int ins_num, float* d_F, void* stream);
 int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num, const float* d_save,
                         const float* d_graw, int64_t M, float* d_dsave, float* d_graw_t, void* stream);
 
@@ -168,14 +175,17 @@ int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num,
  * The plan (which workgroup does which job slice) depends only on (ins_num, M, max_wgs): build it once
  * on the host, upload the two tables, reuse every step.  d_graw_t = dL/draw in the same block-major
  * form, R = 4+C rows, zero in the padding columns.  d_grad_flat: dmnerf_param_count(ins_num) floats in the
- * flat parameter order above.  d_part: workspace of `part_floats` floats.                         */
+ * flat parameter order above.  d_part: workspace of `part_floats` floats.
+ * The gradients of rgb_feature_linear, ins_feature_linear and of the two hidden layers that consume them are formed from
+ * G = dg1 . h_7^T, Q = dg2 . h_7^T and the weights themselves (d_params_flat: the flat parameter vector the forward
+ * used), e.g. d rgb_feature_linear.weight = A^T G: exact algebra, f32 re-association (csrc/heads.hip).        */
 int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes,
                             int64_t* n_out_bytes, int64_t* part_floats, int* n_jobs, int* n_outs);
 int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes,
                       void* h_outs, int64_t out_bytes);
 int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
-                           float* d_part, float* d_grad_flat, void* stream);
+                           const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream);
 /* Diagnostic: when d_ticks != NULL every workgroup of the following dmnerf_mlp_bwd_weights launches writes its
  * {start, end} 100 MHz wall-clock ticks to d_ticks[2*wg], d_ticks[2*wg+1] (n_jobs pairs); NULL turns it off.
  * Used by scripts/diag_wgrad.py to fit the split-K cost model. */

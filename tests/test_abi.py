@@ -39,8 +39,8 @@ def test_host_only_calls_validate_arguments():
     lib = _lib.load()
     assert lib.dmnerf_param_count(13) == 696338
     assert lib.dmnerf_param_count(0) == -1 and lib.dmnerf_blob_floats(500) == -1
-    assert lib.dmnerf_train_save_floats(100) == 2978 * 128      # 2906 feature rows + 72 mask words per sample, rows padded to 32 samples
-    assert lib.dmnerf_blob_t_floats(13) == 1024 + (1 + 2 + 2 + 8 * 4 + 2) * 16384      # table + 37 quarters + 2 landing quarters
+    assert lib.dmnerf_train_save_floats(100) == 2466 * 128      # 2394 feature rows + 72 mask words per sample, rows padded to 32 samples
+    assert lib.dmnerf_blob_t_floats(13) == 1024 + (1 + 2 + 7 * 4 + 2) * 16384          # table + 31 quarters + 2 landing quarters
     # argument errors are reported before anything touches a device
     rc = lib.dmnerf_composite_fwd(None, None, None, 4, 64, 14, None, None, None, None, None)
     assert rc == -1 and "null" in _lib.last_error()
