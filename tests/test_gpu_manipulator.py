@@ -101,14 +101,20 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
     # helpers.py:150-151, closer than one f32 ulp of the cdf (6e-8): which side a bin falls on is decided by the rounding
     # of the cdf sums, in the reference as much as here.  Such threshold-critical draws (they sample empty space; the
     # render does not see them) are set aside, every other draw must agree.
+    # Everywhere else the sample is bins_lo + (u - cdf_lo) / denom * width: a cdf that differs in its last bits (4 ulp =
+    # 2.4e-7; the sum of the 62 weights is formed in a different order) moves it by 2.4e-7 / denom * width -- the
+    # conditioning of the reference's own formula, which is what the tolerance follows (denom is as small as 1e-5).
     below, above = (inds_o - 1).clamp(min=0), inds_o.clamp(max=cdf_o.shape[-1] - 1)
     denom = torch.gather(cdf_o, 1, above) - torch.gather(cdf_o, 1, below)
     critical = (denom - 1e-5).abs() <= 2.4e-7                                      # within 4 ulp of the cdf
+    width = torch.gather(mid, 1, above) - torch.gather(mid, 1, below)
+    tol = 1e-5 * (1 + g["pdf3_out"].abs()) + 4.8e-7 / torch.where(denom < 1e-5, torch.ones_like(denom), denom) * width
     _, zs = H.importance_resample(g["s2_z"].cuda(), g["s2_w"].cuda(), 128, u=g["pdf3_u"].cuda(), return_samples=True)
     zs = cpu(zs)
-    same = (zs - g["pdf3_out"]).abs() <= 1e-5 * (1 + g["pdf3_out"].abs())
+    same = (zs - g["pdf3_out"]).abs() <= tol
+    tight = (zs - g["pdf3_out"]).abs() <= 1e-5 * (1 + g["pdf3_out"].abs())
     frac_crit, agree = float(critical.float().mean()), float(same[~critical].float().mean())
-    assert agree >= 0.999 and float(same.float().mean()) >= 0.99, (agree, frac_crit, float(same.float().mean()))
+    assert agree >= 0.999 and float(tight.float().mean()) >= 0.99, (agree, frac_crit, float(tight.float().mean()))
     # merged depths: a pure permutation, exact
     merged = A.MA.sort_rows(torch.cat([g["s2_z"], g["pdf3_out"], g["pdf1_out"], g["pdf2_out"]], -1).cuda())
     assert torch.equal(cpu(merged), g["s2_ori_z_merged"])
@@ -139,8 +145,8 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
     assert torch.allclose(cpu(rgb), g["final_rgb"], rtol=2e-6, atol=2e-6) and torch.allclose(cpu(ins), g["final_ins"], rtol=2e-6, atol=2e-6)
     assert torch.equal(cpu(ins).argmax(-1), g["final_ins"].argmax(-1))
     with capsys.disabled():
-        print(f"\n[manipulator stages] resampling: {frac_crit:.3f} of the draws threshold-critical, agreement on the others {agree:.5f}, overall "
-              f"{float(same.float().mean()):.5f}; fine network max |d raw|/(1+|raw|) [rgb, sigma, ins]: " + str(worst))
+        print(f"\n[manipulator stages] resampling: {frac_crit:.4f} of the draws threshold-critical, within the conditioning bound on the others "
+              f"{agree:.5f}, within 1e-5 overall {float(tight.float().mean()):.5f}; fine network max |d raw|/(1+|raw|) [rgb, sigma, ins]: " + str(worst))
 
 
 def test_manipulator_whole_chain_smoke(A, golden):
