@@ -118,6 +118,13 @@ __device__ __forceinline__ void load_encoded(const float* __restrict__ e, f32x16
 #ifndef DMN_STORE_AUX
 #define DMN_STORE_AUX 0   /* cache policy bits of the activation stores (2 = nt) */
 #endif
+// Diagnostic variant (make variant NAME=nostore FLAGS=-DDMN_NO_ACT_STORES; never shipped): the activation / gradient
+// row stores compiled out, to separate what the store INSTRUCTIONS cost from what their HBM traffic does to the clock.
+#ifdef DMN_NO_ACT_STORES
+#define DMN_ACT_STORE_B32(...) ((void)0)
+#else
+#define DMN_ACT_STORE_B32(...) __builtin_amdgcn_raw_buffer_store_b32(__VA_ARGS__)
+#endif
 // Accumulator-layout tensors (h, f, q, g1, g2 and their gradients) are stored with TID-ADDRESSED stores:
 // the descriptor has stride 4 + ADD_TID_ENABLE, so lane l of a `buffer_store_dword v, off, rsrc, soffset
 // offset:imm` writes base + soffset + imm + 4 l -- one contiguous 256-byte run per instruction and NO
@@ -173,7 +180,7 @@ __device__ __forceinline__ void store_rows(const RowIO& io, const f32x16 (&v)[NB
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(v[b][r]), io.rs, run_off(0, r), (int)(io.soff + b * 4096), DMN_STORE_AUX);
+            DMN_ACT_STORE_B32(f2u(v[b][r]), io.rs, run_off(0, r), (int)(io.soff + b * 4096), DMN_STORE_AUX);
     }
 }
 
@@ -442,7 +449,7 @@ __device__ __forceinline__ void apply_mask(f32x16 (&d)[NB], const unsigned (&m)[
 // One register (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
 template <int NB>
 __device__ __forceinline__ void store_row_one(const RowIO& io, const f32x16 (&v)[NB], int p) {
-    __builtin_amdgcn_raw_buffer_store_b32(f2u(v[p >> 4][p & 15]), io.rs, run_off(0, p & 15), (int)(io.soff + (p >> 4) * 4096), DMN_STORE_AUX);
+    DMN_ACT_STORE_B32(f2u(v[p >> 4][p & 15]), io.rs, run_off(0, p & 15), (int)(io.soff + (p >> 4) * 4096), DMN_STORE_AUX);
 }
 
 // Stores registers [P0, P0 + NP) (k-pair numbering p = 16 b + r) of an accumulator-layout tensor.
@@ -450,7 +457,7 @@ template <int P0, int NP, int NB>
 __device__ __forceinline__ void store_rows_part(const RowIO& io, const f32x16 (&v)[NB]) {
 #pragma unroll
     for (int p = P0; p < P0 + NP; ++p)
-        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[p >> 4][p & 15]), io.rs, run_off(0, p & 15), (int)(io.soff + (p >> 4) * 4096), DMN_STORE_AUX);
+        DMN_ACT_STORE_B32(f2u(v[p >> 4][p & 15]), io.rs, run_off(0, p & 15), (int)(io.soff + (p >> 4) * 4096), DMN_STORE_AUX);
 }
 
 }  // namespace dmn
