@@ -39,6 +39,36 @@ __global__ void head_product_kernel(const float* __restrict__ flat, const Params
     F[e] = s;
 }
 
+// Inference-only head fusion (args.fuse_heads / args.mfma_split): the flat parameter vector with
+//   rgb_feature_linears.0.weight[:, :256] <- A W_rf,  .bias <- A b_rf + b_rh,   ins_feature_linears.0.weight <- W_ih W_if,  .bias <- W_ih b_if + b_ih
+// Products accumulated in float64 and rounded ONCE (the fused weights are then as good as f32 weights can be); everything
+// else is copied.  Once per weight update; replaces the torch float64 matmul (rocBLAS) the first version used.
+__global__ void head_fuse_params_kernel(const float* __restrict__ flat, const Params P, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.total) return;
+    float v = flat[e];
+    for (int br = 0; br < 2; ++br) {
+        const Lin& hid = br ? P.ins_hidden : P.rgb_hidden;
+        const Lin& feat = br ? P.ins_feature : P.rgb_feature;
+        if (e >= hid.w_off && e < hid.w_off + (int64_t)hid.out * hid.in) {
+            const int i = (int)((e - hid.w_off) / hid.in), j = (int)((e - hid.w_off) % hid.in);
+            if (j < W) {                                             // (the 27 direction columns of the rgb layer stay)
+                const float* __restrict__ a = flat + hid.w_off + (int64_t)i * hid.in;
+                double s = 0.0;
+                for (int k = 0; k < W; ++k) s = __builtin_fma((double)a[k], (double)flat[feat.w_off + (int64_t)k * W + j], s);
+                v = (float)s;
+            }
+        } else if (e >= hid.b_off && e < hid.b_off + hid.out) {
+            const int i = (int)(e - hid.b_off);
+            const float* __restrict__ a = flat + hid.w_off + (int64_t)i * hid.in;
+            double s = (double)flat[e];
+            for (int k = 0; k < W; ++k) s = __builtin_fma((double)a[k], (double)flat[feat.b_off + k], s);
+            v = (float)s;
+        }
+    }
+    out[e] = v;
+}
+
 // outputs, in this order: dA [128][256] | dW_rf [256][256] | db_rf [256] | dW_ih [128][256] | dW_if [256][256] | db_if [256]
 constexpr int N_DA = HW * W, N_DW = W * W;
 constexpr int UNFUSE_OUTPUTS = 2 * (N_DA + N_DW + W);
@@ -84,6 +114,14 @@ extern "C" int dmnerf_head_product(const float* d_flat, int ins_num, float* d_F,
     if (!d_flat || !d_F) return dmn_fail(DMNERF_E_ARG, "head_product: null pointer");
     hipLaunchKernelGGL(head_product_kernel, dim3((HW * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_flat, make_params(ins_num), d_F);
     return dmn_check_launch("head_product");
+}
+
+extern "C" int dmnerf_fuse_heads(const float* d_flat, int ins_num, float* d_flat_fused, void* stream) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "fuse_heads: ins_num %d unsupported", ins_num);
+    if (!d_flat || !d_flat_fused || d_flat == d_flat_fused) return dmn_fail(DMNERF_E_ARG, "fuse_heads: null or aliased pointer");
+    const Params P = make_params(ins_num);
+    hipLaunchKernelGGL(head_fuse_params_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_flat, P, d_flat_fused);
+    return dmn_check_launch("fuse_heads");
 }
 
 // (called by dmnerf_mlp_bwd_weights, wgrad.hip, after the reduction wrote G, Q and the two hidden bias gradients)

@@ -56,11 +56,19 @@ def pack_index(ins_num, device, transposed=False, fused=False):
     return _index_cache[key]
 
 
+def fused_flat(flat, ins_num):
+    """The flat parameter vector with the activation-free ``rgb_feature_linear`` / ``ins_feature_linear`` (dm_nerf.py:89,96)
+    folded into the hidden layers that consume them -- formed on the device by ``dmnerf_fuse_heads`` (float64 accumulation,
+    rounded once; csrc/heads.hip).  Inference only: the same function up to f32 re-association."""
+    out = torch.empty_like(flat)
+    _lib.check(_lib.load().dmnerf_fuse_heads(_lib.ptr(flat), ins_num, _lib.ptr(out), _lib.stream()), "dmnerf_fuse_heads")
+    return out
+
+
 def fuse_heads(state):
-    """Fold the activation-free ``rgb_feature_linear`` / ``ins_feature_linear`` (dm_nerf.py:89,96) into the hidden
-    layers that consume them: a copy of ``state`` whose ``rgb_feature_linears.0`` / ``ins_feature_linears.0`` hold
-    ``W_hidden[:, :256] @ W_feature`` (products formed in float64, rounded once) and the matching biases.
-    Inference only: the result is the same function up to f32 re-association."""
+    """The same folding on a state_dict with torch ops -- the readable statement of what ``dmnerf_fuse_heads`` computes;
+    used by the CPU tests only (the product path calls ``fused_flat``): a copy of ``state`` whose ``rgb_feature_linears.0`` /
+    ``ins_feature_linears.0`` hold ``W_hidden[:, :256] @ W_feature`` (float64, rounded once) and the matching biases."""
     st = {k: v.detach() for k, v in state.items()}
     for feat, hid in (("rgb_feature_linear", "rgb_feature_linears.0"), ("ins_feature_linear", "ins_feature_linears.0")):
         Wf, bf = st[feat + ".weight"].double(), st[feat + ".bias"].double()
@@ -81,8 +89,9 @@ def flat_params(state):
 def pack_blob_split(state, ins_num):
     """The opt-in split-bf16 inference blob: [table of the fused f32 blob | three bf16 planes of every weight]."""
     lib = _lib.load()
-    flat = flat_params(fuse_heads(state))
+    flat = flat_params(state)
     _lib.require_gpu(flat)
+    flat = fused_flat(flat, ins_num)
     total = lib.dmnerf_blob_split_words(ins_num)
     if total <= 0:
         raise ValueError(f"unsupported ins_num={ins_num}")
@@ -109,11 +118,13 @@ def pack_blob(state, ins_num, out=None, transposed=False, fused=False, flat=None
     blob of the backward data-gradient kernel; ``fused``: the inference blob with the feature linears folded
     into the hidden layers).  ``flat``: the flat parameter vector if the caller already has it."""
     lib = _lib.load()
-    flat = flat_params(fuse_heads(state) if fused else state) if flat is None else flat
+    flat = flat_params(state) if flat is None else flat
     if flat.numel() != lib.dmnerf_param_count(ins_num):
         raise ValueError(f"parameter count {flat.numel()} != {lib.dmnerf_param_count(ins_num)} "
                          f"(only D=8, W=256, skips=[4], 63+27 input channels are supported)")
     _lib.require_gpu(flat)
+    if fused:
+        flat = fused_flat(flat, ins_num)
     if transposed:
         # the W^T blob also carries F = rgb_feature_linears.0.weight[:, :256] . rgb_feature_linear.weight (csrc/heads.hip):
         # formed on the device behind the flat parameters, gathered like any other weight

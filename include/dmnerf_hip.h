@@ -168,6 +168,10 @@ int dmnerf_mlp_fwd_embedded_train(const float* d_blob, int ins_num, const float*
 int64_t dmnerf_blob_t_floats(int ins_num);
 int dmnerf_build_pack_index_t(int ins_num, int32_t* h_idx, int64_t n_idx);
 int dmnerf_head_product(const float* d_params_flat, int ins_num, float* d_F, void* stream);
+/* Inference-only head fusion (the blobs of dmnerf_mlp_fwd_rays_fused / _split): d_flat_fused = the flat parameter vector
+ * with the two hidden layers replaced by hidden . feature (products accumulated in float64, rounded once); it must not
+ * alias d_params_flat.  Pack it with the index of dmnerf_build_pack_index_fused.                                    */
+int dmnerf_fuse_heads(const float* d_params_flat, int ins_num, float* d_flat_fused, void* stream);
 int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num, const float* d_save,
                         const float* d_graw, int64_t M, float* d_dsave, float* d_graw_t, void* stream);
 

@@ -224,3 +224,24 @@ def test_error_messages_are_per_thread(A):
         t.join()
     assert seen["a"][0] == -1 and "S=5000" in seen["a"][1]
     assert seen["b"][0] == -1 and "null" in seen["b"][1]
+
+
+def test_device_head_fusion_equals_the_float64_formula(A):
+    """``dmnerf_fuse_heads`` (float64 accumulation on the device, rounded once) against the readable torch statement of the
+    same folding (weights.fuse_heads: float64 matmul): equal to the last bit except where the two f64 summation orders
+    round the final f32 differently (<= 1 ulp); the 27 direction columns and every other parameter are copied verbatim."""
+    from dm_nerf_amd import weights as Wt
+    for ins_num, seed in ((13, 21), (93, 22)):
+        sd = {k: v.cuda() for k, v in O.make_weights(seed, ins_num, gain=1.7).items()}
+        flat = Wt.flat_params(sd)
+        got = Wt.fused_flat(flat, ins_num)
+        want = Wt.flat_params(Wt.fuse_heads(sd))
+        assert got.shape == want.shape
+        changed = (got != flat)
+        assert int(changed.sum()) <= 2 * (128 * 256 + 128)                   # only the two hidden layers' fused blocks
+        ulp = (got - want).abs() / (want.abs().clamp(min=1e-30) * 2 ** -23)
+        assert float(ulp.max()) <= 1.0 and float((got != want).float().mean()) <= 1e-3
+        # the dirs columns of rgb_feature_linears.0 are untouched
+        off = sum(v.numel() for k, v in sd.items() if k.split(".")[0] in ("mlps", "rgb_feature_linear", "ins_feature_linear") and not k.startswith("rgb_feature_linears"))
+        w_rh = got[off:off + 128 * 283].reshape(128, 283)
+        assert torch.equal(w_rh[:, 256:], sd["rgb_feature_linears.0.weight"][:, 256:])
