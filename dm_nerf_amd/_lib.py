@@ -71,6 +71,10 @@ SIGNATURES = {
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_head_product": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "dmnerf_fuse_heads": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "dmnerf_gemm": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
+    "dmnerf_colsum": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
+    "dmnerf_ray_points": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_copy_cols": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp]),
     "dmnerf_wgrad_set_trace": (c_int, [c_vp]),
     "dmnerf_blob_split_words": (c_i64, [c_int]),
     "dmnerf_build_pack_index_split": (c_int, [c_int, c_vp, c_i64]),

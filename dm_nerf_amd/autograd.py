@@ -280,9 +280,11 @@ def _params(model):
 
 def run_network_train(model, rays_o, rays_d, z):
     """Differentiable (w.r.t. the parameters) fused points + encoding + MLP."""
+    if not model._fused_ok():                              # another network shape: layer by layer, its own autograd Function
+        from . import generic
+        return generic.run_network(model, rays_o, rays_d, z, train=True)
     rays_o, rays_d, z = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3)), _lib.f32(z)
     _lib.require_gpu(rays_o, rays_d, z)
-    model._check_supported()
     N, S = z.shape
     max_rays = max(1, MAX_TRAIN_SAMPLES // S)
     if N <= max_rays:

@@ -1,0 +1,207 @@
+// generic.hip -- DM_NeRF for network shapes OTHER than the one the fused kernels are specialised for.
+//
+// create_nerf (config.py:126-138) passes args.netdepth / args.netwidth / args.multires / args.multires_views through; no
+// shipped config changes them (D = 8, W = 256, multires 10 / 4 everywhere), and the register-chained kernels of
+// mlp_fwd_impl.h / mlp_bwd.hip / wgrad.hip are built around 256 = 8 accumulator blocks.  So that such a configuration
+// RUNS rather than raises, this file provides the layer-by-layer path -- slower (one pass over HBM per layer, ~1/3 of the
+// matrix pipe), same arithmetic class (f32 MFMA, an fmaf chain over k ascending per output):
+//   gemm_kernel       C[i][j] (op)= sum_k A(i,k) B(k,j)  with arbitrary element strides for both operands, so the three
+//                     products of a linear layer are one kernel:  forward  Y = X W^T  (+ bias, ReLU),
+//                     data gradient  dX = (dY W) . [H > 0],  weight gradient  dW = dY^T X  (split-K over the samples);
+//   splitk_reduce_kernel   adds the split-K partials in slice order (deterministic, no float atomics);
+//   colsum_kernel     bias gradient, column sums of dY, same two-stage scheme;
+//   ray_points_kernel pts = o + d z and the normalised view direction per sample (render.py:37,49-57), feeding
+//                     dmnerf_embed; copy_cols_kernel writes an [M, n] block into a column slice (the cat of dm_nerf.py:87,90).
+// 128 x 128 block tile, 4 waves each 64 x 64 (2 x 2 v_mfma_f32_32x32x2_f32 tiles), K chunks of 16 staged through LDS
+// k-major so that every MFMA operand read is one conflict-free ds_read_b32.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/dmnerf_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TM = 128, TN = 128, KC = 16;
+
+struct GemmArgs {
+    const float* A; int64_t sai, sak;     // A(i, k) = A[i * sai + k * sak]
+    const float* B; int64_t sbk, sbj;     // B(k, j) = B[k * sbk + j * sbj]
+    float* C; int64_t ldc;                // C[i * ldc + j]   (or the split-K workspace [split][I][J] when splits > 1)
+    int64_t I, K; int J;
+    const float* bias;                    // [J] or null
+    const float* mask; int64_t ldm;       // C *= (mask[i * ldm + j] > 0), or null
+    int relu, accumulate, splits;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+    __shared__ float As[KC][TM + 4];
+    __shared__ float Bs[KC][TN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * TM;
+    const int j0 = blockIdx.y * TN;
+    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+    // this split's K range
+    const int split = blockIdx.z;
+    const int64_t kper = ((a.K + a.splits - 1) / a.splits + KC - 1) / KC * KC;
+    const int64_t kb = (int64_t)split * kper, ke = kb + kper < a.K ? kb + kper : a.K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (f32x16)(0.f);
+    // loader: 2048 elements per operand and chunk, 8 per thread; the thread index runs along the unit-stride dimension
+    const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1;
+    for (int64_t k0 = kb; k0 < ke; k0 += KC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = e * 256 + tid;
+            int ii, kk;
+            if (a_kfast) { kk = idx & (KC - 1); ii = idx >> 4; } else { ii = idx & (TM - 1); kk = idx >> 7; }
+            const int64_t gi = i0 + ii, gk = k0 + kk;
+            As[kk][ii] = (gi < a.I && gk < ke) ? a.A[gi * a.sai + gk * a.sak] : 0.f;
+            int jj, kb2;
+            if (b_kfast) { kb2 = idx & (KC - 1); jj = idx >> 4; } else { jj = idx & (TN - 1); kb2 = idx >> 7; }
+            const int gj = j0 + jj;
+            const int64_t gk2 = k0 + kb2;
+            Bs[kb2][jj] = (gj < a.J && gk2 < ke) ? a.B[gk2 * a.sbk + (int64_t)gj * a.sbj] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const int kr = 2 * s + (lane >> 5), c = lane & 31;
+            const float a0 = As[kr][wi + c], a1 = As[kr][wi + 32 + c];
+            const float b0 = Bs[kr][wj + c], b1 = Bs[kr][wj + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: lane holds column j = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32 x 32 tile
+    float* __restrict__ C = a.splits > 1 ? a.C + (int64_t)split * a.I * a.J : a.C;
+    const int64_t ldc = a.splits > 1 ? a.J : a.ldc;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int gj = j0 + wj + 32 * y + (lane & 31);
+            if (gj >= a.J) continue;
+            const float bj = (a.bias && a.splits == 1) ? a.bias[gj] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gi = i0 + wi + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gi >= a.I) continue;
+                float v = acc[x][y][r];
+                if (a.splits == 1) {                                    // order: bias, accumulate, ReLU, mask
+                    v += bj;
+                    if (a.accumulate) v += C[gi * ldc + gj];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    if (a.mask) v = a.mask[gi * a.ldm + gj] > 0.f ? v : 0.f;
+                }
+                C[gi * ldc + gj] = v;
+            }
+        }
+}
+
+// out[i * ldo + j] (+)= sum_s part[s][i][j]   (+ bias)   in slice order
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t I, int J, float* __restrict__ out, int64_t ldo, int accumulate) {
+    const int64_t n = I * J;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(int64_t)k * n + e];
+        const int64_t i = e / J;
+        const int j = (int)(e % J);
+        float* o = out + i * ldo + j;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// part[slice][j] = sum over the slice's rows of X[m][j]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int J, int slices, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int64_t per = (M + slices - 1) / slices, m0 = (int64_t)blockIdx.y * per, m1 = m0 + per < M ? m0 + per : M;
+    float s = 0.f;
+    if (j < J)
+        for (int64_t m = m0 + q; m < m1; m += 4) s += X[m * ldx + j];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && j < J) part[(int64_t)blockIdx.y * J + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void ray_points_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ z, int64_t N, int S,
+                                  float* __restrict__ pts, float* __restrict__ dirs) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N * S) return;
+    const int64_t n = m / S;
+    const float dx = rd[n * 3], dy = rd[n * 3 + 1], dz = rd[n * 3 + 2], zv = z[m];
+    pts[m * 3 + 0] = ro[n * 3 + 0] + dx * zv;                   // render.py:49: separate multiply and add
+    pts[m * 3 + 1] = ro[n * 3 + 1] + dy * zv;
+    pts[m * 3 + 2] = ro[n * 3 + 2] + dz * zv;
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);       // render.py:37
+    dirs[m * 3 + 0] = dx / nrm; dirs[m * 3 + 1] = dy / nrm; dirs[m * 3 + 2] = dz / nrm;
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t M, int n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * n) return;
+    const int64_t m = e / n;
+    const int c = (int)(e % n);
+    dst[m * ldd + c] = src[m * lds_ + c];
+}
+
+}  // namespace
+
+extern "C" int dmnerf_gemm(const float* d_A, int64_t sai, int64_t sak, const float* d_B, int64_t sbk, int64_t sbj, float* d_C, int64_t ldc,
+                           int64_t I, int J, int64_t K, const float* d_bias, int relu, const float* d_mask, int64_t ldm, int accumulate,
+                           float* d_ws, int splits, void* stream) {
+    if (I < 0 || J < 0 || K < 0 || splits < 1) return dmn_fail(DMNERF_E_ARG, "gemm: bad sizes I=%lld J=%d K=%lld splits=%d", (long long)I, J, (long long)K, splits);
+    if (I == 0 || J == 0) return DMNERF_OK;
+    if (!d_A || !d_B || !d_C) return dmn_fail(DMNERF_E_ARG, "gemm: null pointer");
+    if (splits > 1 && (!d_ws || d_bias || relu || d_mask)) return dmn_fail(DMNERF_E_ARG, "gemm: split-K needs a workspace and takes no bias / relu / mask");
+    const int64_t ti = (I + TM - 1) / TM;
+    const int tj = (J + TN - 1) / TN;
+    if (ti > 0x7fffffffLL || tj > 65535 || splits > 65535) return dmn_fail(DMNERF_E_ARG, "gemm: grid too large");
+    GemmArgs a{};
+    a.A = d_A; a.sai = sai; a.sak = sak; a.B = d_B; a.sbk = sbk; a.sbj = sbj;
+    a.C = splits > 1 ? d_ws : d_C; a.ldc = ldc; a.I = I; a.J = J; a.K = K; a.bias = d_bias; a.mask = d_mask; a.ldm = ldm;
+    a.relu = relu; a.accumulate = accumulate; a.splits = splits;
+    hipLaunchKernelGGL(gemm_kernel, dim3((unsigned)ti, (unsigned)tj, (unsigned)splits), dim3(256), 0, (hipStream_t)stream, a);
+    int rc = dmn_check_launch("gemm");
+    if (rc || splits == 1) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)d_ws, splits, I, J, d_C, ldc, accumulate);
+    return dmn_check_launch("gemm: split-K reduce");
+}
+
+extern "C" int dmnerf_colsum(const float* d_X, int64_t ldx, int64_t M, int J, float* d_out, float* d_ws, int slices, void* stream) {
+    if (M < 0 || J < 1 || slices < 1 || slices > 65535) return dmn_fail(DMNERF_E_ARG, "colsum: bad sizes");
+    if (!d_X || !d_out || !d_ws) return dmn_fail(DMNERF_E_ARG, "colsum: null pointer");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((J + 63) / 64), (unsigned)slices), dim3(256), 0, (hipStream_t)stream, d_X, ldx, M, J, slices, d_ws);
+    int rc = dmn_check_launch("colsum");
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, (const float*)d_ws, slices, (int64_t)1, J, d_out, (int64_t)J, 0);
+    return dmn_check_launch("colsum: reduce");
+}
+
+extern "C" int dmnerf_ray_points(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, float* d_pts, float* d_dirs, void* stream) {
+    if (N < 0 || S < 1) return dmn_fail(DMNERF_E_ARG, "ray_points: bad N=%lld S=%d", (long long)N, S);
+    if (N == 0) return DMNERF_OK;
+    if (!d_rays_o || !d_rays_d || !d_z || !d_pts || !d_dirs) return dmn_fail(DMNERF_E_ARG, "ray_points: null pointer");
+    const int64_t M = N * S;
+    hipLaunchKernelGGL(ray_points_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rays_o, d_rays_d, d_z, N, S, d_pts, d_dirs);
+    return dmn_check_launch("ray_points");
+}
+
+extern "C" int dmnerf_copy_cols(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, void* stream) {
+    if (M < 0 || n < 0) return dmn_fail(DMNERF_E_ARG, "copy_cols: bad sizes");
+    if (M == 0 || n == 0) return DMNERF_OK;
+    if (!d_src || !d_dst) return dmn_fail(DMNERF_E_ARG, "copy_cols: null pointer");
+    const int64_t total = M * n;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src, ld_src, d_dst, ld_dst, M, n);
+    return dmn_check_launch("copy_cols");
+}

@@ -84,12 +84,18 @@ class DM_NeRF(nn.Module):
         self._blob_f_key = self._blob_s_key = self._flat_key = None
 
     # -- kernel-layout weights --------------------------------------------------------------
+    def _fused_ok(self):
+        """True for the shape every shipped config uses (D=8, W=256, skips=[4], 63+27 input channels; config.py:126-138
+        defaults), which the fused register-chained kernels are specialised for.  Any other shape (args.netdepth /
+        netwidth / multires*) runs layer by layer on the kernels of csrc/generic.hip (dm_nerf_amd/generic.py)."""
+        return (self.D == 8 and self.W == 256 and list(self.skips) == [4]
+                and self.input_ch_pts == 63 and self.input_ch_views == 27)
+
     def _check_supported(self):
-        if not (self.D == 8 and self.W == 256 and list(self.skips) == [4]
-                and self.input_ch_pts == 63 and self.input_ch_views == 27):
+        if not self._fused_ok():
             raise NotImplementedError(
-                "dm_nerf_amd kernels implement the configuration create_nerf builds "
-                "(D=8, W=256, skips=[4], 63+27 input channels; config.py:126-138)")
+                "the packed weight blobs exist for the fused kernels' shape only (D=8, W=256, skips=[4], 63+27 input "
+                "channels); other shapes go through dm_nerf_amd.generic")
 
     def invalidate_blobs(self):
         """Forget every cached kernel-layout copy of the weights; the next call re-packs from the parameters.
@@ -156,7 +162,13 @@ class DM_NeRF(nn.Module):
 
     def forward(self, x):
         """``[M, 63+27] -> [M, 4 + ins_num + 1]`` = cat[rgb, density, ins] (networks/dm_nerf.py:80-106)."""
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not self._fused_ok():
+            from .. import generic
+            if x.requires_grad:
+                raise NotImplementedError("dm_nerf_amd: DM_NeRF.forward gives gradients for the parameters only")
+            return generic.mlp_embedded(self, x, train)
+        if train:
             from .. import autograd
             return autograd.mlp_forward_train(self, x)
         x2 = _lib.f32(x.reshape(-1, x.shape[-1]))

@@ -29,6 +29,9 @@ def render_train(raw, z_vals, rays_d):
 def run_network(model, rays_o, rays_d, z_vals):
     """pts = o + d z -> embed(pts) | embed(d/|d|) -> ``model`` (networks/render.py:49-61 / :71-83)
     as one fused kernel: ``[N,3], [N,3], [N,S] -> raw [N,S,4+C]`` (inference only)."""
+    if not model._fused_ok():                              # another network shape: layer by layer (dm_nerf_amd/generic.py)
+        from .. import generic
+        return generic.run_network(model, rays_o, rays_d, z_vals, train=False)
     rays_o, rays_d, z = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3)), _lib.f32(z_vals)
     _lib.require_gpu(rays_o, rays_d, z)
     N, S = z.shape
@@ -81,9 +84,9 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     if training:
         from .. import autograd
         return autograd.dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=t_rand, u=u)
-    for emb, want in ((position_embedder, 63), (view_embedder, 27)):
+    for emb, want in ((position_embedder, model_fine.input_ch_pts), (view_embedder, model_fine.input_ch_views)):
         if getattr(emb, "out_dim", want) != want:
-            raise NotImplementedError("dm_nerf: only multires=10 / multires_views=4 encoders are implemented")
+            raise ValueError("dm_nerf: the embedders' out_dim does not match the models' input channels")
     rays_o, rays_d = rays
     rays_o, rays_d = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3))
     z_in = _lib.f32(z_vals_coarse)
@@ -97,13 +100,14 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     C = ins_num + 1
     perturb = float(args.perturb)
     t_rand, u, u_stride = check_draws(t_rand, u, N, S, n_imp, perturb, dev)
-    if n_imp == 0:
-        # N_importance = 0 (config.py:43 allows it; no shipped config uses it): sample_pdf returns [N, 0], the merged
-        # depths are the coarse ones (render.py:66-70) and the fine network is evaluated on them
+    if n_imp == 0 or not (model_coarse._fused_ok() and model_fine._fused_ok()):
+        # composed from the stage kernels instead of the one fused call.  N_importance = 0 (config.py:43 allows it; no
+        # shipped config uses it): sample_pdf returns [N, 0], the merged depths are the coarse ones (render.py:66-70) and the
+        # fine network is evaluated on them.  A network shape other than the shipped one: run_network goes layer by layer.
         z_c = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
         raw_c = run_network(model_coarse, rays_o, rays_d, z_c)
-        rgb_c, _, dep_c, ins_c = render_train(raw_c, z_c, rays_d)
-        z_f = z_c.clone()
+        rgb_c, w_c, dep_c, ins_c = render_train(raw_c, z_c, rays_d)
+        z_f = z_c.clone() if n_imp == 0 else helpers.importance_resample(z_c, w_c, n_imp, u=u)
         raw_f = run_network(model_fine, rays_o, rays_d, z_f)
         rgb_f, _, dep_f, ins_f = render_train(raw_f, z_f, rays_d)
         if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:

@@ -316,6 +316,24 @@ typedef struct {
 } dmnerf_render_args;
 int dmnerf_render_rays_fwd(const dmnerf_render_args* args, void* stream);
 
+/* ---- network shapes other than D = 8, W = 256, multires 10 / 4 (config.py:126-138 passes args.netdepth / netwidth /
+ * multires* through; no shipped config changes them): the layer-by-layer path of csrc/generic.hip.  One strided f32-MFMA
+ * GEMM serves the three products of a linear layer; the Python mirror (dm_nerf_amd/generic.py) chains them as
+ * DM_NeRF.forward does (networks/dm_nerf.py:80-106) and as its autograd would.
+ *   dmnerf_gemm:   C[i*ldc + j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj]   (+ bias[j], ReLU, * [mask[i*ldm + j] > 0]);
+ *                  splits > 1: split-K over k with a workspace of splits*I*J floats, partials added in slice order
+ *                  (then no bias / relu / mask).
+ *   dmnerf_colsum: out[j] = sum_m X[m*ldx + j] (bias gradient), workspace slices*J floats.
+ *   dmnerf_ray_points: pts [N*S,3] = o + d z, dirs [N*S,3] = d / |d| per sample (render.py:37,49-57).
+ *   dmnerf_copy_cols:  dst[m*ld_dst + c] = src[m*ld_src + c], c < n (the cat of dm_nerf.py:87,90 into a column slice). */
+int dmnerf_gemm(const float* d_A, int64_t sai, int64_t sak, const float* d_B, int64_t sbk, int64_t sbj, float* d_C, int64_t ldc,
+                int64_t I, int J, int64_t K, const float* d_bias, int relu, const float* d_mask, int64_t ldm, int accumulate,
+                float* d_ws, int splits, void* stream);
+int dmnerf_colsum(const float* d_X, int64_t ldx, int64_t M, int J, float* d_out, float* d_ws, int slices, void* stream);
+int dmnerf_ray_points(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, float* d_pts,
+                      float* d_dirs, void* stream);
+int dmnerf_copy_cols(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,7 +73,7 @@ def param_shapes(ins_num, W=256, input_ch_pts=63, input_ch_views=27, D=8, skips=
     return shapes
 
 
-def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0, sigma_gain=1.0, head_gain=1.0):
+def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0, sigma_gain=1.0, head_gain=1.0, D=8, input_ch_pts=63, input_ch_views=27):
     """Deterministic synthetic weights from a numpy seed (no 2.8 MB blobs in the repo).
 
     ``nn.Linear``-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)) scaled by ``gain``;
@@ -86,7 +86,7 @@ def make_weights(seed, ins_num, W=256, sigma_bias=0.0, gain=1.0, sigma_gain=1.0,
     """
     rng = np.random.RandomState(seed)
     sd = {}
-    for name, (o, i) in param_shapes(ins_num, W).items():
+    for name, (o, i) in param_shapes(ins_num, W, input_ch_pts, input_ch_views, D).items():
         bound = gain / np.sqrt(i)
         sd[name + ".weight"] = torch.from_numpy(rng.uniform(-bound, bound, size=(o, i)).astype(np.float32))
         sd[name + ".bias"] = torch.from_numpy(rng.uniform(-bound, bound, size=(o,)).astype(np.float32))
@@ -261,7 +261,8 @@ def dm_nerf(rays, sd_coarse, sd_fine, z_vals_coarse, perturb=0., N_importance=12
         e_pos = embed(pts_flat, multires)
         dirs = torch.reshape(viewdirs[:, None].expand(pts.shape), [-1, 3])
         e_dir = embed(dirs, multires_views)
-        raw = mlp_forward(sd, torch.cat([e_pos, e_dir], -1))
+        depth = sum(1 for k in sd if k.startswith("mlps.") and k.endswith(".weight"))       # netdepth (config.py:31)
+        raw = mlp_forward(sd, torch.cat([e_pos, e_dir], -1), input_ch_pts=e_pos.shape[-1], input_ch_views=e_dir.shape[-1], D=depth)
         return torch.reshape(raw, list(pts.shape[:-1]) + [raw.shape[-1]])
 
     raw_coarse = run(sd_coarse, z_vals_coarse)

@@ -1,0 +1,141 @@
+"""GPU tests (-m gpu) of network shapes other than the shipped one (config.py:126-138 passes args.netdepth / netwidth /
+multires / multires_views through): the layer-by-layer path of csrc/generic.hip + dm_nerf_amd/generic.py against the oracle --
+the strided GEMM itself in its three forms, DM_NeRF.forward, the whole dm_nerf dict, and the parameter gradients."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [dict(D=6, W=128, multires=6, multires_views=2, ins_num=5),          # narrower / shallower, fewer octaves
+          dict(D=8, W=192, multires=10, multires_views=4, ins_num=13),        # a width that is not a multiple of 128
+          dict(D=10, W=320, multires=8, multires_views=4, ins_num=40)]        # deeper / wider, two logit blocks
+
+
+@pytest.fixture(scope="module")
+def A():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from dm_nerf_amd import _lib, config as Cfg, generic as G
+    from dm_nerf_amd.networks import dm_nerf as M, helpers as H, render as R
+    _lib.load()
+    return types.SimpleNamespace(M=M, H=H, R=R, Cfg=Cfg, G=G, lib=_lib)
+
+
+def cpu(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu()
+
+
+def maxrel(a, b):
+    return float(((a - b).abs() / (1 + b.abs())).max())
+
+
+def test_strided_gemm_three_forms(A):
+    """forward  Y = relu(X W^T + b),  data gradient  (dY W) . [H > 0] (+ accumulate),  weight gradient  dY^T X  (split-K) and
+    the column sums -- ragged sizes, operands inside wider buffers -- against float64."""
+    g = torch.Generator().manual_seed(1)
+    M_, K, N = 1000, 167, 130
+    X = torch.randn(M_, K + 5, generator=g).cuda()                       # used through ld = K + 5
+    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    Y = torch.empty(M_, N + 3, device="cuda")
+    A.G._linear(X, K + 5, Wt, b, A.G._col(Y, 3), N + 3, M_, relu=True)
+    want = torch.relu(X[:, :K].double() @ Wt.double().t() + b.double())
+    assert float((Y[:, 3:].double() - want).abs().max()) <= 2e-5
+    dY = torch.randn(M_, N, generator=g).cuda()
+    H = torch.randn(M_, K, generator=g).cuda()
+    dX = torch.full((M_, K), 0.5, device="cuda")
+    A.G._dgrad(dY, N, Wt, K, dX, K, M_, mask=H, ldm=K, accumulate=True)
+    want = (dY.double() @ Wt.double() + 0.5) * (H > 0)
+    assert float((dX.double() - want).abs().max()) <= 2e-5
+    dW, db = A.G._wgrad(dY, N, N, X, K + 5, K, M_)
+    want = dY.double().t() @ X[:, :K].double()
+    assert float((dW.double() - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    assert float((db.double() - dY.double().sum(0)).abs().max()) <= 1e-4
+    assert A.G._splits(N, K, 10 ** 6) > 1
+
+
+@pytest.mark.parametrize("cfg", SHAPES)
+def test_model_forward_and_gradients_other_shapes(A, cfg):
+    D, W, ins_num = cfg["D"], cfg["W"], cfg["ins_num"]
+    inp, inv = 3 + 6 * cfg["multires"], 3 + 6 * cfg["multires_views"]
+    sd = O.make_weights(7 + D, ins_num, W=W, gain=1.5, D=D, input_ch_pts=inp, input_ch_views=inv)
+    m = A.M.DM_NeRF(D, W, inp, inv, [4], ins_num)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert not m._fused_ok()
+    g = torch.Generator().manual_seed(D)
+    Mr = 333
+    pts = (torch.rand(Mr, 3, generator=g) * 2 - 1) * 5.0
+    dirs = torch.nn.functional.normalize(torch.randn(Mr, 3, generator=g), dim=-1)
+    x = torch.cat([O.embed(pts, cfg["multires"]), O.embed(dirs, cfg["multires_views"])], -1)
+    cot = torch.randn(Mr, 4 + ins_num + 1, generator=g)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.mlp_forward(sdg, x, input_ch_pts=inp, input_ch_views=inv, D=D)
+    (want * cot).sum().backward()
+    with torch.no_grad():
+        y0 = m(x.cuda())
+    assert y0.shape == want.shape and maxrel(cpu(y0), want.detach()) <= 1e-5
+    m.train()
+    y = m(x.cuda())
+    assert y.requires_grad and torch.equal(y.detach(), y0)
+    (y * cot.cuda()).sum().backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        gw = sdg[k].grad.double()
+        err = float((p.grad.cpu().double() - gw).abs().max())
+        assert err <= 2e-4 * float(gw.abs().max()) + 1e-7, (k, err, float(gw.abs().max()))
+    # h.detach() on the ins branch (dm_nerf.py:95): an ins-only loss reaches only the three ins layers
+    m.zero_grad()
+    m(x.cuda())[:, 4:].square().sum().backward()
+    for k, p in m.named_parameters():
+        assert (float(p.grad.abs().max()) > 0) == k.startswith(("ins_feature_linear", "ins_feature_linears.0", "ins_linear")), k
+
+
+@pytest.mark.parametrize("cfg", SHAPES[:2])
+def test_dm_nerf_dict_other_shapes(A, cfg):
+    """create_nerf with non-default netdepth / netwidth / multires -> the 10-key dict against the oracle (inference and training)."""
+    ins_num = cfg["ins_num"]
+    args = types.SimpleNamespace(multires=cfg["multires"], multires_views=cfg["multires_views"], i_embed=0, netdepth=cfg["D"],
+                                 netwidth=cfg["W"], ins_num=ins_num, device=torch.device("cuda:0"))
+    pe, ve, mc, mf, _ = A.Cfg.create_nerf(args)
+    inp, inv = pe.out_dim, ve.out_dim
+    kw = dict(W=cfg["W"], gain=1.7, sigma_bias=0.3, D=cfg["D"], input_ch_pts=inp, input_ch_views=inv)
+    sd_c, sd_f = O.make_weights(31, ins_num, **kw), O.make_weights(32, ins_num, **kw)
+    mc.load_state_dict(sd_c); mf.load_state_dict(sd_f)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(70.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(cfg["D"]).choice(480 * 640, 70, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    z = O.z_val_sample(70, 4.0, 15.0, 64).contiguous()
+    eargs = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    mc.eval(); mf.eval()
+    with torch.no_grad():
+        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0., multires=cfg["multires"], multires_views=cfg["multires_views"])
+        got = {k: cpu(v) for k, v in A.R.dm_nerf(rays.cuda(), pe, ve, mc, mf, z.cuda(), eargs).items()}
+        raw_f = cpu(A.R.run_network(mf, rays[0].cuda(), rays[1].cuda(), want['z_vals_fine'].cuda()))
+    assert set(got) == set(want) and got['raw_fine'].shape == (70, 192, 4 + ins_num + 1)
+    assert maxrel(got['raw_coarse'], want['raw_coarse']) <= 1e-5 and maxrel(raw_f, want['raw_fine']) <= 1e-5
+    assert torch.allclose(got['rgb_coarse'], want['rgb_coarse'], rtol=2e-6, atol=2e-6)
+    assert torch.allclose(got['ins_coarse'], want['ins_coarse'], rtol=2e-6, atol=2e-6)
+    assert float(((got['z_vals_fine'] - want['z_vals_fine']).abs() <= 1e-4).float().mean()) >= 0.999
+    assert torch.allclose(got['rgb_fine'], want['rgb_fine'], atol=2e-3)
+    # training: gradients of an rgb + ins loss on both levels against autograd of the oracle (same fine depths)
+    mc.train(); mf.train()
+    targs = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None)
+    out = A.R.dm_nerf(rays.cuda(), pe, ve, mc, mf, z.cuda(), targs)
+    (out['rgb_fine'].sum() + out['rgb_coarse'].sum() + out['ins_fine'].sum() + out['ins_coarse'].sum()).backward()
+    sdc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    sdf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    o = O.dm_nerf(rays, sdc, sdf, z, perturb=0., multires=cfg["multires"], multires_views=cfg["multires_views"],
+                  z_fine_override=out['z_vals_fine'].detach().cpu())
+    (o['rgb_fine'].sum() + o['rgb_coarse'].sum() + o['ins_fine'].sum() + o['ins_coarse'].sum()).backward()
+    for m_, sd_ in ((mc, sdc), (mf, sdf)):
+        for k, p in m_.named_parameters():
+            gw = sd_[k].grad.double()
+            rel_l2 = float((p.grad.cpu().double() - gw).norm() / (gw.norm() + 1e-30))
+            assert rel_l2 <= 2e-3, (k, rel_l2)
