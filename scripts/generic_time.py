@@ -1,0 +1,25 @@
+import sys, time, types, torch
+sys.path.insert(0, '.')
+from dm_nerf_amd import config as Cfg
+from dm_nerf_amd.networks import helpers as H, render as R
+for D, W in ((8, 256), (8, 192), (6, 128), (10, 320)):
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=D, netwidth=W, ins_num=13, device=torch.device("cuda:0"))
+    pe, ve, mc, mf, _ = Cfg.create_nerf(args)
+    N = 4096
+    ro, rd = torch.randn(N, 3, device="cuda"), torch.randn(N, 3, device="cuda")
+    z = H.z_val_sample(N, 4., 15., 64)
+    ea = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
+    with torch.no_grad():
+        R.dm_nerf(torch.stack([ro, rd]), pe, ve, mc, mf, z, ea); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): R.dm_nerf(torch.stack([ro, rd]), pe, ve, mc, mf, z, ea)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    mac = sum(p.numel() for n, p in mc.named_parameters() if n.endswith("weight"))
+    ta = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=None)
+    mc.train(); mf.train()
+    out = R.dm_nerf(torch.stack([ro, rd]), pe, ve, mc, mf, z, ta); (out['rgb_fine'].sum() + out['ins_fine'].sum()).backward(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        out = R.dm_nerf(torch.stack([ro, rd]), pe, ve, mc, mf, z, ta); (out['rgb_fine'].sum() + out['rgb_coarse'].sum() + out['ins_fine'].sum()).backward()
+    torch.cuda.synchronize(); dtt = (time.perf_counter() - t0) / 2
+    print(f"D={D} W={W} fused={mc._fused_ok()}: render {dt*1e3:.1f} ms/4096 rays = {N/dt/1e3:.0f} k rays/s ({2*mac*256*N/dt/1e12:.1f} TFLOP/s); fwd+bwd {dtt*1e3:.1f} ms = {N/dtt/1e3:.0f} k rays/s")
