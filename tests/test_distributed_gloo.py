@@ -64,6 +64,17 @@ def _worker(rank, world, port, q):
                 p.grad = torch.full_like(p, float(rank + 1))
         nbytes = D.allreduce_grads(lin)
         g_ok = all(bool((p.grad == 3.0).all()) for m in lin for p in m.parameters())
+        # a rank WITHOUT a gradient for some tensor (its slice produced none) must still contribute the same number of
+        # elements: the bucket spans all parameters, missing gradients count as zero (unequal buckets hang)
+        for m in lin:
+            for p in m.parameters():
+                p.grad = torch.full_like(p, float(rank + 1))
+        if rank == 1:
+            lin[1].bias.grad = None
+            lin[0].weight.grad = None
+        nb2 = D.allreduce_grads(lin)
+        g_ok = g_ok and nb2 == nbytes and bool((lin[1].bias.grad == 1.0).all()) and bool((lin[0].weight.grad == 1.0).all()) \
+            and bool((lin[0].bias.grad == 3.0).all())
         # ray-sharded training step == single-process gradients (mean-squared error over the global batch)
         torch.manual_seed(0)
         lin2 = torch.nn.Linear(3, 3)
