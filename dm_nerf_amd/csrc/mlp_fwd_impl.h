@@ -54,7 +54,8 @@ struct MlpArgs {
 
 template <int OBI, bool EMBEDDED, bool SAVE, bool FUSED = false>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
-    static_assert(!(FUSED && SAVE), "the fused-heads blob is inference-only");
+    // (FUSED && SAVE = the opt-in training forward on the fused-heads blob: the backward is in re-associated form anyway,
+    // csrc/heads.hip, and needs exactly what this variant saves: pe, de, h_0..h_7, g1, g2 and the masks)
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [ring 2 x 64 KiB][table 16 KiB][park 16 KiB]
     float* const tab = lds + RING_FLOATS;
     DMN_STAMP(0);
@@ -226,15 +227,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         // (training does not save rgb_feature / ins_feature: the backward folds the activation-free feature linears,
         // layout.h::BlobTLayout -- their weight gradients come from G = dg1 . h_7^T and Q = dg2 . h_7^T)
         auto& fsrc = *(FUSED ? &h : &acc);                             // the hidden layer's input: rgb_feature, or h itself when fused
-        gemm_quarter<0, 16, 4, 4>(ws, fsrc, hid, lane);
-        gemm_quarter<16, 16, 4, 4>(ws, fsrc, hid, lane);
+        // fused training: there is no rgb_feature stage to save h_7 under -- it rides here, while it is this GEMM's B operand
+        constexpr bool SAVE_H7 = SAVE && FUSED;
+        RowIO h7io;
+        if constexpr (SAVE_H7) h7io = make_rowio(a.save + SL.h + (int64_t)7 * 256 * MP, 256, srows * MP, blk, lane);
+        auto st_h7 = [&](int k0) { return [&, k0](int k) { store_row_one(h7io, h, k0 + k); }; };
+        gemm_quarter<0, 16, 4, 4, false, SAVE_H7 ? 63 : 0>(ws, fsrc, hid, lane, st_h7(0));
+        gemm_quarter<16, 16, 4, 4, false, SAVE_H7 ? 63 : 0>(ws, fsrc, hid, lane, st_h7(63));
         f32x16 dpk[1];                                                 // the parked direction encoding comes back for its one quarter
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = park()[q * 64];
             dpk[0][4 * q + 0] = v[0]; dpk[0][4 * q + 1] = v[1]; dpk[0][4 * q + 2] = v[2]; dpk[0][4 * q + 3] = v[3];
         }
-        gemm_quarter<0, 4, 4, 8>(ws, dpk, hid, lane);
+        gemm_quarter<0, 4, 4, 8, false, SAVE_H7 ? 2 : 0>(ws, dpk, hid, lane, st_h7(126));
 #pragma unroll
         for (int b = 0; b < 4; ++b) hid[b] = relu16(hid[b]);
         if constexpr (SAVE) {

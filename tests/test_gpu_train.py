@@ -304,3 +304,48 @@ def test_penalizer_golden_value_and_gradient(A, golden):
         grad, = torch.autograd.grad(loss.sum() * 1.5, raw)
         assert float(grad[..., :4].abs().max()) == 0.0
         tclose(grad[..., 4:] / 1.5, g[f"{k}_grad"], f"penalizer grad {k}", rel=2e-5)
+
+
+def test_opt_in_fused_heads_training(A):
+    """``args.fuse_heads`` in training mode: the forward runs on the fused-heads blob (the two activation-free feature linears
+    folded into the hidden layers), the backward is the same re-associated one.  Forward inside the MLP contract against the
+    oracle (NOT bit-equal to the default path: that is why it is opt-in); per-tensor gradients against PyTorch autograd of the
+    oracle; a dm_nerf step through the flag moves the loss like the default step."""
+    for ins_num, seed, N, S in ((13, 15, 8, 64), (59, 16, 5, 33)):
+        sd = O.make_weights(seed, ins_num, gain=1.7)
+        g = torch.Generator().manual_seed(seed)
+        rays_o, rays_d = torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+        z = torch.sort(torch.rand(N, S, generator=g) * 5 + 1, -1)[0]
+        cot = torch.randn(N, S, 4 + ins_num + 1, generator=g)
+        raw_want, want = _oracle_mlp_grads(sd, rays_o, rays_d, z, cot)
+        m = model_from(A, sd, ins_num)
+        raw = A.G.run_network_train(m, rays_o.cuda(), rays_d.cuda(), z.cuda(), fused=True)
+        tclose(raw, raw_want, "raw (fused training forward)", rel=1e-5)
+        (raw * cot.cuda()).sum().backward()
+        for k, p in m.named_parameters():
+            tclose(p.grad, want[k], f"grad {k} (fused forward, ins={ins_num})")
+        with torch.no_grad():
+            layerwise = A.R.run_network(m, rays_o.cuda(), rays_d.cuda(), z.cuda())
+        assert float((raw.detach() - layerwise).abs().max()) <= 1e-5 * (1 + float(layerwise.abs().max()))
+    # through dm_nerf
+    ins_num, N = 13, 64
+    sd_c, sd_f = O.make_weights(61, ins_num, gain=1.7, sigma_bias=0.3), O.make_weights(62, ins_num, gain=1.7, sigma_bias=0.3)
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(25.0, -65.0, 7.0))
+    sel = torch.from_numpy(np.random.RandomState(6).choice(480 * 640, N, replace=False))
+    rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).cuda()
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous().cuda()
+    target = torch.rand(N, 3, generator=torch.Generator().manual_seed(7)).cuda()
+    losses = {}
+    for fused in (False, True):
+        mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
+        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
+        args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, fuse_heads=fused)
+        tr = []
+        for _ in range(3):
+            out = A.R.dm_nerf(rays, None, None, mc, mf, z, args)
+            loss = ((out['rgb_fine'] - target) ** 2).mean() + ((out['rgb_coarse'] - target) ** 2).mean() + out['ins_fine'].square().mean()
+            opt.zero_grad(); loss.backward(); opt.step()
+            tr.append(float(loss.detach()))
+        losses[fused] = tr
+    assert np.allclose(losses[True], losses[False], rtol=1e-4) and losses[True][2] < losses[True][0], losses
