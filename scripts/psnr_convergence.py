@@ -37,6 +37,16 @@ def psnr(a, b):
     return float(-10.0 * torch.log10(((a.double() - b.double()) ** 2).mean()))
 
 
+def purity(pred, gt):
+    """Permutation-invariant label quality: the Hungarian-matched loss (evaluator.py:19-74) leaves the channel <-> object
+    assignment free, so predicted channel ids are compared with the teacher's labels through the best many-to-one map:
+    sum over predicted channels of their largest overlap with one teacher label, / pixels."""
+    tot = 0
+    for c in torch.unique(pred):
+        tot += int(torch.bincount(gt[pred == c]).max())
+    return tot / pred.numel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
@@ -128,7 +138,8 @@ def main():
         "psnr_heldout_hip_db": p_hip, "psnr_heldout_oracle_db": p_ora, "abs_delta_psnr_db": abs(p_hip - p_ora),
         "psnr_untrained_db": None,
         "psnr_hip_vs_oracle_student_db": psnr(hip_rgb, ora_rgb),
-        "label_accuracy_hip": float((hip_lab == test_lab).float().mean()), "label_accuracy_oracle": float((ora_lab == test_lab).float().mean()),
+        "label_purity_hip": purity(hip_lab, test_lab), "label_purity_oracle": purity(ora_lab, test_lab),
+        "label_purity_untrained": None, "channels_used_hip": int(len(torch.unique(hip_lab))), "channels_used_oracle": int(len(torch.unique(ora_lab))),
         "label_agreement_hip_vs_oracle": float((hip_lab == ora_lab).float().mean()),
         "loss_first": [loss_hip[0], loss_ora[0]], "loss_last": [loss_hip[-1], loss_ora[-1]],
         "max_rel_loss_gap": float(max(abs(x - y) / abs(y) for x, y in zip(loss_hip, loss_ora))),
@@ -138,6 +149,7 @@ def main():
     with torch.no_grad():
         e0 = O.dm_nerf(test_rays, sd0_c, sd0_f, O.z_val_sample(H * W, NEAR, FAR, 64).contiguous(), perturb=0.)
     res["psnr_untrained_db"] = psnr(e0['rgb_fine'], test_rgb)
+    res["label_purity_untrained"] = purity(e0['ins_fine'].argmax(-1), test_lab)
     print(json.dumps(res))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
