@@ -3,8 +3,8 @@
 // create_nerf (config.py:126-138) passes args.netdepth / args.netwidth / args.multires / args.multires_views through; no
 // shipped config changes them (D = 8, W = 256, multires 10 / 4 everywhere), and the register-chained kernels of
 // mlp_fwd_impl.h / mlp_bwd.hip / wgrad.hip are built around 256 = 8 accumulator blocks.  So that such a configuration
-// RUNS rather than raises, this file provides the layer-by-layer path -- slower (one pass over HBM per layer, ~1/3 of the
-// matrix pipe), same arithmetic class (f32 MFMA, an fmaf chain over k ascending per output):
+// RUNS rather than raises, this file provides the layer-by-layer path -- slower (one pass over HBM per layer, 0.27-0.37 of
+// the matrix pipe measured), same arithmetic class (f32 MFMA, an fmaf chain over k ascending per output):
 //   gemm_kernel       C[i][j] (op)= sum_k A(i,k) B(k,j)  with arbitrary element strides for both operands, so the three
 //                     products of a linear layer are one kernel:  forward  Y = X W^T  (+ bias, ReLU),
 //                     data gradient  dX = (dY W) . [H > 0],  weight gradient  dW = dY^T X  (split-K over the samples);
@@ -12,8 +12,9 @@
 //   colsum_kernel     bias gradient, column sums of dY, same two-stage scheme;
 //   ray_points_kernel pts = o + d z and the normalised view direction per sample (render.py:37,49-57), feeding
 //                     dmnerf_embed; copy_cols_kernel writes an [M, n] block into a column slice (the cat of dm_nerf.py:87,90).
-// 128 x 128 block tile, 4 waves each 64 x 64 (2 x 2 v_mfma_f32_32x32x2_f32 tiles), K chunks of 16 staged through LDS
-// k-major so that every MFMA operand read is one conflict-free ds_read_b32.
+// 128 x 128 block tile, 4 waves each 64 x 64 (2 x 2 v_mfma_f32_32x32x2_f32 tiles), K chunks of 32 staged through LDS
+// k-major (every MFMA operand read is one conflict-free ds_read_b32), the next chunk's global loads in flight under the
+// current chunk's MFMAs.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -25,7 +26,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 128, TN = 128, KC = 16;
+constexpr int TM = 128, TN = 128, KC = 32;
+constexpr int LPT = TM * KC / 256;       // elements per thread, operand and chunk (16)
 
 struct GemmArgs {
     const float* A; int64_t sai, sak;     // A(i, k) = A[i * sai + k * sak]
@@ -37,7 +39,9 @@ struct GemmArgs {
     int relu, accumulate, splits;
 };
 
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+// AK / BK: the operand's unit-stride dimension is k (compile-time: the index arithmetic of the loader folds away)
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     __shared__ float As[KC][TM + 4];
     __shared__ float Bs[KC][TN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,23 +57,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = (f32x16)(0.f);
-    // loader: 2048 elements per operand and chunk, 8 per thread; the thread index runs along the unit-stride dimension
-    const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1;
-    for (int64_t k0 = kb; k0 < ke; k0 += KC) {
+    // Loader: TM x KC elements per operand and chunk, LPT per thread; the thread index runs along the operand's unit-stride
+    // dimension (coalesced 4-byte loads whatever the form: NT forward, NN data gradient, TN weight gradient).  The NEXT
+    // chunk is fetched into registers before the current chunk's 64 MFMAs per wave, so the global latency hides under them.
+    constexpr bool a_kfast = AK, b_kfast = BK;
+    float ra[LPT], rb[LPT];
+    auto fetch = [&](int64_t k0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < LPT; ++e) {
             const int idx = e * 256 + tid;
-            int ii, kk;
-            if (a_kfast) { kk = idx & (KC - 1); ii = idx >> 4; } else { ii = idx & (TM - 1); kk = idx >> 7; }
+            const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx >> 5) : (idx & (TM - 1));
+            // Branch-free and mask-free: rows / columns beyond the matrix are read from the clamped (valid) position -- they
+            // only feed output elements the epilogue never stores --, and positions beyond the K range are multiplied by 0
+            // (a float factor, not a lane mask kept alive across the MFMA loop: 32 of those spilled SGPRs).
             const int64_t gi = i0 + ii, gk = k0 + kk;
-            As[kk][ii] = (gi < a.I && gk < ke) ? a.A[gi * a.sai + gk * a.sak] : 0.f;
-            int jj, kb2;
-            if (b_kfast) { kb2 = idx & (KC - 1); jj = idx >> 4; } else { jj = idx & (TN - 1); kb2 = idx >> 7; }
+            const float fa = gk < ke ? 1.f : 0.f;
+            ra[e] = a.A[(gi < a.I ? gi : a.I - 1) * a.sai + (gk < ke ? gk : ke - 1) * a.sak] * fa;
+            const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
             const int gj = j0 + jj;
             const int64_t gk2 = k0 + kb2;
-            Bs[kb2][jj] = (gj < a.J && gk2 < ke) ? a.B[gk2 * a.sbk + (int64_t)gj * a.sbj] : 0.f;
+            const float fb = gk2 < ke ? 1.f : 0.f;
+            rb[e] = a.B[(gk2 < ke ? gk2 : ke - 1) * a.sbk + (int64_t)(gj < a.J ? gj : a.J - 1) * a.sbj] * fb;
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int64_t k0 = kb; k0 < ke; k0 += KC) {
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            const int idx = e * 256 + tid;
+            const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx >> 5) : (idx & (TM - 1));
+            As[kk][ii] = ra[e];
+            const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
+            Bs[kb2][jj] = rb[e];
         }
         __syncthreads();
+        if (k0 + KC < ke) fetch(k0 + KC);
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
             const int kr = 2 * s + (lane >> 5), c = lane & 31;
@@ -171,7 +193,12 @@ extern "C" int dmnerf_gemm(const float* d_A, int64_t sai, int64_t sak, const flo
     a.A = d_A; a.sai = sai; a.sak = sak; a.B = d_B; a.sbk = sbk; a.sbj = sbj;
     a.C = splits > 1 ? d_ws : d_C; a.ldc = ldc; a.I = I; a.J = J; a.K = K; a.bias = d_bias; a.mask = d_mask; a.ldm = ldm;
     a.relu = relu; a.accumulate = accumulate; a.splits = splits;
-    hipLaunchKernelGGL(gemm_kernel, dim3((unsigned)ti, (unsigned)tj, (unsigned)splits), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)ti, (unsigned)tj, (unsigned)splits);
+    const bool ak = sak == 1, bk = sbk == 1;
+    if (ak && bk) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (ak) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (bk) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     int rc = dmn_check_launch("gemm");
     if (rc || splits == 1) return rc;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)d_ws, splits, I, J, d_C, ldc, accumulate);
