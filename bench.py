@@ -14,7 +14,7 @@ FRAME over RCCL (what distributed.render_frame does).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`; secondary objects
 (never part of `value`): `frame` (one complete 640x480 pose through the frame driver), `train` (one optimisation step,
 its own per-kernel roofline and CPU baseline), `train_loop` (the shipped N_train = 3072 loop incl. batch selection),
-`render_fused_heads`, `render_split_bf16`, `train_fused_heads` (opt-in modes).
+`render_fused_heads`, `render_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes).
 """
 import argparse
 import json
@@ -111,7 +111,7 @@ def train_flop_per_ray():
     return 2.0 * (2 * MAC_PER_SAMPLE + (MAC_PER_SAMPLE - 101248)) * (2 * S_COARSE + N_IMP)
 
 
-def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False):
+def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, mfma_split=False):
     """Secondary measurement: rays/s of one full optimisation step on ONE batch of ``n`` rays (default 4096 per GPU;
     64+128 samples, perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
     levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
@@ -127,7 +127,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False):
     params = list(mc.parameters()) + list(mf.parameters())
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
     args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
-                                 fuse_heads=fuse_heads)
+                                 fuse_heads=fuse_heads, mfma_split=mfma_split)
     n = N_RAYS * world if n is None else n
     g = torch.Generator(device=dev).manual_seed(0)
     target = torch.rand(n, 3, device=dev, generator=g)
@@ -524,6 +524,10 @@ def main():
                 res["train_fused_heads"] = {"rays_per_s": tf["rays_per_s"], "ms_per_step": tf["ms_per_step"],
                                             "forward_kernel_ms": next((k["kernel_ms"] for k in (tf["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_fwd")), None),
                                             "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
+                ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=True)
+                res["train_split_bf16"] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
+                                           "forward_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_fwd")), None),
+                                           "note": "opt-in (args.mfma_split in training): forward on the split-bf16 MFMA kernel (f32-class values), f32 backward; not part of `train`"}
         if train_multi is not None:
             res["train"] = train_multi
     if world > 1:

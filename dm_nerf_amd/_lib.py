@@ -55,6 +55,7 @@ SIGNATURES = {
     "dmnerf_composite_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "dmnerf_train_save_floats": (c_i64, [c_i64]),
     "dmnerf_mlp_fwd_embedded_train": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dmnerf_mlp_fwd_rays_train_split": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_mlp_fwd_rays_train_fused": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_mlp_fwd_rays_train": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_blob_t_floats": (c_i64, [c_int]),

@@ -171,10 +171,14 @@ class MLPRaysFunction(torch.autograd.Function):
         ins_num = model.ins_num
         raw = torch.empty(N, S, 4 + ins_num + 1, dtype=torch.float32, device=z.device)
         save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
-        fused = bool(getattr(model, "_train_fused", False))          # opt-in (args.fuse_heads): see run_network_train
+        mode = getattr(model, "_train_mode", None)                   # opt-in forward variants: see run_network_train
         blob = model.blob()
-        fwd_blob = model.blob_fused() if fused else blob
-        fn = lib.dmnerf_mlp_fwd_rays_train_fused if fused else lib.dmnerf_mlp_fwd_rays_train
+        if mode == "split":
+            fwd_blob, fn = model.blob_split(), lib.dmnerf_mlp_fwd_rays_train_split
+        elif mode == "fused":
+            fwd_blob, fn = model.blob_fused(), lib.dmnerf_mlp_fwd_rays_train_fused
+        else:
+            fwd_blob, fn = blob, lib.dmnerf_mlp_fwd_rays_train
         with _timed("mlp_fwd_train", M):
             _lib.check(fn(_lib.ptr(fwd_blob), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
                           N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
@@ -281,11 +285,12 @@ def _params(model):
     return [p for _, p in model.named_parameters()]
 
 
-def run_network_train(model, rays_o, rays_d, z, fused=False):
-    """Differentiable (w.r.t. the parameters) fused points + encoding + MLP.  ``fused`` (opt-in, ``args.fuse_heads``): the
-    forward runs on the fused-heads blob (-19 % MACs; values equal up to f32 re-association, not bit-equal to the
-    inference default); the backward is the same either way."""
-    model._train_fused = bool(fused) and model._fused_ok()
+def run_network_train(model, rays_o, rays_d, z, fused=False, split=False):
+    """Differentiable (w.r.t. the parameters) fused points + encoding + MLP.  Opt-in forward variants (the backward is the
+    same f32 one either way): ``fused`` (``args.fuse_heads``) runs the forward on the fused-heads blob (-19 % MACs; values
+    equal up to f32 re-association, not bit-equal to the inference default); ``split`` (``args.mfma_split``) runs it on the
+    split-bf16 MFMA kernel (fused heads + six bf16 products per f32 product: f32-class values at 2.1x the f32 MFMA rate)."""
+    model._train_mode = ("split" if split else "fused" if fused else None) if model._fused_ok() else None
     if not model._fused_ok():                              # another network shape: layer by layer, its own autograd Function
         from . import generic
         return generic.run_network(model, rays_o, rays_d, z, train=True)
@@ -344,15 +349,15 @@ def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=No
     from .networks.render import check_draws             # RNG order of the reference: [N,S] then [N,n_imp]; shapes validated
     t_rand, u, _ = check_draws(t_rand, u, N, S, n_imp, perturb, z_in.device)
     z_coarse = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
-    fused = bool(getattr(args, "fuse_heads", False))
-    raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse, fused)
+    fused, split = bool(getattr(args, "fuse_heads", False)), bool(getattr(args, "mfma_split", False))
+    raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse, fused, split)
     rgb_coarse, weights_coarse, depth_coarse, ins_coarse = CompositeFunction.apply(raw_coarse, z_coarse, rays_d)
     with torch.no_grad():                              # z_samples.detach()  (render.py:68)
         if n_imp == 0:                                 # sample_pdf returns [N, 0]: the fine depths are the coarse ones
             z_fine = z_coarse.clone()
         else:
             z_fine = helpers.importance_resample(z_coarse, weights_coarse.detach(), n_imp, det=(perturb == 0.), u=u)
-    raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine, fused)
+    raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine, fused, split)
     rgb_fine, weights_fine, depth_fine, ins_fine = CompositeFunction.apply(raw_fine, z_fine, rays_d)
     if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
         ins_fine = ins_fine[-args.N_ins:]

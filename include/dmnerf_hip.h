@@ -152,6 +152,10 @@ int dmnerf_mlp_fwd_rays_train(const float* d_blob, int ins_num, const float* d_r
 int dmnerf_mlp_fwd_rays_train_fused(const float* d_blob_fused, int ins_num, const float* d_rays_o,
                                     const float* d_rays_d, const float* d_z, int64_t N, int S,
                                     float* d_raw, float* d_save, void* stream);
+/* OPT-IN: the training forward on the split-bf16 MFMA path (blob of dmnerf_pack_split): f32-class values (not the bitwise
+ * f32 chain), the same f32 d_save contents for the same backward. */
+int dmnerf_mlp_fwd_rays_train_split(const float* d_blob_split, int ins_num, const float* d_rays_o, const float* d_rays_d,
+                                    const float* d_z, int64_t N, int S, float* d_raw, float* d_save, void* stream);
 /* DM_NeRF.forward on pre-embedded rows (networks/dm_nerf.py:80-106 called directly, as mesh / third-party code does) in
  * training mode: d_raw as dmnerf_mlp_fwd_embedded, plus the activation workspace d_save (dmnerf_train_save_floats(M))
  * that dmnerf_mlp_bwd_data / dmnerf_mlp_bwd_weights consume.  Parameter gradients only: the kernels produce no

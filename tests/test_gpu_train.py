@@ -306,8 +306,10 @@ def test_penalizer_golden_value_and_gradient(A, golden):
         tclose(grad[..., 4:] / 1.5, g[f"{k}_grad"], f"penalizer grad {k}", rel=2e-5)
 
 
-def test_opt_in_fused_heads_training(A):
-    """``args.fuse_heads`` in training mode: the forward runs on the fused-heads blob (the two activation-free feature linears
+@pytest.mark.parametrize("mode", ["fuse_heads", "mfma_split"])
+def test_opt_in_fused_heads_training(A, mode):
+    """``args.fuse_heads`` / ``args.mfma_split`` in training mode (the split-bf16 forward is the fused-heads function on the bf16
+    MFMA, f32-class; it writes the same f32 workspace for the same f32 backward).  For ``fuse_heads``: the forward runs on the fused-heads blob (the two activation-free feature linears
     folded into the hidden layers), the backward is the same re-associated one.  Forward inside the MLP contract against the
     oracle (NOT bit-equal to the default path: that is why it is opt-in); per-tensor gradients against PyTorch autograd of the
     oracle; a dm_nerf step through the flag moves the loss like the default step."""
@@ -319,7 +321,7 @@ def test_opt_in_fused_heads_training(A):
         cot = torch.randn(N, S, 4 + ins_num + 1, generator=g)
         raw_want, want = _oracle_mlp_grads(sd, rays_o, rays_d, z, cot)
         m = model_from(A, sd, ins_num)
-        raw = A.G.run_network_train(m, rays_o.cuda(), rays_d.cuda(), z.cuda(), fused=True)
+        raw = A.G.run_network_train(m, rays_o.cuda(), rays_d.cuda(), z.cuda(), fused=mode == "fuse_heads", split=mode == "mfma_split")
         tclose(raw, raw_want, "raw (fused training forward)", rel=1e-5)
         (raw * cot.cuda()).sum().backward()
         for k, p in m.named_parameters():
@@ -340,7 +342,7 @@ def test_opt_in_fused_heads_training(A):
     for fused in (False, True):
         mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
         opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
-        args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, fuse_heads=fused)
+        args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, **{mode: fused})
         tr = []
         for _ in range(3):
             out = A.R.dm_nerf(rays, None, None, mc, mf, z, args)
