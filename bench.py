@@ -527,7 +527,9 @@ def main():
                 ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=True)
                 res["train_split_bf16"] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
                                            "forward_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_fwd")), None),
-                                           "note": "opt-in (args.mfma_split in training): forward on the split-bf16 MFMA kernel (f32-class values), f32 backward; not part of `train`"}
+                                           "dgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_bwd_kernel")), None),
+                                           "wgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("wgrad")), None),
+                                           "note": "opt-in (args.mfma_split in training): forward and data gradients on the split-bf16 MFMA kernels (f32-class values), f32 weight gradients; not part of `train`"}
         if train_multi is not None:
             res["train"] = train_multi
     if world > 1:

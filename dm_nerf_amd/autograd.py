@@ -183,7 +183,8 @@ class MLPRaysFunction(torch.autograd.Function):
             _lib.check(fn(_lib.ptr(fwd_blob), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
                           N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
         ctx.model, ctx.M, ctx.save = model, M, save
-        ctx.blob, ctx.blob_t, ctx.flat = blob, model.blob_t(), model.flat()      # the weights this forward used
+        ctx.blob, ctx.flat = blob, model.flat()                                   # the weights this forward used
+        ctx.blob_t, ctx.blob_ts = (None, model.blob_t_split()) if mode == "split" else (model.blob_t(), None)
         return raw
 
     @staticmethod
@@ -202,8 +203,12 @@ def _mlp_backward(ctx, g_raw):
     Mp = _row_len(M)
     gt = torch.empty(Mp // 32, 4 + C, 32, dtype=torch.float32, device=g.device)   # d raw, block-major, written by the kernel
     with _timed("mlp_bwd_data", M):
-        _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
-                                           _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
+        if getattr(ctx, "blob_ts", None) is not None:            # opt-in: split-bf16 data gradients (args.mfma_split)
+            _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                                                     _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split")
+        else:
+            _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                                               _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
     jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
     part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
     flat = None

@@ -158,6 +158,28 @@ DMN_HD inline SplitLayout make_split_layout(int ins_num) {
     return S;
 }
 
+// Split-bf16 blob of the OPT-IN data-gradient kernel (mlp_bwd_split.hip): W^T segments in the SplitLayout tile format,
+//   slot[(((kb_in_slot * 3 + plane) * OB + ob) * 64 + lane) * 8 + q] = plane(W[out = cfeat(8 kb + q, lane >> 5)][in = 32 ob + (lane & 31)])
+// ins_linear^T (2 OBI k-blocks, OB 4) | F^T (8 k-blocks, OB 8) | mlps.7^T .. mlps.1^T (16 k-blocks, OB 8 each; mlps.5: its h columns);
+// the table in front is the f32 backward blob's (TAB_T_FLOATS: the two VALU heads).
+struct SplitTLayout {
+    int C, OBI;
+    int s_inso, s_rgbf, s_stage, n_slots;
+    int64_t stream, total;        // word offsets (stream = TAB_T_FLOATS), total incl. 2 landing slots
+};
+DMN_HD inline SplitTLayout make_split_layout_t(int ins_num) {
+    SplitTLayout S{};
+    S.C = ins_num + 1; S.OBI = (S.C + 31) / 32;
+    int o = 0;
+    S.s_inso = o; o += split_slots(2 * S.OBI, 4);
+    S.s_rgbf = o; o += split_slots(8, 8);
+    S.s_stage = o; o += 7 * split_slots(16, 8);
+    S.n_slots = o;
+    S.stream = 1024;
+    S.total = S.stream + (int64_t)(o + 2) * SPLIT_SLOT_WORDS;
+    return S;
+}
+
 // Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
 //   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
 //

@@ -151,6 +151,42 @@ extern "C" int dmnerf_build_pack_index_split(int ins_num, int32_t* idx, int64_t 
     return DMNERF_OK;
 }
 
+// transposed split segment: k = outputs of `l` (accumulator order), rows = inputs of `l`
+static void fill_split_seg_t(int32_t* idx, int slot0, const Lin& l, int nkb, int ob_n) {
+    const int kps = split_kb_per_slot(ob_n);
+    for (int kb = 0; kb < nkb; ++kb)
+        for (int plane = 0; plane < 3; ++plane)
+            for (int ob = 0; ob < ob_n; ++ob)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 8; ++q) {
+                        const int64_t src = l.w(cfeat(8 * kb + q, lane >> 5), ob * 32 + (lane & 31));
+                        const int64_t e = ((int64_t)(slot0 + kb / kps) * SPLIT_TILES_PER_SLOT + ((kb % kps) * 3 + plane) * ob_n + ob) * 512 + lane * 8 + q;
+                        idx[e] = src < 0 ? -1 : (int32_t)(src | ((int64_t)plane << 28));
+                    }
+}
+
+extern "C" int64_t dmnerf_blob_t_split_words(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_split_layout_t(ins_num).total;
+}
+
+// sources: [flat parameters | F] like dmnerf_build_pack_index_t (F = head product, behind the parameters)
+extern "C" int dmnerf_build_pack_index_t_split(int ins_num, int32_t* idx, int64_t n_idx) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "build_pack_index_t_split: ins_num %d unsupported", ins_num);
+    const SplitTLayout S = make_split_layout_t(ins_num);
+    const int64_t need = (S.total - S.stream) * 2;
+    if (!idx || n_idx != need) return dmn_fail(DMNERF_E_ARG, "build_pack_index_t_split: need %lld index slots, got %lld", (long long)need, (long long)n_idx);
+    const Params P = make_params(ins_num);
+    for (int64_t i = 0; i < need; ++i) idx[i] = -1;
+    fill_split_seg_t(idx, S.s_inso, P.ins_out, 2 * S.OBI, 4);
+    Lin F;
+    F.w_off = P.total; F.b_off = -1; F.out = HW; F.in = W;
+    fill_split_seg_t(idx, S.s_rgbf, F, 8, 8);
+    const Lin* stage[7] = {&P.mlps[7], &P.mlps[6], &P.mlps[5], &P.mlps[4], &P.mlps[3], &P.mlps[2], &P.mlps[1]};
+    for (int s = 0; s < 7; ++s) fill_split_seg_t(idx, S.s_stage + s * split_slots(16, 8), *stage[s], 16, 8);
+    return DMNERF_OK;
+}
+
 extern "C" int64_t dmnerf_blob_t_floats(int ins_num) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
     return make_layout_t(ins_num).total;

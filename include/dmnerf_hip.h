@@ -227,6 +227,14 @@ int dmnerf_mlp_fwd_rays_fused(const float* d_blob_fused, int ins_num, const floa
 int64_t dmnerf_blob_split_words(int ins_num);
 int dmnerf_build_pack_index_split(int ins_num, int32_t* h_idx, int64_t n_idx);
 int dmnerf_pack_split(const float* d_flat, const int32_t* d_idx, float* d_stream_words, int64_t n_words, void* stream);
+/* OPT-IN split-bf16 data-gradient kernel (training with args.mfma_split): the blob is [the first 1024 floats of the W^T
+ * blob (dmnerf_build_pack_index_t: the two VALU heads' table) | W^T split stream]; the index (two int32 per stream word,
+ * as above) addresses [flat parameters | F] like dmnerf_build_pack_index_t.  Reads and writes exactly what
+ * dmnerf_mlp_bwd_data reads and writes (networks/dm_nerf.py:80-106 backward), f32-class, not its bitwise chain. */
+int64_t dmnerf_blob_t_split_words(int ins_num);
+int dmnerf_build_pack_index_t_split(int ins_num, int32_t* h_idx, int64_t n_idx);
+int dmnerf_mlp_bwd_data_split(const float* d_blob_t_split, int ins_num, const float* d_save, const float* d_graw, int64_t M,
+                              float* d_dsave, float* d_graw_t, void* stream);
 int dmnerf_mlp_fwd_rays_split(const float* d_blob_split, int ins_num, const float* d_rays_o, const float* d_rays_d,
                               const float* d_z, int64_t N, int S, float* d_raw, void* stream);
 

@@ -351,3 +351,50 @@ def test_opt_in_fused_heads_training(A, mode):
             tr.append(float(loss.detach()))
         losses[fused] = tr
     assert np.allclose(losses[True], losses[False], rtol=1e-4) and losses[True][2] < losses[True][0], losses
+
+
+def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A):
+    """The opt-in split-bf16 data-gradient kernel (csrc/mlp_bwd_split.hip) against the default f32 one on the SAME saved
+    forward and the same dL/draw: every dy tensor of the workspace (31 weight quarters' worth of products, masks applied) and
+    the transposed d raw.  f32-class: per tensor  max|diff| <= 1e-5 * max|f32 result|  (six bf16 products per f32 product,
+    f32 accumulation; the d raw copy is bit-equal).  Ragged M (tail block) and every logit-block count (OBI 1..3)."""
+    from dm_nerf_amd import _lib
+    lib = _lib.load()
+    for ins_num, N, S, seed in ((13, 9, 64, 31), (59, 4, 33, 32), (93, 3, 70, 33), (1, 2, 17, 34)):
+        sd = O.make_weights(seed, ins_num, gain=1.7)
+        m = model_from(A, sd, ins_num)
+        g = torch.Generator().manual_seed(seed)
+        rays_o, rays_d = torch.randn(N, 3, generator=g).cuda(), torch.randn(N, 3, generator=g).cuda()
+        z = torch.sort(torch.rand(N, S, generator=g) * 5 + 1, -1)[0].cuda()
+        M_, C = N * S, ins_num + 1
+        graw = torch.randn(M_, 4 + C, generator=g).cuda()
+        raw = torch.empty(N, S, 4 + C, device="cuda")
+        save = torch.empty(lib.dmnerf_train_save_floats(M_), device="cuda")
+        _lib.check(lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(m.blob()), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z), N, S,
+                                                 _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "fwd")
+        Mp = A.G._row_len(M_)
+        outs = []
+        for split in (False, True):
+            dsave = torch.full_like(save, float("nan"))
+            gt = torch.full((Mp // 32, 4 + C, 32), float("nan"), device="cuda")
+            if split:
+                _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(m.blob_t_split()), ins_num, _lib.ptr(save), _lib.ptr(graw), M_,
+                                                         _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd split")
+            else:
+                _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(m.blob()), _lib.ptr(m.blob_t()), ins_num, _lib.ptr(save), _lib.ptr(graw), M_,
+                                                   _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd")
+            torch.cuda.synchronize()
+            outs.append((dsave.cpu(), gt.cpu()))
+        (d0, g0), (d1, g1) = outs
+        assert torch.equal(torch.isnan(d0), torch.isnan(d1)), "the two kernels write different parts of the workspace"
+        assert torch.equal(torch.nan_to_num(g0), torch.nan_to_num(g1)), "d raw (transposed copy) differs"
+        a, b = torch.nan_to_num(d0), torch.nan_to_num(d1)
+        assert float(a.abs().max()) > 0
+        # per written region of 256 Mp (or less) floats: relative to that region's own scale
+        written = (~torch.isnan(d0)).nonzero().flatten()
+        lo, hi = int(written.min()), int(written.max()) + 1
+        step = 128 * Mp
+        for s in range(lo, hi, step):
+            x, y = a[s:s + step], b[s:s + step]
+            scale = float(x.abs().max())
+            assert float((x - y).abs().max()) <= 1e-5 * scale + 1e-12, (ins_num, s // step, float((x - y).abs().max()), scale)
