@@ -168,6 +168,10 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     per_flop = {"mlp_fwd_train": 2.0 * MAC_PER_SAMPLE, "mlp_bwd_data": 2.0 * (MAC_PER_SAMPLE - 101248), "mlp_bwd_weights": 2.0 * MAC_PER_SAMPLE}
     names = {"mlp_fwd_train": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,true,false>", "mlp_bwd_data": f"mlp_bwd_kernel<{(INS_NUM + 32) // 32}>",
              "mlp_bwd_weights": "wgrad_kernel + wgrad_reduce_kernel"}
+    if mfma_split:
+        names.update(mlp_fwd_train=f"mlp_split_kernel<{(INS_NUM + 32) // 32},true>", mlp_bwd_data=f"mlp_bwd_split_kernel<{(INS_NUM + 32) // 32}>")
+    elif fuse_heads:
+        names.update(mlp_fwd_train=f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},true,true,false>")
     kernels = []
     for tag in ("mlp_fwd_train", "mlp_bwd_data", "mlp_bwd_weights"):
         ms = [b.elapsed_time(e) for t, M, b, e in events if t == tag and M == m_fine]
@@ -526,10 +530,10 @@ def main():
                                             "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
                 ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=True)
                 res["train_split_bf16"] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
-                                           "forward_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_fwd")), None),
-                                           "dgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_bwd_kernel")), None),
+                                           "forward_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_split")), None),
+                                           "dgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_bwd")), None),
                                            "wgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("wgrad")), None),
-                                           "note": "opt-in (args.mfma_split in training): forward and data gradients on the split-bf16 MFMA kernels (f32-class values), f32 weight gradients; not part of `train`"}
+                                           "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the split-bf16 MFMA kernels (f32-class values: six bf16 products per f32 product, f32 accumulation); not part of `train`"}
         if train_multi is not None:
             res["train"] = train_multi
     if world > 1:

@@ -72,23 +72,25 @@ def _views(buf, M):
 _plan_cache = {}
 
 
-def wgrad_plan(ins_num, M, device, max_wgs=None):
-    """Device-resident split-K plan of the weight-gradient kernel for (ins_num, M): (jobs, n_jobs, outs, n_outs, part_floats)."""
+def wgrad_plan(ins_num, M, device, max_wgs=None, split=False):
+    """Device-resident split-K plan of the weight-gradient kernel for (ins_num, M): (jobs, n_jobs, outs, n_outs, part_floats).
+    ``split``: balanced for the opt-in split-bf16 kernel (csrc/wgrad_split.hip)."""
     import ctypes
 
     import numpy as np
     if max_wgs is None:
         max_wgs = torch.cuda.get_device_properties(device).multi_processor_count     # one workgroup per CU
-    key = (ins_num, M, str(device), max_wgs)
+    key = (ins_num, M, str(device), max_wgs, bool(split))
     if key not in _plan_cache:
         lib = _lib.load()
+        f_sizes, f_plan = (lib.dmnerf_wgrad_plan_sizes_split, lib.dmnerf_wgrad_plan_split) if split else (lib.dmnerf_wgrad_plan_sizes, lib.dmnerf_wgrad_plan)
         jb, ob, pf = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         nj, no = ctypes.c_int(), ctypes.c_int()
-        _lib.check(lib.dmnerf_wgrad_plan_sizes(ins_num, M, max_wgs, ctypes.byref(jb), ctypes.byref(ob), ctypes.byref(pf),
-                                               ctypes.byref(nj), ctypes.byref(no)), "dmnerf_wgrad_plan_sizes")
+        _lib.check(f_sizes(ins_num, M, max_wgs, ctypes.byref(jb), ctypes.byref(ob), ctypes.byref(pf),
+                           ctypes.byref(nj), ctypes.byref(no)), "dmnerf_wgrad_plan_sizes")
         hj, ho = np.empty(jb.value, dtype=np.uint8), np.empty(ob.value, dtype=np.uint8)
-        _lib.check(lib.dmnerf_wgrad_plan(ins_num, M, max_wgs, hj.ctypes.data_as(ctypes.c_void_p), jb.value,
-                                         ho.ctypes.data_as(ctypes.c_void_p), ob.value), "dmnerf_wgrad_plan")
+        _lib.check(f_plan(ins_num, M, max_wgs, hj.ctypes.data_as(ctypes.c_void_p), jb.value,
+                          ho.ctypes.data_as(ctypes.c_void_p), ob.value), "dmnerf_wgrad_plan")
         _plan_cache[key] = (torch.from_numpy(hj).to(device), nj.value, torch.from_numpy(ho).to(device), no.value, pf.value)
     return _plan_cache[key]
 
@@ -202,14 +204,15 @@ def _mlp_backward(ctx, g_raw):
     dsave = torch.empty_like(ctx.save)
     Mp = _row_len(M)
     gt = torch.empty(Mp // 32, 4 + C, 32, dtype=torch.float32, device=g.device)   # d raw, block-major, written by the kernel
+    split = getattr(ctx, "blob_ts", None) is not None            # opt-in: split-bf16 backward kernels (args.mfma_split)
     with _timed("mlp_bwd_data", M):
-        if getattr(ctx, "blob_ts", None) is not None:            # opt-in: split-bf16 data gradients (args.mfma_split)
+        if split:
             _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                      _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split")
         else:
             _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
-    jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device)
+    jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device, split=split)
     part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
     flat = None
     arena = getattr(model, "_grad_arena", None)                  # data-parallel step: write into the shared all-reduce buffer
@@ -218,9 +221,9 @@ def _mlp_backward(ctx, g_raw):
     if flat is None:
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)
     with _timed("mlp_bwd_weights", M):
-        _lib.check(lib.dmnerf_mlp_bwd_weights(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs,
-                                              _lib.ptr(outs), n_outs, _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat),
-                                              _lib.stream()), "dmnerf_mlp_bwd_weights")
+        f_wgrad = lib.dmnerf_mlp_bwd_weights_split if split else lib.dmnerf_mlp_bwd_weights
+        _lib.check(f_wgrad(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs), n_outs,
+                           _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat), _lib.stream()), "dmnerf_mlp_bwd_weights")
     ctx.save = None
     return tuple(split_flat_grads(model, flat))
 

@@ -24,13 +24,11 @@
 #include "common.h"
 #include "layout.h"
 #include "mlp_common.h"
+#include "split_bf16.h"
 
 using namespace dmn;
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int SP_SLOT_BYTES = SPLIT_SLOT_WORDS * 4;          // 49 152
 constexpr int SP_RING_FLOATS = 3 * SPLIT_SLOT_WORDS;
@@ -63,28 +61,6 @@ struct SStream {
 __device__ __forceinline__ void ss_fetch_piece(const SStream& ws, int target_slot, int i) {
     float* dst = ws.ring + target_slot * SPLIT_SLOT_WORDS + ws.wave * 256 + i * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ws.rs, (DMN_LAS void*)dst, 16, (int)ws.voff, (int)(ws.off + i * 4096), 0, 0);
-}
-
-__device__ __forceinline__ bf16x8 as_b(const unsigned* w) {
-    const u32x4s v = {w[0], w[1], w[2], w[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ bf16x8 as_a(const f32x4& v) { return __builtin_bit_cast(bf16x8, v); }
-
-// (x0, x1) -> the three bf16-pair words of the truncation split (x = hi + mid + lo exactly); the two subtractions of a
-// stage are one v_pk_add_f32
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& whi, unsigned& wmid, unsigned& wlo) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    whi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const f32x2 x = {x0, x1};
-    const f32x2 h = {__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
-    const f32x2 r = x - h;
-    const unsigned v0 = __float_as_uint(r[0]), v1 = __float_as_uint(r[1]);
-    wmid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const f32x2 m = {__uint_as_float(v0 & 0xffff0000u), __uint_as_float(v1 & 0xffff0000u)};
-    const f32x2 q = r - m;
-    wlo = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
 }
 
 // planes of NV accumulator-layout f32x16 blocks: block b, register r = 8 t + q -> k-block 2 b + t, word (q >> 1)

@@ -21,81 +21,15 @@
 //     and round, the rounds dealt out over the waves that hold the same A blocks.
 // Exact f32 (fmaf-chain MFMA), no vendor BLAS.  Roofline: ~equal parts MFMA (2 x MAC x M FLOP) and
 // HBM (each dy / x row is read once per job: ~23 KB per sample and model).
-#include <hip/hip_runtime.h>
-
 #include <cstring>
 #include <vector>
 
-#include "../../include/dmnerf_hip.h"
-#include "common.h"
-#include "layout.h"
-#include "mlp_common.h"
 #include "params.h"
+#include "wgrad_common.h"
 
 int dmn_head_unfuse(const float* d_flat, int ins_num, const float* d_G, const float* d_Q, float* d_grad, hipStream_t stream);   // heads.hip
 
-using namespace dmn;
-
 namespace {
-
-constexpr int KT = 32;                      // samples per chunk
-constexpr int WG_LDS_BYTES = 147456;        // ring budget (of the CU's 160 KiB)
-constexpr int MAX_DEPTH = 6;                // ring slots (the chunk loop is unrolled by the depth)
-
-// One workgroup's work (device table, offsets only => reusable across steps).
-struct WgJob {
-    int64_t a_off, b_off;     // float offsets of the A / B TENSORS inside their source buffers
-    int a_R, b_R;             // total rows of those tensors (block stride = R*32 floats)
-    int a_row0, b_row0;       // first row of the job inside the tensor
-    int64_t part_off;         // float offset of this workgroup's partial [NBA*32][NBB*32] in the workspace
-    int64_t bias_off;         // float offset of its partial row sums [NBA*32], or -1
-    int a_src, b_src;         // 0 = saved activations, 1 = dgrad output, 2 = transposed d raw
-    int rowsA, rowsB;         // valid rows (the rest of the 32-row blocks is zero)
-    int cls;                  // shape class (NBA, NBB)
-    int chunk0, nchunk;       // 32-sample chunks [chunk0, chunk0 + nchunk)
-    int pad;
-};
-static_assert(sizeof(WgJob) % 8 == 0, "WgJob layout");
-
-// One output tensor slice (weight columns [col_off, col_off + rowsB) of a parameter, plus its bias).
-struct WgOut {
-    int64_t part_off, slice_stride;   // first partial, distance between slices
-    int64_t bias_part_off, bias_slice_stride;   // per slice: bias_sub partial vectors of NBA*32 floats each
-    int64_t out_off, bias_out_off;    // float offsets into the flat gradient vector (reference order); bias -1 = none
-    int n_slices, rowsA, rowsB, ldp;  // ldp = NBB*32
-    int ld_out, col_off, bias_sub, ldb;        // bias_sub shares per slice, ldb = NBA*32 apart
-    int perm_a, perm_b, to_scratch, pad1;      // operand rows are in the accumulator-layout memory order (layout.h::row_feature);
-                                               // to_scratch: out_off addresses the head of the partials workspace (G / Q of heads.hip)
-};
-
-struct WgArgs {
-    const float* src[3];
-    float* part;
-    const WgJob* jobs;
-    int64_t Mp;
-    long long* trace;     // diagnostic: per-workgroup {start, end} of the 100 MHz wall clock, or null
-};
-
-template <int NBA, int NBB>
-struct Split {   // which (A block, B block) pairs a wave owns: a rectangle SAn x SBn; block = literal + wave part
-    static constexpr int SBn = NBB >= 4 ? NBB / 4 : 1;
-    static constexpr int SAn = NBB >= 4 ? NBA : (NBB == 2 ? NBA / 2 : NBA / 4);
-    static constexpr int NSHARE = NBB >= 4 ? 4 : (NBB == 2 ? 2 : 1);        // waves that hold the same A blocks
-    static_assert(NBB >= 4 || (NBB == 2 && NBA % 2 == 0) || (NBB == 1 && NBA % 4 == 0), "unsupported shape class");
-    // A block of (wave w, k) = a_lit(k) + a_wave(w); B block = b_lit(k) + b_wave(w)
-    __device__ static constexpr int a_lit(int k) { return NBB >= 4 ? k : (NBB == 2 ? 2 * k : 4 * k); }
-    __device__ static int a_wave(int w) { return NBB >= 4 ? 0 : (NBB == 2 ? (w >> 1) : w); }
-    __device__ static constexpr int b_lit(int k) { return NBB >= 4 ? 4 * k : 0; }
-    __device__ static int b_wave(int w) { return NBB >= 4 ? w : (NBB == 2 ? (w & 1) : 0); }
-    __device__ static int share_rank(int w) { return NBB >= 4 ? w : (NBB == 2 ? (w & 1) : 0); }
-};
-
-template <int NBA, int NBB>
-struct Ring {
-    static constexpr int BUF = (NBA + NBB) * 4096;                                    // bytes per chunk: rows * 128
-    static constexpr int D = WG_LDS_BYTES / BUF < MAX_DEPTH ? WG_LDS_BYTES / BUF : MAX_DEPTH;
-    static_assert(D >= 2, "ring needs two slots");
-};
 
 template <int NBA, int NBB>
 __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float* lds) {
@@ -220,34 +154,8 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
 #pragma unroll
     for (int k = 0; k < SBn; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
 
-    // epilogue: partial tile [NBA*32][NBB*32], C layout: lane holds column j = li, rows crow(r, half)
-    float* __restrict__ P = a.part + jb.part_off;
-    constexpr int LDP = NBB * 32;
-#pragma unroll
-    for (int ia = 0; ia < SAn; ++ia) {
-        const int ba = SP::a_lit(ia) + SP::a_wave(w);
-#pragma unroll
-        for (int ib = 0; ib < SBn; ++ib) {
-            const int bb = SP::b_lit(ib) + SP::b_wave(w);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = ba * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                P[(int64_t)row * LDP + bb * 32 + li] = acc[ia * SBn + ib][r];
-            }
-        }
-        if (want_bias) {
-            // this wave's share of the row sums (its rounds, both k halves); the reduction adds the NSHARE shares
-            float sum = (bs[ia][0] + bs[ia][1]) + (bs[ia][2] + bs[ia][3]);
-            sum += __shfl_xor(sum, 32);
-            if (half == 0) a.part[jb.bias_off + (int64_t)my_rank * (NBA * 32) + ba * 32 + li] = sum;
-        }
-    }
+    store_partials<Split<NBA, NBB>, NBA, NBB>(a, jb, acc, bs, w, half, li, want_bias, my_rank);
 }
-
-// shape classes (NBA, NBB)
-enum { C_8_8 = 0, C_4_8, C_8_2, C_4_1, C_1_8, C_1_4, C_2_4, C_3_4, C_4_4, N_CLASSES };
-constexpr int CLS_NBA[N_CLASSES] = {8, 4, 8, 4, 1, 1, 2, 3, 4};
-constexpr int CLS_NBB[N_CLASSES] = {8, 8, 2, 1, 8, 4, 4, 4, 4};
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -318,7 +226,7 @@ struct Plan {
 };
 
 // Parameter offsets in the flat gradient vector = reference state_dict order (weight, bias per layer).
-Plan make_plan(int ins_num, int64_t M, int max_wgs) {
+Plan make_plan(int ins_num, int64_t M, int max_wgs, bool split = false) {
     const int C = ins_num + 1;
     const int64_t Mp = save_row_len(M);
     const int nchunks = (int)(Mp / KT);
@@ -355,10 +263,14 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
     // Cost of one 32-sample chunk for a workgroup = its measured time in ns (scripts/diag_wgrad.py on MI355X,
     // r01): the MFMA time 256 * NBA * NBB cycles at ~2.4 GHz plus ~3 % for the fat classes; the skinny
     // classes are bound by the per-chunk hand-over (barrier + DMA issue), ~0.5 us.
-    auto chunk_cost = [](int cls) {
+    // split (wgrad_split.hip, six bf16 MFMAs per f32 product: 96 NBA NBB MFMA cycles per chunk): measured with
+    // DMNERF_DIAG_SPLIT=1 scripts/diag_wgrad.py (r02q); the skinny classes keep their hand-over / HBM floor.
+    auto chunk_cost = [split](int cls) {
         static const double ns[N_CLASSES] = {/*8,8*/ 7025, /*4,8*/ 3530, /*8,2*/ 1858, /*4,1*/ 538, /*1,8*/ 984,
                                              /*1,4*/ 540, /*2,4*/ 1000, /*3,4*/ 1400, /*4,4*/ 1800};
-        return ns[cls];
+        static const double ns_split[N_CLASSES] = {/*8,8*/ 4436, /*4,8*/ 2568, /*8,2*/ 1920, /*4,1*/ 839, /*1,8*/ 1311,
+                                                   /*1,4*/ 872, /*2,4*/ 1100, /*3,4*/ 1300, /*4,4*/ 1600};
+        return split ? ns_split[cls] : ns[cls];
     };
     // Slices per job: minimise the longest workgroup (chunks per slice x chunk cost) under sum(slices) <= max_wgs:
     // start from one slice each and keep giving a slice to the job whose workgroups are the longest.
@@ -413,10 +325,10 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs) {
 
 }  // namespace
 
-extern "C" int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
-                                       int64_t* part_floats, int* n_jobs, int* n_outs) {
+static int plan_sizes(bool split, int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
+                      int64_t* part_floats, int* n_jobs, int* n_outs) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS || M < 1 || max_wgs < 32) return dmn_fail(DMNERF_E_ARG, "wgrad_plan: bad argument");
-    const Plan P = make_plan(ins_num, M, max_wgs);
+    const Plan P = make_plan(ins_num, M, max_wgs, split);
     if (n_job_bytes) *n_job_bytes = (int64_t)(P.jobs.size() * sizeof(WgJob));
     if (n_out_bytes) *n_out_bytes = (int64_t)(P.outs.size() * sizeof(WgOut));
     if (part_floats) *part_floats = P.part_floats;
@@ -425,9 +337,9 @@ extern "C" int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int6
     return DMNERF_OK;
 }
 
-extern "C" int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
+static int plan_fill(bool split, int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS || M < 1 || max_wgs < 32 || !h_jobs || !h_outs) return dmn_fail(DMNERF_E_ARG, "wgrad_plan: bad argument");
-    const Plan P = make_plan(ins_num, M, max_wgs);
+    const Plan P = make_plan(ins_num, M, max_wgs, split);
     if (job_bytes != (int64_t)(P.jobs.size() * sizeof(WgJob)) || out_bytes != (int64_t)(P.outs.size() * sizeof(WgOut)))
         return dmn_fail(DMNERF_E_ARG, "wgrad_plan: buffer sizes do not match dmnerf_wgrad_plan_sizes");
     memcpy(h_jobs, P.jobs.data(), (size_t)job_bytes);
@@ -435,9 +347,25 @@ extern "C" int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jo
     return DMNERF_OK;
 }
 
-static long long* g_wgrad_trace = nullptr;
+extern "C" int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
+                                       int64_t* part_floats, int* n_jobs, int* n_outs) {
+    return plan_sizes(false, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
+}
+extern "C" int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
+    return plan_fill(false, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
+}
+// the same tables balanced for the chunk times of the split-bf16 kernel (wgrad_split.hip)
+extern "C" int dmnerf_wgrad_plan_sizes_split(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
+                                             int64_t* part_floats, int* n_jobs, int* n_outs) {
+    return plan_sizes(true, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
+}
+extern "C" int dmnerf_wgrad_plan_split(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
+    return plan_fill(true, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
+}
+
+long long* g_dmn_wgrad_trace = nullptr;      // (wgrad_split.hip shares the diagnostic hook)
 extern "C" int dmnerf_wgrad_set_trace(int64_t* d_ticks) {
-    g_wgrad_trace = (long long*)d_ticks;
+    g_dmn_wgrad_trace = (long long*)d_ticks;
     return DMNERF_OK;
 }
 
@@ -449,7 +377,7 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights: ins_num %d unsupported", ins_num);
     WgArgs a{};
     a.src[0] = d_save; a.src[1] = d_dsave; a.src[2] = d_graw_t;
-    a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_wgrad_trace;
+    a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_dmn_wgrad_trace;
     const size_t lds_bytes = WG_LDS_BYTES;
     static DmnOncePerDevice once;
     if (hipError_t e = once.run([&] { return hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); });
@@ -458,10 +386,13 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_jobs), dim3(256), lds_bytes, (hipStream_t)stream, a);
     int rc = dmn_check_launch("mlp_bwd_weights");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, (unsigned)n_outs), dim3(256), 0, (hipStream_t)stream,
-                       d_part, (const WgOut*)d_outs, n_outs, d_grad_flat);
-    rc = dmn_check_launch("mlp_bwd_weights: reduce");
+    return dmn_wgrad_finish(d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, (hipStream_t)stream);
+}
+
+int dmn_wgrad_finish(const void* d_outs, int n_outs, const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, hipStream_t stream) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, (unsigned)n_outs), dim3(256), 0, stream, d_part, (const WgOut*)d_outs, n_outs, d_grad_flat);
+    const int rc = dmn_check_launch("mlp_bwd_weights: reduce");
     if (rc) return rc;
     // rgb_feature_linear(s) / ins_feature_linear(s) from G, Q and the hidden layers' bias gradients (heads.hip)
-    return dmn_head_unfuse(d_params_flat, ins_num, d_part, d_part + HEAD_F_FLOATS, d_grad_flat, (hipStream_t)stream);
+    return dmn_head_unfuse(d_params_flat, ins_num, d_part, d_part + HEAD_F_FLOATS, d_grad_flat, stream);
 }

@@ -199,6 +199,17 @@ int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t
 int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                            const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream);
+/* OPT-IN split-bf16 weight gradients (training with args.mfma_split; csrc/wgrad_split.hip): the same tables, workspace and
+ * second stage; both f32 operands are split on the fly into three bf16 planes and a product is six bf16 MFMAs accumulated
+ * in f32 (f32-class, not the bitwise chain of dmnerf_mlp_bwd_weights).  The _split plan balances the slices for this
+ * kernel's chunk times (its 256 x 256 jobs are HBM-bound); either plan is valid for either kernel.                  */
+int dmnerf_wgrad_plan_sizes_split(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes,
+                                  int64_t* n_out_bytes, int64_t* part_floats, int* n_jobs, int* n_outs);
+int dmnerf_wgrad_plan_split(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes,
+                            void* h_outs, int64_t out_bytes);
+int dmnerf_mlp_bwd_weights_split(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                                 const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                                 const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream);
 /* Diagnostic: when d_ticks != NULL every workgroup of the following dmnerf_mlp_bwd_weights launches writes its
  * {start, end} 100 MHz wall-clock ticks to d_ticks[2*wg], d_ticks[2*wg+1] (n_jobs pairs); NULL turns it off.
  * Used by scripts/diag_wgrad.py to fit the split-K cost model. */

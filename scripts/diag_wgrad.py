@@ -3,6 +3,7 @@
 Runs one fine-level (4096 x 192 samples) and one coarse-level (4096 x 64) MLP backward with
 dmnerf_wgrad_set_trace on and prints, per job of the plan, the slice count, chunks per slice and
 the measured time per workgroup / per 32-sample chunk.  Used to fit chunk_cost() in csrc/wgrad.hip.
+DMNERF_DIAG_SPLIT=1: the opt-in split-bf16 backward (csrc/wgrad_split.hip) and its plan.
 """
 import ctypes
 import os
@@ -35,14 +36,15 @@ def main():
         ro, rd = torch.randn(N, 3, device=dev), torch.randn(N, 3, device=dev)
         z = torch.sort(torch.rand(N, S, device=dev) * 4 + 1, -1)[0]
         Mtot = N * S
-        jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev)
+        split = bool(int(os.environ.get("DMNERF_DIAG_SPLIT", "0")))
+        jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev, split=split)
         jh = jobs.cpu().numpy().view(JOB)
         assert JOB.itemsize * n_jobs == jobs.numel(), (JOB.itemsize, n_jobs, jobs.numel())
         ticks = torch.zeros(2 * n_jobs, dtype=torch.int64, device=dev)
         for it in range(3):
             for p in m.parameters():
                 p.grad = None
-            raw = G.run_network_train(m, ro, rd, z)
+            raw = G.run_network_train(m, ro, rd, z, split=split)
             cot = torch.randn_like(raw)
             if it == 2:
                 lib.dmnerf_wgrad_set_trace(ctypes.c_void_p(ticks.data_ptr()))
@@ -68,7 +70,7 @@ def main():
             nch = jh["nchunk"][i:k]
             print(f"  job rows {int(j['rowsA']):3d}x{int(j['rowsB']):3d} cls ({nba},{nbb}) slices {k - i:3d} chunks/slice {int(nch.max()):5d}"
                   f"  wg time mean {d.mean():8.0f} max {d.max():8.0f} us   per chunk {1e3 * (d / nch).mean():7.0f} ns"
-                  f"  (MFMA-ideal {256 * nba * nbb / 2.4:7.0f} ns)")
+                  f"  (MFMA-ideal {(96 if split else 256) * nba * nbb / 2.4:7.0f} ns)")
             i = k
 
 

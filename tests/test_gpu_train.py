@@ -398,3 +398,50 @@ def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A):
             x, y = a[s:s + step], b[s:s + step]
             scale = float(x.abs().max())
             assert float((x - y).abs().max()) <= 1e-5 * scale + 1e-12, (ins_num, s // step, float((x - y).abs().max()), scale)
+
+
+def test_split_wgrad_kernel_vs_f32_wgrad_kernel(A):
+    """The opt-in split-bf16 weight-gradient kernel (csrc/wgrad_split.hip) against the default f32 one on the SAME saved
+    forward and the same dy (f32 dgrad): every parameter gradient, per tensor  max|diff| <= 2e-5 * max|f32 result|  (both sum
+    ~10^3 .. 10^4 products per entry in f32; six bf16 products per f32 product).  Both plans (f32- and split-balanced) are valid
+    for both kernels; ragged M and every logit-block count."""
+    from dm_nerf_amd import _lib
+    lib = _lib.load()
+    for ins_num, N, S, seed in ((13, 33, 64, 41), (59, 9, 33, 42), (93, 5, 70, 43), (1, 2, 17, 44)):
+        sd = O.make_weights(seed, ins_num, gain=1.7)
+        m = model_from(A, sd, ins_num)
+        g = torch.Generator().manual_seed(seed)
+        rays_o, rays_d = torch.randn(N, 3, generator=g).cuda(), torch.randn(N, 3, generator=g).cuda()
+        z = torch.sort(torch.rand(N, S, generator=g) * 5 + 1, -1)[0].cuda()
+        M_, C = N * S, ins_num + 1
+        graw = torch.randn(M_, 4 + C, generator=g).cuda()
+        raw = torch.empty(N, S, 4 + C, device="cuda")
+        save = torch.empty(lib.dmnerf_train_save_floats(M_), device="cuda")
+        _lib.check(lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(m.blob()), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z), N, S,
+                                                 _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "fwd")
+        Mp = A.G._row_len(M_)
+        dsave = torch.empty_like(save)
+        gt = torch.empty(Mp // 32, 4 + C, 32, device="cuda")
+        _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(m.blob()), _lib.ptr(m.blob_t()), ins_num, _lib.ptr(save), _lib.ptr(graw), M_,
+                                           _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd")
+        flat = m.flat()
+        grads = {}
+        for kern in ("f32", "split"):
+            for plan in ("f32", "split"):
+                jobs, n_jobs, outs, n_outs, pf = A.G.wgrad_plan(ins_num, M_, raw.device, split=plan == "split")
+                part = torch.full((pf,), float("nan"), device="cuda")
+                out = torch.full((lib.dmnerf_param_count(ins_num),), float("nan"), device="cuda")
+                fn = lib.dmnerf_mlp_bwd_weights_split if kern == "split" else lib.dmnerf_mlp_bwd_weights
+                _lib.check(fn(_lib.ptr(save), _lib.ptr(dsave), _lib.ptr(gt), M_, _lib.ptr(jobs), n_jobs, _lib.ptr(outs), n_outs,
+                              _lib.ptr(flat), ins_num, _lib.ptr(part), _lib.ptr(out), _lib.stream()), kern)
+                torch.cuda.synchronize()
+                assert not bool(torch.isnan(out).any()), (kern, plan)
+                grads[kern, plan] = A.G.split_flat_grads(m, out)
+        names = [k for k, _ in m.named_parameters()]
+        for plan in ("f32", "split"):
+            for k, a, b in zip(names, grads["f32", "f32"], grads["split", plan]):
+                scale = float(a.abs().max())
+                err = float((a - b).abs().max())
+                assert err <= 2e-5 * scale + 1e-9, (ins_num, plan, k, err, scale)
+        for k, a, b in zip(names, grads["f32", "f32"], grads["f32", "split"]):      # the f32 kernel on the other plan: slice order only
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, (ins_num, k)
