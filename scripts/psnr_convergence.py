@@ -13,6 +13,7 @@ and both students are evaluated on a HELD-OUT view against the teacher: PSNR, la
 two students with each other.  Prints one JSON object (and writes it to --out).
 
     python scripts/psnr_convergence.py --steps 100 --batch 64 --out gpurun_out/psnr_convergence.json
+    python scripts/psnr_convergence.py --mode mfma_split ...      (the opt-in split-bf16 training kernels)
 """
 import argparse
 import json
@@ -53,6 +54,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--H", type=int, default=30)
     ap.add_argument("--W", type=int, default=40)
+    ap.add_argument("--mode", default="default", choices=["default", "fuse_heads", "mfma_split"],
+                    help="opt-in training mode of the MI355X student (args.fuse_heads / args.mfma_split)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     assert torch.cuda.is_available(), "needs an MI355X"
@@ -82,7 +85,8 @@ def main():
         steps.append((idx, torch.rand(a.batch, 64, generator=gen), torch.rand(a.batch, 128, generator=gen)))
     sd0_c, sd0_f = O.make_weights(903, INS_NUM), O.make_weights(904, INS_NUM)
     z = O.z_val_sample(a.batch, NEAR, FAR, 64).contiguous()
-    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=None, tolerance=TOL, deta_w=DW)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=None, tolerance=TOL, deta_w=DW,
+                                 fuse_heads=a.mode == "fuse_heads", mfma_split=a.mode == "mfma_split")
 
     # ---- student 1: the MI355X path
     mc, mf = M.DM_NeRF(8, 256, 63, 27, [4], INS_NUM), M.DM_NeRF(8, 256, 63, 27, [4], INS_NUM)
@@ -134,6 +138,7 @@ def main():
     res = {
         "scene": f"teacher = oracle.PEAKY weights (seeds 803/804), ins_num {INS_NUM}; 3 training views + 1 held-out view of {H}x{W}, 64+128 samples; "
                  f"teacher label map: {int(len(torch.unique(test_lab)))} labels in the held-out view",
+        "mode": a.mode,
         "recipe": f"{a.steps} steps x {a.batch} rays, img2mse + ins_criterion + ins_penalizer on both levels, Adam 5e-4, perturb=1, identical batches and jitter",
         "psnr_heldout_hip_db": p_hip, "psnr_heldout_oracle_db": p_ora, "abs_delta_psnr_db": abs(p_hip - p_ora),
         "psnr_untrained_db": None,

@@ -360,7 +360,7 @@ def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A):
     f32 accumulation; the d raw copy is bit-equal).  Ragged M (tail block) and every logit-block count (OBI 1..3)."""
     from dm_nerf_amd import _lib
     lib = _lib.load()
-    for ins_num, N, S, seed in ((13, 9, 64, 31), (59, 4, 33, 32), (93, 3, 70, 33), (1, 2, 17, 34)):
+    for ins_num, N, S, seed in ((13, 9, 64, 31), (59, 4, 33, 32), (93, 3, 70, 33), (1, 2, 17, 34), (120, 2, 40, 35)):
         sd = O.make_weights(seed, ins_num, gain=1.7)
         m = model_from(A, sd, ins_num)
         g = torch.Generator().manual_seed(seed)
@@ -407,7 +407,7 @@ def test_split_wgrad_kernel_vs_f32_wgrad_kernel(A):
     for both kernels; ragged M and every logit-block count."""
     from dm_nerf_amd import _lib
     lib = _lib.load()
-    for ins_num, N, S, seed in ((13, 33, 64, 41), (59, 9, 33, 42), (93, 5, 70, 43), (1, 2, 17, 44)):
+    for ins_num, N, S, seed in ((13, 33, 64, 41), (59, 9, 33, 42), (93, 5, 70, 43), (1, 2, 17, 44), (120, 3, 40, 45)):      # logit blocks 1, 2, 3, 1, 4
         sd = O.make_weights(seed, ins_num, gain=1.7)
         m = model_from(A, sd, ins_num)
         g = torch.Generator().manual_seed(seed)
