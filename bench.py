@@ -14,7 +14,7 @@ FRAME over RCCL (what distributed.render_frame does).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`; secondary objects
 (never part of `value`): `frame` (one complete 640x480 pose through the frame driver), `train` (one optimisation step,
 its own per-kernel roofline and CPU baseline), `train_loop` (the shipped N_train = 3072 loop incl. batch selection),
-`render_fused_heads`, `render_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes).
+`render_fused_heads`, `render_split_bf16`, `frame_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes).
 """
 import argparse
 import json
@@ -250,12 +250,13 @@ def train_loop_leg(mc, mf, dev, steps):
             "note": "shipped N_train=3072: prefetched batch selection (reference numpy stream, side thread, pinned index upload, resident dataset) + full optimisation step"}
 
 
-def frame_leg(mc, mf, K, c2w, dev):
+def frame_leg(mc, mf, K, c2w, dev, mfma_split=False):
     """One complete 640x480 pose through the frame driver (distributed.render_path: raygen of the band, 75 chunks of
     N_test = 4096 rays, preallocated frame buffers, device-side label / confidence of ins_eval) -- what render_test does
     per pose (networks/tester.py:58-85) minus file output and CPU metrics."""
     from dm_nerf_amd import distributed as D
-    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, N_test=N_RAYS, N_samples=S_COARSE, near=NEAR, far=FAR)
+    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, N_test=N_RAYS, N_samples=S_COARSE, near=NEAR, far=FAR,
+                                 mfma_split=mfma_split)
     with torch.no_grad():
         D.render_path(c2w[None].to(dev), (H_IMG, W_IMG, K), (mc, mf), args, labels_only=True)
         torch.cuda.synchronize()
@@ -268,7 +269,8 @@ def frame_leg(mc, mf, K, c2w, dev):
     dt = min(ts)
     return {"frames_per_s": 1.0 / dt, "seconds_per_frame": dt, "rays_per_s": H_IMG * W_IMG / dt,
             "labels_in_frame": int(len(torch.unique(out["label"]))),
-            "note": "render_path, one 640x480 pose: raygen + 75 x dm_nerf(4096 rays) + label/conf kernel, labels_only"}
+            "note": "render_path, one 640x480 pose: raygen + 75 x dm_nerf(4096 rays) + label/conf kernel, labels_only"
+                    + ("; opt-in split-bf16 MFMA (args.mfma_split)" if mfma_split else "")}
 
 
 def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
@@ -514,6 +516,7 @@ def main():
             res["frame"] = frame_leg(mc, mf, K, c2w, dev)
             res["render_fused_heads"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'])
             res["render_split_bf16"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], split=True)
+            res["frame_split_bf16"] = frame_leg(mc, mf, K, c2w, dev, mfma_split=True)
         if world == 1 and not a.no_train:
             tb = None
             if not a.no_cpu_baseline:                   # (before the GPU leg: it updates the weights in place)
