@@ -27,7 +27,7 @@ def short(name):
 p = find("trace", "*kernel_stats.csv")
 if p:
     print("== rocprofv3 --kernel-trace --stats :: bench_kernel_stats.csv (top rows) ==")
-    for r in list(csv.DictReader(open(p)))[:8]:
+    for r in list(csv.DictReader(open(p)))[:14]:
         print(f"{short(r['Name']):64s} calls={r['Calls']:>4s} total_ns={r['TotalDurationNs']:>11s} avg_ns={float(r['AverageNs']):>10.0f} pct={float(r['Percentage']):.3f}")
 p = find("trace", "*kernel_trace.csv")
 if p:
@@ -38,7 +38,7 @@ if p:
         g[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
     print("== kernel trace grouped by (kernel, grid threads) ==")
-    for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:8]:
+    for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:16]:
         m = meta[k]
         print(f"{k[0]:64s} grid={k[1]:>9d} n={len(v):>3d} avg_us={sum(v) / len(v) / 1e3:>9.1f} min_us={min(v) / 1e3:>9.1f} "
               f"vgpr={m[0]} agpr={m[1]} sgpr={m[2]} lds={m[3]} scratch={m[4]}")
