@@ -73,6 +73,49 @@ def test_split_index_addresses_the_right_parameters(ins_num):
     assert (idx[(s_inso + n_inso) * SLOT_ELEMS:] == -1).all()      # landing slots are zero
 
 
+@pytest.mark.parametrize("ins_num", [13, 59, 93, 120])
+def test_transposed_split_index_addresses_the_right_parameters(ins_num):
+    """The W^T split stream of the opt-in data-gradient kernel (layout.h::SplitTLayout): ins_linear^T | F^T | mlps.7^T .. mlps.1^T,
+    k = the layer's OUTPUTS in accumulator order, rows = its inputs; F sits behind the flat parameters."""
+    lib = _lib.load()
+    TAB_T = 1024
+    total = lib.dmnerf_blob_t_split_words(ins_num)
+    n = (total - TAB_T) * 2
+    idx = np.empty(n, dtype=np.int32)
+    _lib.check(lib.dmnerf_build_pack_index_t_split(ins_num, idx.ctypes.data_as(ctypes.c_void_p), n), "split index (transposed)")
+    C = ins_num + 1
+    obi = (C + 31) // 32
+    shapes = {"mlps.0": (256, 63), **{f"mlps.{i}": (256, 319 if i == 5 else 256) for i in range(1, 8)},
+              "rgb_feature_linear": (256, 256), "ins_feature_linear": (256, 256), "rgb_feature_linears.0": (128, 283),
+              "ins_feature_linears.0": (128, 256), "density_linear": (1, 256), "ins_linear": (C, 128), "rgb_linear": (3, 128)}
+    off, o = {}, 0
+    for m in W.PARAM_MODULES:
+        off[m] = o
+        o += shapes[m][0] * shapes[m][1] + shapes[m][0]
+    off["F"], shapes["F"] = o, (128, 256)                          # head product [rgb hidden 128][h_7 256], behind the parameters
+    n_inso = -(-2 * obi // 4)                                      # 2 OBI k-blocks, OB 4: 4 k-blocks per slot
+    assert n == (n_inso + 4 + 7 * 8 + 2) * SLOT_ELEMS              # F^T: 8 k-blocks of OB 8 = 4 slots; a stage: 8 slots; 2 landing slots
+
+    def check(slot0, mod, nkb, ob_n):
+        outs, ld = shapes[mod]
+        kps = 16 // ob_n
+        for kb in sorted({0, 1, nkb // 2, nkb - 1}):
+            for plane in range(3):
+                for ob in range(ob_n):
+                    for lane in (0, 7, 31, 32, 63):
+                        for q in range(8):
+                            e = ((slot0 + kb // kps) * 48 + ((kb % kps) * 3 + plane) * ob_n + ob) * 512 + lane * 8 + q
+                            out, inp = cfeat(8 * kb + q, lane >> 5), ob * 32 + (lane & 31)
+                            want = -1 if (out >= outs or inp >= min(ld, 32 * ob_n)) else (off[mod] + out * ld + inp) | (plane << 28)
+                            assert idx[e] == want, (mod, kb, plane, ob, lane, q, idx[e], want)
+
+    check(0, "ins_linear", 2 * obi, 4)
+    check(n_inso, "F", 8, 8)
+    for s, l in enumerate((7, 6, 5, 4, 3, 2, 1)):
+        check(n_inso + 4 + 8 * s, f"mlps.{l}", 16, 8)             # (mlps.5: its first 256 input columns = h; the 63 pts columns get no dgrad)
+    assert (idx[(n_inso + 4 + 56) * SLOT_ELEMS:] == -1).all()      # landing slots
+
+
 def test_fuse_heads_is_the_same_function():
     import torch
     from oracle import ref_cpu as O
