@@ -191,7 +191,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
                     + (f"; one batch sharded over {world} ranks (sharded_train_step)" if world > 1 else "")}
 
 
-def train_loop_leg(mc, mf, dev, steps):
+def train_loop_leg(mc, mf, dev, steps, mfma_split=False):
     """The training LOOP as shipped (configs/dmsr/train/study.txt: N_train 3072; train_dmsr.py:24-64): per iteration the
     batch selection on the reference's numpy stream -- drawn ahead by dm_nerf_amd.prefetch.TrainBatchPrefetcher on a side
     thread, dataset resident in HBM, indices through pinned memory -- then the same optimisation step as `train`.
@@ -210,7 +210,8 @@ def train_loop_leg(mc, mf, dev, steps):
     K = dmsr_intrinsics(H_IMG, W_IMG)
     mc.train(); mf.train()
     opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999))
-    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
+                                 mfma_split=mfma_split)
     z = H.z_val_sample(N, NEAR, FAR, S_COARSE, device=dev)
     torch.manual_seed(0); torch.cuda.manual_seed(0)
 
@@ -537,6 +538,8 @@ def main():
                                            "dgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_bwd")), None),
                                            "wgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("wgrad")), None),
                                            "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the split-bf16 MFMA kernels (f32-class values: six bf16 products per f32 product, f32 accumulation); not part of `train`"}
+                tl = train_loop_leg(mc, mf, dev, a.train_steps, mfma_split=True)
+                res["train_split_bf16"]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
         if train_multi is not None:
             res["train"] = train_multi
     if world > 1:
