@@ -5,12 +5,18 @@
 // activations, so a lane's 8 samples of a row (two ds_read_b128) are split ON THE FLY into three planes of packed bf16
 // pairs (split_bf16.h) and one 16-sample step of a tile pair is six v_mfma_f32_32x32x16_bf16 (hi hi, hi mid, hi lo, mid hi,
 // mid mid, lo hi) instead of eight v_mfma_f32_32x32x2_f32: 96 NBA NBB MFMA cycles per 32-sample chunk instead of 256 NBA NBB.
-// The 256 x 256 jobs move from the f32 MFMA roof to the HBM bound of their 64 KiB per chunk; the skinny jobs were there already.
+// Measured: a 32-sample chunk of a 256 x 256 job 7 025 -> 4 436 ns (its MFMAs alone: 2 560 ns at 2.4 GHz); the
+// skinny jobs were HBM- / hand-over-bound already and do not move.
 //
-// Schedule: a chunk is 2 steps x SAn "items" (one A block against the wave's SBn B blocks = 6 SBn MFMAs).  While the MFMAs of
-// item i run, the VALU splits the raw operands of item i + 1 (36 instructions per block) and the LDS reads of item i + 2
-// are issued, one piece of work per MFMA gap; B planes are double-buffered by step, A planes and raw operands by item.  The
-// ring hand-over sits at the start of the chunk's last-but-one item (every read of the chunk has returned by then).
+// Schedule: a chunk is 2 steps of 16 samples; a step is IS "items" (GA A blocks against the wave's SBn B blocks = 6 GA SBn
+// MFMAs, at least four accumulators in rotation wherever the tile has them).  While the MFMAs of item i run, the raw A
+// operands of item i + 1 are split and the LDS reads of item i + 2 are issued; the B operands of the NEXT step are read in a
+// step's first item (the hand-over item when that step belongs to the next chunk) and split over the rest of the step.  All
+// of it is placed per MFMA gap: a one-wave-per-SIMD kernel hides ~5 single-issue instructions per MFMA, so the split of an
+// operand pair is cut into two units of 5 / 6 instructions and the units of a chunk are spread evenly (no packed f32 VALU:
+// split_bf16.h::split_pair_scalar's arithmetic, this file is built with -fno-slp-vectorize).  B planes are double-buffered
+// by step, A planes and raw operands by item.  The ring hand-over sits at the start of the chunk's last-but-one item (every
+// read of the chunk has returned by then), the refill pieces follow it three gaps apart.
 // f32-class results (not the bitwise fmaf chain of wgrad.hip), hence opt-in.
 #include "split_bf16.h"
 #include "wgrad_common.h"
