@@ -163,17 +163,17 @@ def grad_arena(models):
 
 
 class MLPRaysFunction(torch.autograd.Function):
-    """raw[N,S,4+C] = DM_NeRF(embed(o + d z) | embed(d/|d|)); parameters are inputs 3.. in state_dict order."""
+    """raw[N,S,4+C] = DM_NeRF(embed(o + d z) | embed(d/|d|)); parameters are inputs 5.. in state_dict order.
+    ``mode``: None (default f32 kernels) | "fused" | "split" (the opt-in variants of run_network_train)."""
 
     @staticmethod
-    def forward(ctx, model, rays_o, rays_d, z, *params):
+    def forward(ctx, model, mode, rays_o, rays_d, z, *params):
         lib = _lib.load()
         N, S = z.shape
         M = N * S
         ins_num = model.ins_num
         raw = torch.empty(N, S, 4 + ins_num + 1, dtype=torch.float32, device=z.device)
         save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
-        mode = getattr(model, "_train_mode", None)                   # opt-in forward variants: see run_network_train
         blob = model.blob()
         if mode == "split":
             fwd_blob, fn = model.blob_split(), lib.dmnerf_mlp_fwd_rays_train_split
@@ -191,7 +191,7 @@ class MLPRaysFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_raw):
-        return (None, None, None, None) + _mlp_backward(ctx, g_raw)
+        return (None, None, None, None, None) + _mlp_backward(ctx, g_raw)
 
 
 def _mlp_backward(ctx, g_raw):
@@ -294,11 +294,11 @@ def _params(model):
 
 
 def run_network_train(model, rays_o, rays_d, z, fused=False, split=False):
-    """Differentiable (w.r.t. the parameters) fused points + encoding + MLP.  Opt-in forward variants (the backward is the
-    same f32 one either way): ``fused`` (``args.fuse_heads``) runs the forward on the fused-heads blob (-19 % MACs; values
-    equal up to f32 re-association, not bit-equal to the inference default); ``split`` (``args.mfma_split``) runs it on the
-    split-bf16 MFMA kernel (fused heads + six bf16 products per f32 product: f32-class values at 2.1x the f32 MFMA rate)."""
-    model._train_mode = ("split" if split else "fused" if fused else None) if model._fused_ok() else None
+    """Differentiable (w.r.t. the parameters) fused points + encoding + MLP.  Opt-in variants: ``fused`` (``args.fuse_heads``)
+    runs the FORWARD on the fused-heads blob (-19 % MACs; values equal up to f32 re-association, not bit-equal to the inference
+    default; default f32 backward); ``split`` (``args.mfma_split``) runs forward, data gradients and weight gradients on the
+    split-bf16 MFMA kernels (fused heads + six bf16 products per f32 product: f32-class values)."""
+    mode = "split" if split else "fused" if fused else None
     if not model._fused_ok():                              # another network shape: layer by layer, its own autograd Function
         from . import generic
         return generic.run_network(model, rays_o, rays_d, z, train=True)
@@ -307,12 +307,12 @@ def run_network_train(model, rays_o, rays_d, z, fused=False, split=False):
     N, S = z.shape
     max_rays = max(1, MAX_TRAIN_SAMPLES // S)
     if N <= max_rays:
-        return MLPRaysFunction.apply(model, rays_o, rays_d, z, *_params(model))
+        return MLPRaysFunction.apply(model, mode, rays_o, rays_d, z, *_params(model))
     # a training launch addresses its saved-activation workspace with 32-bit byte offsets (DMNERF_MAX_TRAIN_SAMPLES in
     # include/dmnerf_hip.h): larger batches run as several launches, each with its own workspace; autograd adds the
     # parameter gradients of the pieces (rays are independent, so this is the same sum in a different order)
     params = _params(model)
-    return torch.cat([MLPRaysFunction.apply(model, rays_o[s:s + max_rays], rays_d[s:s + max_rays], z[s:s + max_rays], *params)
+    return torch.cat([MLPRaysFunction.apply(model, mode, rays_o[s:s + max_rays], rays_d[s:s + max_rays], z[s:s + max_rays], *params)
                       for s in range(0, N, max_rays)], 0)
 
 
