@@ -339,24 +339,33 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
         after += total;
     }
 
-    // pass 3: channel gradients, lane <-> channel
+    // pass 3: channel gradients.  Per-channel coefficients once (the sample weights' LDS row is reused: t is dead), then
+    // the ray's S x (4 + C) block as ONE contiguous stream, lane <-> element (coalesced 256-byte stores, every lane busy)
+    lds_sync_wave();
+    float* cl = tl;                                       // MAX_S >= 4 + MAX_LOGITS
     for (int c = lane; c < ch; c += WAVE) {
-        if (c == 3) continue;
-        if (c < 3) {
-            const float g = c == 0 ? gr0 : (c == 1 ? gr1 : gr2);
-            for (int s = 0; s < S; ++s) {
-                const float sg = sigmoidf_ref(rr[(int64_t)s * ch + c]);
-                dr[(int64_t)s * ch + c] = (g * wl[s]) * ((1.f - sg) * sg);
-            }
-        } else {
-            const int k = c - 4;
-            float coef = 0.f;
-            if (k < C - 1) {
-                const float mk = ins_map[n * (int64_t)(C - 1) + k];
-                coef = g_ins[n * (int64_t)(C - 1) + k] * ((1.f - mk) * mk);
-            }
-            for (int s = 0; s < S; ++s) dr[(int64_t)s * ch + c] = coef * wl[s];
+        float coef = 0.f;
+        if (c < 3) coef = c == 0 ? gr0 : (c == 1 ? gr1 : gr2);
+        else if (c >= 4 && c - 4 < C - 1) {
+            const float mk = ins_map[n * (int64_t)(C - 1) + (c - 4)];
+            coef = g_ins[n * (int64_t)(C - 1) + (c - 4)] * ((1.f - mk) * mk);
         }
+        cl[c] = coef;
+    }
+    lds_sync_wave();
+    int s = lane / ch, c = lane - s * ch;
+    const int ds = WAVE / ch, dc = WAVE - ds * ch;
+    for (int e = lane; e < S * ch; e += WAVE) {
+        if (c != 3) {
+            if (c < 3) {
+                const float sg = sigmoidf_ref(rr[e]);
+                dr[e] = (cl[c] * wl[s]) * ((1.f - sg) * sg);
+            } else {
+                dr[e] = cl[c] * wl[s];
+            }
+        }
+        s += ds; c += dc;
+        if (c >= ch) { c -= ch; ++s; }
     }
 }
 

@@ -188,7 +188,16 @@ __global__ void wgrad_reduce_kernel(float* __restrict__ part, const WgOut* __res
         if (e < n_w) {
             const int r = (int)(e / o.rowsB), c = (int)(e % o.rowsB);
             const float* p = part + o.part_off + (int64_t)r * o.ldp + c;
-            for (int k = 0; k < o.n_slices; ++k) s += p[k * o.slice_stride];
+            // fixed slice order; eight loads in flight per trip (the loop is latency-bound otherwise)
+            int k = 0;
+            for (; k + 8 <= o.n_slices; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * o.slice_stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < o.n_slices; ++k) s += p[k * o.slice_stride];
             const int ro = o.perm_a ? row_feature(r) : r, co = o.perm_b ? row_feature(c) : c;
             grad[o.out_off + (int64_t)ro * o.ld_out + o.col_off + co] = s;
         } else {
