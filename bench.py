@@ -299,14 +299,19 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
         return time.perf_counter() - t0
 
     torch.autograd.set_detect_anomaly(False)
-    t_small = one(128); t_small = one(128)                # warm-up (thread pools, allocator) + calibration
+    t_begin = time.perf_counter()
+    one(128)                                              # warm-up (thread pools, allocator)
+    t128, t256 = one(128), one(256)                       # calibration: step time ~ a + b n (the small step is mostly fixed cost)
+    b = max((t256 - t128) / 128.0, 1e-4)
+    a_ = max(t128 - 128.0 * b, 0.0)
     n = 1024
-    est = t_small * n / 128 * 1.3                         # the step grows a little faster than linearly with the batch
-    reps = 3 if est * 4.2 <= seconds else (1 if est * 2.2 <= seconds else 0)
-    if reps == 0:
-        n = int(max(128, min(1024, (seconds / 2.2) / (t_small * 1.3 / 128) // 128 * 128)))
-        reps = 1
-    ts = [one(n) for _ in range(reps)]
+    if (a_ + b * n) * 1.3 * 2.2 > seconds:                # a host too slow for even one full-size step + the anomaly step
+        n = int(max(128, min(1024, ((seconds / (2.2 * 1.3)) - a_) / b // 128 * 128)))
+    ts = [one(n)]
+    # up to three timed steps, as long as another one AND the anomaly-on step still fit (decided on measured step times)
+    while len(ts) < 3 and (time.perf_counter() - t_begin) + 2.1 * max(ts) <= seconds:
+        ts.append(one(n))
+    reps = len(ts)
     dt = statistics.median(ts)
     torch.autograd.set_detect_anomaly(True)
     try:
