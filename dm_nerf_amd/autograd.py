@@ -174,7 +174,7 @@ class MLPRaysFunction(torch.autograd.Function):
         ins_num = model.ins_num
         raw = torch.empty(N, S, 4 + ins_num + 1, dtype=torch.float32, device=z.device)
         save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
-        blob = model.blob()
+        blob = None if mode == "split" else model.blob()          # (the f32 dgrad reads it; the split kernels have their own blobs)
         if mode == "split":
             fwd_blob, fn = model.blob_split(), lib.dmnerf_mlp_fwd_rays_train_split
         elif mode == "fused":
