@@ -199,7 +199,8 @@ int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t
 int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                            const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream);
-/* OPT-IN split-bf16 weight gradients (training with args.mfma_split; csrc/wgrad_split.hip): the same tables, workspace and
+/* OPT-IN split-bf16 weight gradients (training with args.mfma_split; csrc/wgrad_split.hip) -- the parameter gradients of
+ * networks/dm_nerf.py:80-106 that torch autograd forms in the reference's train loops (train_dmsr.py:62-64): the same tables, workspace and
  * second stage; both f32 operands are split on the fly into three bf16 planes and a product is six bf16 MFMAs accumulated
  * in f32 (f32-class, not the bitwise chain of dmnerf_mlp_bwd_weights).  The _split plan balances the slices for this
  * kernel's chunk times (its 256 x 256 jobs are HBM-bound); either plan is valid for either kernel.                  */
