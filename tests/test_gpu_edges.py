@@ -245,3 +245,57 @@ def test_device_head_fusion_equals_the_float64_formula(A):
         off = sum(v.numel() for k, v in sd.items() if k.split(".")[0] in ("mlps", "rgb_feature_linear", "ins_feature_linear") and not k.startswith("rgb_feature_linears"))
         w_rh = got[off:off + 128 * 283].reshape(128, 283)
         assert torch.equal(w_rh[:, 256:], sd["rgb_feature_linears.0.weight"][:, 256:])
+
+
+def test_training_batches_beyond_the_launch_limit_run_as_several_launches(monkeypatch):
+    """A training launch addresses its workspace with 32-bit byte offsets (DMNERF_MAX_TRAIN_SAMPLES): larger batches are cut
+    into several launches whose parameter gradients autograd adds up (autograd.run_network_train / mlp_forward_train).  With
+    the limit lowered to 4096 samples a 100-ray x 64-sample batch runs as two launches: same raw (bit for bit: rays are
+    independent), gradients equal to the single launch's up to the summation order; an over-long direct C-ABI call is refused."""
+    import types
+    from dm_nerf_amd import _lib, autograd as G
+    from dm_nerf_amd.networks import dm_nerf as M
+    lib = _lib.load()
+    torch.manual_seed(3)
+    ins_num, N, S = 13, 100, 64
+    m = M.DM_NeRF(8, 256, 63, 27, [4], ins_num).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    ro, rd = torch.randn(N, 3, device="cuda", generator=g), torch.randn(N, 3, device="cuda", generator=g)
+    z = torch.sort(torch.rand(N, S, device="cuda", generator=g) * 5 + 1, -1)[0]
+    cot = torch.randn(N, S, 4 + ins_num + 1, device="cuda", generator=g)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        raw = G.run_network_train(m, ro, rd, z)
+        (raw * cot).sum().backward()
+        return raw.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+    raw1, g1 = run()
+    monkeypatch.setattr(G, "MAX_TRAIN_SAMPLES", 4096)
+    raw2, g2 = run()
+    assert torch.equal(raw1, raw2)
+    for (k, _), a, b in zip(m.named_parameters(), g1, g2):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, k
+    # pre-embedded rows: the same cut
+    x = torch.randn(6000, 90, device="cuda", generator=g)
+    for p in m.parameters():
+        p.grad = None
+    out2 = m(x); out2.square().sum().backward()
+    gx2 = [p.grad.clone() for p in m.parameters()]
+    monkeypatch.setattr(G, "MAX_TRAIN_SAMPLES", 1048576)
+    for p in m.parameters():
+        p.grad = None
+    out1 = m(x); out1.square().sum().backward()
+    assert torch.equal(out1.detach(), out2.detach())
+    for (k, _), a, b in zip(m.named_parameters(), [p.grad for p in m.parameters()], gx2):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, k
+    # the C ABI itself refuses a launch beyond the limit (loudly, before anything is launched)
+    n_big = 1048576 // 64 + 1                                   # 16385 rays x 64 samples = the limit + 64
+    rob, rdb = torch.randn(n_big, 3, device="cuda"), torch.randn(n_big, 3, device="cuda")
+    zb = torch.sort(torch.rand(n_big, 64, device="cuda") * 5 + 1, -1)[0]
+    rawb = torch.empty(n_big, 64, 4 + ins_num + 1, device="cuda")
+    rc = lib.dmnerf_mlp_fwd_rays_train(_lib.ptr(m.blob()), ins_num, _lib.ptr(rob), _lib.ptr(rdb), _lib.ptr(zb), n_big, 64,
+                                       _lib.ptr(rawb), _lib.ptr(rawb), _lib.stream())
+    assert rc != 0 and b"exceed" in lib.dmnerf_last_error(), (rc, lib.dmnerf_last_error())
+    torch.cuda.synchronize()
