@@ -299,3 +299,18 @@ def test_training_batches_beyond_the_launch_limit_run_as_several_launches(monkey
                                        _lib.ptr(rawb), _lib.ptr(rawb), _lib.stream())
     assert rc != 0 and b"exceed" in lib.dmnerf_last_error(), (rc, lib.dmnerf_last_error())
     torch.cuda.synchronize()
+
+
+def test_more_objects_than_the_abi_supports_is_refused_loudly():
+    """C = ins_num + 1 <= DMNERF_MAX_LOGITS = 128 (include/dmnerf_hip.h; Replica room_0 has 94): ins_num = 128 constructs (it is
+    an ordinary nn.Module) but every path into a kernel raises instead of truncating the object-code head."""
+    from dm_nerf_amd.networks import dm_nerf as M, render as R
+    m = M.DM_NeRF(8, 256, 63, 27, [4], 128).cuda()
+    with pytest.raises((ValueError, RuntimeError)):
+        m.blob()
+    ro, rd = torch.randn(4, 3, device="cuda"), torch.randn(4, 3, device="cuda")
+    z = torch.sort(torch.rand(4, 8, device="cuda") + 1, -1)[0]
+    with pytest.raises((ValueError, RuntimeError)), torch.no_grad():
+        R.run_network(m, ro, rd, z)
+    with pytest.raises((ValueError, RuntimeError)):
+        m.train()(torch.randn(8, 90, device="cuda"))

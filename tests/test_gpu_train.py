@@ -84,7 +84,8 @@ def _oracle_mlp_grads(sd, rays_o, rays_d, z, cot):
 
 
 def test_mlp_backward_vs_autograd(A):
-    for N, S, ins_num, seed in ((8, 64, 13, 5), (3, 21, 13, 6), (4, 32, 59, 7), (5, 40, 93, 8)):
+    # ins_num 127 / 1: the widest (C = 128 = DMNERF_MAX_LOGITS, four logit blocks) and the narrowest object-code head
+    for N, S, ins_num, seed in ((8, 64, 13, 5), (3, 21, 13, 6), (4, 32, 59, 7), (5, 40, 93, 8), (3, 20, 127, 9), (2, 17, 1, 10)):
         sd = O.make_weights(seed, ins_num, gain=1.7)
         g = torch.Generator().manual_seed(seed)
         rays_o = torch.randn(N, 3, generator=g)
