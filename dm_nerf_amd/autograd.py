@@ -200,6 +200,13 @@ def _mlp_backward(ctx, g_raw):
     model, M = ctx.model, ctx.M
     ins_num = model.ins_num
     C = ins_num + 1
+    if M == 0:                                                   # an empty batch (e.g. a rank's empty shard): zero gradients
+        ctx.save = None
+        arena = getattr(model, "_grad_arena", None)
+        flat = arena[0].take(arena[1]) if arena is not None and arena[0].flat.device == g_raw.device else None
+        if flat is None:
+            flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g_raw.device)
+        return tuple(split_flat_grads(model, flat.zero_()))
     g = _lib.f32(g_raw).reshape(M, 4 + C)
     dsave = torch.empty_like(ctx.save)
     Mp = _row_len(M)

@@ -314,3 +314,16 @@ def test_more_objects_than_the_abi_supports_is_refused_loudly():
         R.run_network(m, ro, rd, z)
     with pytest.raises((ValueError, RuntimeError)):
         m.train()(torch.randn(8, 90, device="cuda"))
+
+
+def test_empty_training_batch_gives_zero_gradients(A):
+    """An empty batch (a rank whose shard of a tiny batch is empty) trains without error: raw [0, S, 4 + C], zero gradients."""
+    from dm_nerf_amd import autograd as G
+    m = A.M.DM_NeRF(8, 256, 63, 27, [4], 13).cuda().train()
+    ro, rd = torch.empty(0, 3, device="cuda"), torch.empty(0, 3, device="cuda")
+    z = torch.empty(0, 64, device="cuda")
+    raw = G.run_network_train(m, ro, rd, z)
+    assert raw.shape == (0, 64, 18)
+    raw.sum().backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k
