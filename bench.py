@@ -14,7 +14,10 @@ FRAME over RCCL (what distributed.render_frame does).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`; secondary objects
 (never part of `value`): `frame` (one complete 640x480 pose through the frame driver), `train` (one optimisation step,
 its own per-kernel roofline and CPU baseline), `train_loop` (the shipped N_train = 3072 loop incl. batch selection),
-`render_fused_heads`, `render_split_bf16`, `frame_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes).
+`render_fused_heads`, `render_split_bf16`, `frame_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes),
+`render_ins59` / `train_ins59` (BASELINE config 3: Replica-width object head), `manipulator` (BASELINE config 5: the
+manipulation render of networks/manipulator.py:137-205, T = 1 and 2 moved objects), `train_shard_proxy` (the full step at the
+384 / 512 rays one of 8 ranks sees under strong scaling: what a one-GPU box can say about the 8-GPU run).
 """
 import argparse
 import json
@@ -38,6 +41,20 @@ H_IMG, W_IMG = 480, 640
 NEAR, FAR = 4.0, 15.0
 MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)          # 693 504
 F32_MFMA_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+B16_MFMA_PEAK_TFLOPS = 2500.0                          # same guide: dense bf16 / f16 v_mfma_f32_32x32x16_*
+HAVE_F16X2 = False                                     # set in main(): the library exports the f16x2 split kernels
+
+
+def mac_counts(ins_num):
+    """MACs per sample.  ``reference_*``: the reference's formulation (forward = wgrad = 691 712 + 128 C,
+    dgrad = that - 101 248).  ``fwd`` / ``fwd_fused`` / ``dgrad`` / ``wgrad``: what this library's kernels EXECUTE after the head
+    re-association (useful MACs, zero padding not counted): the fused-heads / split forward and the
+    weight-gradient kernel lose the two activation-free 256 x 256 products (-131 072); the data-gradient kernel runs
+    mlps.7^T .. mlps.1^T (7 x 65 536), F^T (32 768), ins_linear^T (128 C) and the two VALU heads (384 + 256)."""
+    C = ins_num + 1
+    ref = 691712 + 128 * C
+    return {"reference_fwd": ref, "reference_dgrad": ref - 101248, "reference_wgrad": ref,
+            "fwd": ref, "fwd_fused": ref - 131072, "dgrad": 7 * 65536 + 32768 + 128 * C + 384 + 256, "wgrad": ref - 131072}
 
 
 def parse():
@@ -95,11 +112,11 @@ def host_info():
     return {"cpu_model": model, "logical_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
 
 
-def build_models(device):
+def build_models(device, ins_num=None):
     from dm_nerf_amd import config as Cfg
     torch.manual_seed(0)
     args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256,
-                                 ins_num=INS_NUM, device=device)
+                                 ins_num=INS_NUM if ins_num is None else ins_num, device=device)
     pe, ve, mc, mf, _ = Cfg.create_nerf(args)
     with torch.no_grad():                       # "trained-like": give the density head surfaces
         mc.density_linear.bias.add_(0.3)
@@ -107,11 +124,12 @@ def build_models(device):
     return pe, ve, mc.eval(), mf.eval()
 
 
-def train_flop_per_ray():
-    return 2.0 * (2 * MAC_PER_SAMPLE + (MAC_PER_SAMPLE - 101248)) * (2 * S_COARSE + N_IMP)
+def train_flop_per_ray(ins_num=None):
+    m = mac_counts(INS_NUM if ins_num is None else ins_num)
+    return 2.0 * (m["reference_fwd"] + m["reference_wgrad"] + m["reference_dgrad"]) * (2 * S_COARSE + N_IMP)
 
 
-def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, mfma_split=False):
+def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, mfma_split=False, ins_num=None):
     """Secondary measurement: rays/s of one full optimisation step on ONE batch of ``n`` rays (default 4096 per GPU;
     64+128 samples, perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
     levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
@@ -121,8 +139,11 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     world > 1: the batch is sharded over the ranks by dm_nerf_amd.distributed.sharded_train_step -- batch-global losses on
     all-gathered rgb / ins, penalizer sums and the 5.57 MB gradient arena all-reduced in place over RCCL; ``ro`` / ``rd``
     must then hold the same rays on every rank.  Also returns the per-kernel roofline of the three MFMA kernels of the
-    fine-network pass, timed with HIP events on their stream (autograd.KERNEL_EVENTS)."""
+    fine-network pass, timed with HIP events on their stream (autograd.KERNEL_EVENTS): ``frac`` divides the MACs the kernel
+    EXECUTES (mac_counts) by the peak of the MFMA type it runs on; ``algorithmic_frac`` divides the reference's FLOP count of
+    the stage -- it exceeds ``frac`` where the head re-association removed work."""
     from dm_nerf_amd import autograd as G, distributed as D
+    ins_num = INS_NUM if ins_num is None else ins_num
     mc.train(); mf.train()
     params = list(mc.parameters()) + list(mf.parameters())
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
@@ -139,7 +160,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     torch.cuda.manual_seed(0)
 
     def one():
-        return D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, INS_NUM)[0]
+        return D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, ins_num)[0]
 
     def fence():
         if world > 1:
@@ -161,34 +182,81 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     mc.eval(); mf.eval()
-    flop = train_flop_per_ray() * n
+    mac = mac_counts(ins_num)
+    flop_ref = train_flop_per_ray(ins_num) * n
     # per-kernel roofline of the fine-network launches (the dominant ones: 192 of the 256 samples per ray)
     n_local = D.ray_slice(n, D.world_info()[0], world)[1]
     m_fine = n_local * (S_COARSE + N_IMP)
-    per_flop = {"mlp_fwd_train": 2.0 * MAC_PER_SAMPLE, "mlp_bwd_data": 2.0 * (MAC_PER_SAMPLE - 101248), "mlp_bwd_weights": 2.0 * MAC_PER_SAMPLE}
-    names = {"mlp_fwd_train": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,true,false>", "mlp_bwd_data": f"mlp_bwd_kernel<{(INS_NUM + 32) // 32}>",
-             "mlp_bwd_weights": "wgrad_kernel + wgrad_reduce_kernel"}
+    obi = (ins_num + 32) // 32
+    fwd_exec = mac["fwd_fused"] if (mfma_split or fuse_heads) else mac["fwd"]
+    products = split_products(mfma_split)               # 16-bit MFMA products per f32 product (1 on the f32 MFMA)
+    peak = B16_MFMA_PEAK_TFLOPS if mfma_split else F32_MFMA_PEAK_TFLOPS
+    exec_mac = {"mlp_fwd_train": fwd_exec, "mlp_bwd_data": mac["dgrad"], "mlp_bwd_weights": mac["wgrad"]}
+    ref_mac = {"mlp_fwd_train": mac["reference_fwd"], "mlp_bwd_data": mac["reference_dgrad"], "mlp_bwd_weights": mac["reference_wgrad"]}
+    names = {"mlp_fwd_train": f"mlp_fwd_kernel<{obi},false,true,false>", "mlp_bwd_data": f"mlp_bwd_kernel<{obi}>",
+             "mlp_bwd_weights": "wgrad_kernel + wgrad_reduce_kernel + head_unfuse_kernel"}
     if mfma_split:
-        names.update(mlp_fwd_train=f"mlp_split_kernel<{(INS_NUM + 32) // 32},true>", mlp_bwd_data=f"mlp_bwd_split_kernel<{(INS_NUM + 32) // 32}>")
+        names.update(split_kernel_names(mfma_split, obi))
     elif fuse_heads:
-        names.update(mlp_fwd_train=f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},true,true,false>")
+        names.update(mlp_fwd_train=f"mlp_fwd_kernel<{obi},true,true,false>")
     kernels = []
     for tag in ("mlp_fwd_train", "mlp_bwd_data", "mlp_bwd_weights"):
         ms = [b.elapsed_time(e) for t, M, b, e in events if t == tag and M == m_fine]
         if ms:
             k_ms = float(np.mean(ms))
-            tf = per_flop[tag] * m_fine / (k_ms * 1e-3) / 1e12
-            kernels.append({"kernel": names[tag], "launches": len(ms), "kernel_ms": k_ms, "achieved": tf, "frac": tf / F32_MFMA_PEAK_TFLOPS})
+            tf = 2.0 * exec_mac[tag] * products * m_fine / (k_ms * 1e-3) / 1e12
+            tf_ref = 2.0 * ref_mac[tag] * m_fine / (k_ms * 1e-3) / 1e12
+            kernels.append({"kernel": names[tag], "launches": len(ms), "kernel_ms": k_ms, "mac_per_sample_executed": exec_mac[tag],
+                            "mfma_products_per_mac": products, "achieved": tf, "peak": peak, "frac": tf / peak,
+                            "algorithmic_tflops": tf_ref, "algorithmic_frac": tf_ref / F32_MFMA_PEAK_TFLOPS})
     worst = min(kernels, key=lambda k: k["frac"]) if kernels else None
-    return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop / dt / 1e12,
-            "frac_of_f32_mfma_peak": flop / dt / 1e12 / (F32_MFMA_PEAK_TFLOPS * world), "final_loss": float(loss.detach()),
-            "batch_rays": n,
-            "roofline": None if worst is None else {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS, "kernel": worst["kernel"],
+    flop_exec = 2.0 * (fwd_exec + mac["dgrad"] + mac["wgrad"]) * products * (2 * S_COARSE + N_IMP) * n
+    return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop_exec / dt / 1e12, "tflops_reference_flops": flop_ref / dt / 1e12,
+            "frac_of_mfma_peak": {"executed": flop_exec / dt / 1e12 / (peak * world), "reference_flops": flop_ref / dt / 1e12 / (F32_MFMA_PEAK_TFLOPS * world),
+                                  "peak": peak, "note": "whole step incl. losses, compositing, Adam; executed = MFMA work the three MLP kernels issue "
+                                                        "(mac_counts), reference_flops = SURVEY 8(d)'s 1013 MFLOP/ray against the f32 MFMA peak"},
+            "final_loss": float(loss.detach()),
+            "batch_rays": n, "ins_num": ins_num,
+            "roofline": None if worst is None else {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "kernel": worst["kernel"],
                                                     "kernel_ms": worst["kernel_ms"], "achieved": worst["achieved"], "frac": worst["frac"],
                                                     "samples_per_launch": m_fine, "all": kernels,
-                                                    "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; `kernel` = the one furthest below the roof"},
+                                                    "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; `kernel` = the one furthest below "
+                                                            "the roof on EXECUTED MACs; algorithmic_* = the reference's FLOP count of the stage over the same time"},
             "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"
                     + (f"; one batch sharded over {world} ranks (sharded_train_step)" if world > 1 else "")}
+
+
+def split_products(mode):
+    """16-bit MFMA products per f32 product of an ``args.mfma_split`` mode (False: the f32 MFMA, one)."""
+    if not mode:
+        return 1
+    return 3 if str(mode) == "f16x2" else 6
+
+
+def split_kernel_names(mode, obi):
+    obx = 4 if obi == 3 else obi
+    if str(mode) == "f16x2":
+        return {"mlp_fwd_train": f"mlp_f16_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_f16_kernel<{obi}>", "mlp_bwd_weights": "wgrad_f16_kernel + reduce + unfuse"}
+    return {"mlp_fwd_train": f"mlp_split_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_split_kernel<{obi}>", "mlp_bwd_weights": "wgrad_split_kernel + reduce + unfuse"}
+
+
+def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full):
+    """What ONE GPU can say about the 8-GPU strong-scaling run (SURVEY 8(e) caveat): the complete optimisation step at the
+    per-rank shard of an 8-way split of the shipped batch sizes -- 384 rays (N_train 3072 / 8) and 512 rays (4096 / 8).
+    predicted_strong_efficiency_8 = (t_full / 8) / t_shard: the fixed per-step cost (launch overheads, the loss / Adam
+    kernels that do not shrink with the batch) is what keeps it below 1; the exchange itself (0.2 MB gather + one 5.57 MB
+    all-reduce) is not in it."""
+    out = {}
+    for n in (384, 512):
+        r = train_leg(mc, mf, ro, rd, z, steps, dev, n=n)
+        out[f"n{n}"] = {"ms_per_step": r["ms_per_step"], "rays_per_s": r["rays_per_s"],
+                        "kernel_ms": {k["kernel"].split("<")[0].split(" ")[0]: k["kernel_ms"] for k in (r["roofline"] or {}).get("all", [])}}
+    out["full_batch_rays"] = n_full
+    out["full_batch_ms"] = t_full_ms
+    out["predicted_strong_efficiency_8"] = {"n512_of_4096": (t_full_ms / 8.0) / out["n512"]["ms_per_step"] * (4096.0 / n_full)}
+    out["note"] = ("full optimisation step (same recipe as `train`) at the per-rank shard of an 8-way strong split; efficiency = "
+                   "(t_full / 8) / t_shard with t_full rescaled to 4096 rays")
+    return out
 
 
 def train_loop_leg(mc, mf, dev, steps, mfma_split=False):
@@ -325,14 +393,20 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
             "host": host_info()}
 
 
-def fused_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref, split=False):
-    """Not the headline: the same render step with an opt-in inference mode.  split=False: the activation-free
-    rgb_feature_linear / ins_feature_linear folded into the hidden layers (562 432 instead of 693 504
-    MAC per sample, results equal up to f32 re-association).  split=True: additionally the GEMMs on the bf16 MFMA with
-    every f32 operand split into three bf16 planes and six products per term (f32-class accuracy, csrc/mlp_split.hip)."""
+def render_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref=None, fuse_heads=False, mfma_split=False, ins_num=None):
+    """Not the headline: the same render step (dm_nerf on 4096-ray chunks of the band) in another configuration.
+    fuse_heads: the activation-free rgb_feature_linear / ins_feature_linear folded into the hidden layers (SURVEY 8(f)-4;
+    562 432 instead of 693 504 MAC per sample at ins_num 13, results equal up to f32 re-association).  mfma_split: additionally the
+    GEMMs on the 16-bit MFMA with every f32 operand split into planes -- True / "bf16x3": three bf16 planes, six products;
+    "f16x2": two f16 planes, three products (f32-class accuracy either way; csrc/mlp_split_impl.h, csrc/mlp_f16_impl.h).
+    ins_num: the models' object-code width (BASELINE config 3: Replica office_0 = 59).  Roofline of the fine-network launch from
+    HIP events around it: executed MACs x 16-bit products against the peak of the MFMA type used."""
     from dm_nerf_amd.networks import render as R
-    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, fuse_heads=True, mfma_split=split)
+    ins_num = INS_NUM if ins_num is None else ins_num
+    fused = bool(fuse_heads or mfma_split)
+    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, fuse_heads=fused, mfma_split=mfma_split)
     n_chunks = ro.shape[0] // N_RAYS
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     with torch.no_grad():
         for i in range(2):
             out = R.dm_nerf(torch.stack([ro[:N_RAYS], rd[:N_RAYS]]), pe, ve, mc, mf, z, args)
@@ -340,14 +414,61 @@ def fused_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref, split=False):
         t0 = time.perf_counter()
         for i in range(steps):
             c = i % n_chunks
-            out = R.dm_nerf(torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]]), pe, ve, mc, mf, z, args)
+            out = R.dm_nerf(torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]]), pe, ve, mc, mf, z, args, _events=ev[i])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-    d = float((out['rgb_fine'] - rgb_ref).abs().max())          # same last chunk as the headline loop
-    return {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "mac_per_sample": 562432,
-            "max_abs_rgb_diff_vs_layerwise": d,
-            "note": ("opt-in (args.mfma_split): fused heads + split-bf16 MFMA, six bf16 products per f32 product" if split
-                     else "opt-in (args.fuse_heads)") + ", not the headline metric"}
+    mac = mac_counts(ins_num)
+    exec_mac = mac["fwd_fused"] if fused else mac["fwd"]
+    products = split_products(mfma_split)
+    peak = B16_MFMA_PEAK_TFLOPS if mfma_split else F32_MFMA_PEAK_TFLOPS
+    k_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))
+    tf = 2.0 * exec_mac * products * N_RAYS * (S_COARSE + N_IMP) / (k_ms * 1e-3) / 1e12
+    res = {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "ins_num": ins_num, "mac_per_sample": exec_mac,
+           "roofline": {"bound": "mfma", "unit": "TFLOP/s", "kernel_ms": k_ms, "achieved": tf, "peak": peak, "frac": tf / peak,
+                        "mfma_products_per_mac": products, "note": "fine-network MLP launch, HIP events; executed MACs x 16-bit products per MAC"},
+           "note": ("opt-in (args.mfma_split = %r): fused heads + split-operand 16-bit MFMA" % (mfma_split,) if mfma_split
+                    else "opt-in (args.fuse_heads)" if fuse_heads else "default f32 path") + ", not the headline metric"}
+    if rgb_ref is not None:                                      # same last chunk as the headline loop
+        res["max_abs_rgb_diff_vs_layerwise"] = float((out['rgb_fine'] - rgb_ref).abs().max())
+    return res
+
+
+def manipulator_leg(mc, mf, K, dev, steps=3):
+    """BASELINE config 5's render: ``manipulator`` (networks/manipulator.py:137-205) on one 4096-ray chunk with T = 1 and T = 2
+    moved objects -- per call 1 + T coarse and 1 + T fine network passes of 64 / 192 samples per ray plus 2 T passes on the merged
+    64 + 128 + 128 T depths (T = 1: 1152 network samples per ray = 4.5 x a dm_nerf render), three resamplings with random u (sample_pdf(det=False) even at evaluation), two exchanger
+    rounds, the final composite.  Rays: the bench camera for the original view; each target view is the same camera
+    moved by a rigid transform (what manipulator_demo does with the edited object's pose, :346-371)."""
+    from dm_nerf_amd.networks import helpers as H, manipulator as MA
+    from dm_nerf_amd.synthetic import pose_spherical
+    c2w = pose_spherical(30.0, -65.0, 7.0).to(dev)
+    ro, rd = H.get_rays_k(H_IMG, W_IMG, K, c2w)
+    ori = torch.stack([ro.reshape(-1, 3)[:N_RAYS], rd.reshape(-1, 3)[:N_RAYS]])
+    tars = []
+    for k in range(2):
+        c2 = pose_spherical(30.0 + 4.0 * (k + 1), -65.0, 7.0 + 0.1 * (k + 1)).to(dev)
+        to, td = H.get_rays_k(H_IMG, W_IMG, K, c2)
+        tars.append(torch.stack([to.reshape(-1, 3)[:N_RAYS], td.reshape(-1, 3)[:N_RAYS]]))
+    out = {}
+    for T in (1, 2):
+        args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, target_labels=list(range(1, T + 1)))
+        torch.manual_seed(0); torch.cuda.manual_seed(0)
+        with torch.no_grad():
+            MA.manipulator(None, None, mc, mf, ori, tars[:T], args)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                rgb, ins, _, _ = MA.manipulator(None, None, mc, mf, ori, tars[:T], args)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        samples = (1 + T) * (2 * S_COARSE + N_IMP) + 2 * T * (S_COARSE + N_IMP + N_IMP * T)   # network evaluations per ray
+        mac = mac_counts(INS_NUM)["fwd"]
+        out[f"T{T}"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "network_samples_per_ray": samples,
+                        "tflops": 2.0 * mac * samples * N_RAYS / dt / 1e12, "frac_of_f32_mfma_peak": 2.0 * mac * samples * N_RAYS / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all())}
+    out["note"] = ("manipulator() on one 4096-ray chunk, 64 + 128 samples, T moved objects (default f32 kernels); network_samples_per_ray = "
+                   "(1+T)(64+192) + 2T(192+128T) -- the reference re-evaluates the original rays once per target (:190-193); frac = whole call (incl. resampling, exchanger, composites) against the f32 MFMA roof")
+    return out
 
 
 def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
@@ -385,7 +506,7 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
 
 
 def main():
-    global INS_NUM, MAC_PER_SAMPLE
+    global INS_NUM, MAC_PER_SAMPLE, HAVE_F16X2
     a = parse()
     INS_NUM = a.ins_num
     MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)
@@ -411,19 +532,21 @@ def main():
 
     from dm_nerf_amd import _lib, distributed as D
     from dm_nerf_amd.networks import helpers as H, render as R
+    HAVE_F16X2 = "dmnerf_mlp_fwd_rays_f16" in _lib.SIGNATURES
     from dm_nerf_amd.synthetic import dmsr_intrinsics, pose_spherical
 
     pe, ve, mc, mf = build_models(dev)
     K = dmsr_intrinsics(H_IMG, W_IMG)
     c2w = pose_spherical(30.0, -65.0, 7.0)
-    # rank r owns a contiguous band of rows of the frame and generates its own rays (no scatter)
-    rows = H_IMG // world
-    ro, rd = H.get_rays_k(H_IMG, W_IMG, K, c2w.to(dev), row0=rank * rows, nrows=rows)
-    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    # rank r owns a contiguous band of rows of the frame and generates its own rays (no scatter): the product's frame driver
+    # (distributed.FrameRenderer = the body of render_frame) renders it chunk by chunk into ONE packed band buffer and
+    # all-gathers that buffer once per frame; a "step" is one chunk of it
     n_step = N_RAYS // world if strong else N_RAYS             # rays THIS rank renders per step
-    n_chunks = ro.shape[0] // n_step
-    z = H.z_val_sample(n_step, NEAR, FAR, S_COARSE, device=dev)
     args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None)
+    fr = D.FrameRenderer(H_IMG, W_IMG, K, c2w.to(dev), (mc, mf), NEAR, FAR, args, chunk=n_step, n_samples=S_COARSE)
+    ro, rd = fr.rays_o, fr.rays_d
+    n_chunks = ro.shape[0] // n_step                           # whole chunks of the band (a ragged tail chunk is not a bench step)
+    z = fr.z_full
     mc.blob(); mf.blob()                                        # packed weights resident
     # setup, not a step: load the code objects (a 32-ray render) and create the RCCL communicator (one scalar all-reduce),
     # so that --warmup 0 still times K steady-state steps
@@ -433,25 +556,19 @@ def main():
         dist.all_reduce(torch.zeros(1, device=dev))
     torch.cuda.synchronize()
     flush_c_stdio()
-    # the rank's band of the frame, filled chunk by chunk: rgb | ins | depth per ray; all-gathered ONCE PER FRAME
-    band = torch.empty(n_chunks * n_step, 3 + INS_NUM + 1, device=dev) if world > 1 else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     gathers = [0]
 
     def gather_frame():
         gathers[0] += 1
-        return D.all_gather_cat(band)
+        return fr.gather()
 
     def step(i, events=None):
         c = i % n_chunks
-        rays = torch.stack([ro[c * n_step:(c + 1) * n_step], rd[c * n_step:(c + 1) * n_step]])
-        out = R.dm_nerf(rays, pe, ve, mc, mf, z, args, _events=events)
-        if world > 1:
-            t = band[c * n_step:(c + 1) * n_step]
-            t[:, :3] = out['rgb_fine']; t[:, 3:3 + INS_NUM] = out['ins_fine']; t[:, -1] = out['depth_fine']
-            if c == n_chunks - 1:                               # the band is complete: one all-gather per frame
-                gather_frame()
-        return out
+        rgb, ins, depth = fr.step(c, events=events)
+        if world > 1 and c == n_chunks - 1:                     # the band is complete: one all-gather per frame
+            gather_frame()
+        return rgb, ins
 
     def barrier():
         if world > 1:
@@ -465,7 +582,7 @@ def main():
         gathers[0] = 0
         t0 = time.perf_counter()
         for i in range(a.steps):
-            out = step(i, ev[i])
+            out_rgb, out_ins = step(i, ev[i])
         if world > 1 and a.steps > 0 and gathers[0] == 0:
             gather_frame()                                      # fewer steps than a band has chunks: the frame's gather is still timed
         barrier()
@@ -489,6 +606,15 @@ def main():
             train_multi = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
+        if world == 1:
+            # the full 10-key dict of the chunk the timed loop rendered last (the frame driver keeps rgb / ins / depth only):
+            # the same call, untimed -- what the CPU comparison and the opt-in legs are checked against
+            c_last = 0 if a.steps == 0 else (a.steps - 1) % n_chunks
+            with torch.no_grad():
+                out = R.dm_nerf(torch.stack([ro[c_last * N_RAYS:(c_last + 1) * N_RAYS], rd[c_last * N_RAYS:(c_last + 1) * N_RAYS]]), pe, ve, mc, mf, z, args)
+            torch.cuda.synchronize()
+            if a.steps:
+                assert torch.equal(out['rgb_fine'], out_rgb), "frame driver and dm_nerf disagree on the same chunk"
         # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
         k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else float("nan")
         flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * n_step
@@ -520,9 +646,16 @@ def main():
             res["speedup_vs_cpu"] = rays_per_s / base["value"]
         if world == 1 and not a.no_extras:
             res["frame"] = frame_leg(mc, mf, K, c2w, dev)
-            res["render_fused_heads"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'])
-            res["render_split_bf16"] = fused_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], split=True)
+            res["render_fused_heads"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], fuse_heads=True)
+            res["render_split_bf16"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split=True)
             res["frame_split_bf16"] = frame_leg(mc, mf, K, c2w, dev, mfma_split=True)
+            if HAVE_F16X2:
+                res["render_split_f16x2"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
+                res["frame_split_f16x2"] = frame_leg(mc, mf, K, c2w, dev, mfma_split="f16x2")
+            res["manipulator"] = manipulator_leg(mc, mf, K, dev)
+            if INS_NUM != 59:                           # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
+                pe9, ve9, mc9, mf9 = build_models(dev, 59)
+                res["render_ins59"] = render_leg(pe9, ve9, mc9, mf9, ro, rd, z, a.steps, ins_num=59)
         if world == 1 and not a.no_train:
             tb = None
             if not a.no_cpu_baseline:                   # (before the GPU leg: it updates the weights in place)
@@ -533,18 +666,20 @@ def main():
                 res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
             if not a.no_extras:
                 res["train_loop"] = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
+                res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS)
+                if INS_NUM != 59:
+                    t9 = train_leg(mc9, mf9, ro, rd, z, a.train_steps, dev, ins_num=59)
+                    res["train_ins59"] = {k: t9[k] for k in ("rays_per_s", "ms_per_step", "tflops", "frac_of_mfma_peak", "roofline", "ins_num")}
                 tf = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, fuse_heads=True)
-                res["train_fused_heads"] = {"rays_per_s": tf["rays_per_s"], "ms_per_step": tf["ms_per_step"],
-                                            "forward_kernel_ms": next((k["kernel_ms"] for k in (tf["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_fwd")), None),
+                res["train_fused_heads"] = {"rays_per_s": tf["rays_per_s"], "ms_per_step": tf["ms_per_step"], "roofline": tf["roofline"],
                                             "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
-                ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=True)
-                res["train_split_bf16"] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
-                                           "forward_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_split")), None),
-                                           "dgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("mlp_bwd")), None),
-                                           "wgrad_kernel_ms": next((k["kernel_ms"] for k in (ts["roofline"] or {}).get("all", []) if k["kernel"].startswith("wgrad")), None),
-                                           "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the split-bf16 MFMA kernels (f32-class values: six bf16 products per f32 product, f32 accumulation); not part of `train`"}
-                tl = train_loop_leg(mc, mf, dev, a.train_steps, mfma_split=True)
-                res["train_split_bf16"]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
+                for key, mode in (("train_split_bf16", True),) + ((("train_split_f16x2", "f16x2"),) if HAVE_F16X2 else ()):
+                    ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=mode)
+                    res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"], "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
+                                "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the split-operand 16-bit MFMA kernels "
+                                        f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
+                    tl = train_loop_leg(mc, mf, dev, a.train_steps, mfma_split=mode)
+                    res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
         if train_multi is not None:
             res["train"] = train_multi
     if world > 1:

@@ -4,8 +4,8 @@ Rays are independent units, so the path shards with no data-path collective (SUR
 
 * render (reference: the serial chunk loop of ``render_test``, networks/tester.py:55-85): rank r owns
   a contiguous band of image rows, generates its own rays (no scatter), renders them in chunks,
-  and ONE all-gather per frame assembles ``rgb [H,W,3]``, ``ins [H,W,ins_num]``, ``depth [H,W]``
-  (replaces the O(chunks^2) ``torch.cat`` accumulation, tester.py:73-77).
+  and ONE all-gather per frame of one packed band buffer assembles ``rgb [H,W,3]``, ``ins [H,W,ins_num]``,
+  ``depth [H,W]`` (``FrameRenderer``; replaces the O(chunks^2) ``torch.cat`` accumulation, tester.py:73-77).
 * training: every rank renders a slice of the same ray batch; ``allreduce_grads`` sums the gradients
   of both models in one flat 5.57 MB bucket per step (after ``total_loss.backward()``,
   train_dmsr.py:63); ``all_gather_cat`` exchanges the small per-ray outputs that batch-global
@@ -239,56 +239,114 @@ def _default_raygen(H, W, K, c2w, row0, nrows):
     return helpers.get_rays_k(H, W, K, c2w, row0=row0, nrows=nrows)
 
 
-def _default_render_chunk(rays_o, rays_d, z, models, args):
+def _default_render_chunk(rays_o, rays_d, z, models, args, events=None):
     from .networks import render
-    out = render.dm_nerf(torch.stack([rays_o, rays_d]), None, None, models[0], models[1], z, args)
+    out = render.dm_nerf(torch.stack([rays_o, rays_d]), None, None, models[0], models[1], z, args, _events=events)
     return out['rgb_fine'], out['ins_fine'], out['depth_fine']
+
+
+_compact_index_cache = {}
+
+
+def _compact_index(sizes, mx, device):
+    """Row index that drops the padding of a gathered ``[world * mx, ...]`` tensor whose rank r contributed ``sizes[r]`` rows."""
+    key = (tuple(sizes), mx, str(device))
+    if key not in _compact_index_cache:
+        _compact_index_cache[key] = torch.cat([torch.arange(r * mx, r * mx + n) for r, n in enumerate(sizes)]).to(device)
+    return _compact_index_cache[key]
+
+
+class FrameRenderer:
+    """One pose, rows sharded over the ranks: the per-pose body of ``render_test`` (networks/tester.py:58-85) as a resumable
+    object -- ``step(i)`` renders chunk i of this rank's band into ONE packed band buffer
+    ``[band rays, 3 + ins_num + 1]`` (rgb | ins | depth; ``labels_only``: ``[band rays, 6]`` = rgb | label | conf | depth, the
+    label stored as an exactly representable float), ``gather()`` assembles the frame with ONE all-gather of that buffer.
+    The buffer is allocated at the largest band's size, so ranks whose band is one row shorter (H not divisible by the world
+    size) gather without a padding copy and the padding rows are dropped by one indexed row copy after the collective.
+    ``render_frame`` is ``step`` over all chunks + ``gather``; bench.py drives the same object chunk by chunk."""
+
+    def __init__(self, H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64,
+                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None):
+        self.rank, self.world = world_info()
+        self.H, self.W, self.models, self.args, self.chunk = int(H), int(W), models, args, int(chunk)
+        self.labels_only = bool(labels_only)
+        self.render_chunk = render_chunk or _default_render_chunk
+        self._pass_events = render_chunk is None
+        if z_fn is None:
+            from .networks import helpers
+            z_fn = lambda n, dev: helpers.z_val_sample(n, near, far, n_samples, device=dev)
+        self.z_fn = z_fn
+        if self.labels_only and label_conf is None:
+            from .networks import evaluator
+            label_conf = evaluator.ins_label_conf
+        self.label_conf = label_conf
+        row0, nrows = row_band(H, self.rank, self.world)
+        ro, rd = (raygen or _default_raygen)(H, W, K, c2w, row0, nrows)
+        self.rays_o, self.rays_d = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        self.n_local = self.rays_o.shape[0]
+        self.sizes = [row_band(H, r, self.world)[1] * self.W for r in range(self.world)]
+        self.dev = self.rays_o.device
+        self.n_chunks = -(-self.n_local // self.chunk)
+        self.z_full = self.z_fn(min(self.chunk, max(self.n_local, 1)), self.dev) if self.n_local else None
+        self.band = None                                           # allocated by the first chunk (its dtype / ins width)
+
+    def step(self, i, events=None):
+        """Render chunk ``i`` (0 .. n_chunks - 1; the last one may be ragged, tester.py:65-67) into the band."""
+        s = i * self.chunk
+        e = min(s + self.chunk, self.n_local)
+        z = self.z_full if e - s == self.z_full.shape[0] else self.z_fn(e - s, self.dev)
+        if self._pass_events:
+            c_rgb, c_ins, c_depth = self.render_chunk(self.rays_o[s:e], self.rays_d[s:e], z, self.models, self.args, events=events)
+        else:
+            c_rgb, c_ins, c_depth = self.render_chunk(self.rays_o[s:e], self.rays_d[s:e], z, self.models, self.args)
+        if self.band is None:
+            self.n_ins = c_ins.shape[-1]
+            cols = 6 if self.labels_only else 3 + self.n_ins + 1
+            self.band = torch.empty(max(self.sizes), cols, dtype=c_rgb.dtype, device=self.dev)
+        t = self.band[s:e]
+        t[:, :3] = c_rgb
+        if self.labels_only:
+            label, conf = self.label_conf(c_ins)
+            t[:, 3] = label.to(t.dtype)                            # (< 2^24: exact)
+            t[:, 4] = conf
+        else:
+            t[:, 3:3 + self.n_ins] = c_ins
+        t[:, -1] = c_depth
+        return c_rgb, c_ins, c_depth
+
+    def gather(self):
+        """ONE all-gather of the packed band -> the frame's tensors on every rank."""
+        H, W = self.H, self.W
+        if self.band is None:                                      # a frame with no rays on this rank cannot size the band
+            raise RuntimeError("FrameRenderer.gather() before any chunk was rendered")
+        if self.world == 1:
+            full = self.band
+        else:
+            full = all_gather_cat(self.band)
+            if len(set(self.sizes)) != 1:
+                full = full.index_select(0, _compact_index(self.sizes, max(self.sizes), self.dev))
+        rgb, depth = full[:, :3].reshape(H, W, 3), full[:, -1].reshape(H, W)
+        if self.labels_only:
+            return rgb, full[:, 3].to(torch.int64).reshape(H, W), full[:, 4].reshape(H, W), depth
+        return rgb, full[:, 3:3 + self.n_ins].reshape(H, W, -1), depth
 
 
 def render_frame(H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64,
                  raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None):
-    """Full-frame render, rows sharded over ranks, one all-gather per output.
+    """Full-frame render, rows sharded over ranks, ONE all-gather per frame (``FrameRenderer``).
 
     Mirrors the per-pose body of ``render_test`` (networks/tester.py:58-85): same chunking
     (``chunk`` = N_test rays, ragged last chunk), ``args.perturb`` is the caller's business
     (test scripts set it False, test_dmsr.py:86).  Returns ``rgb [H,W,3]``, ``ins [H,W,ins_num]``,
-    ``depth [H,W]`` on every rank.  ``labels_only=True``: the object map is reduced on the device to what ``ins_eval``
-    consumes (evaluator.py:127-137) -- ``label [H,W]`` int64 = argmax, ``conf [H,W]`` = max -- before the gather, and
-    ``(rgb, label, conf, depth)`` is returned: 12 instead of 4*ins_num bytes per pixel cross the links.
+    ``depth [H,W]`` on every rank (views of the one gathered buffer).  ``labels_only=True``: the object map is reduced on the
+    device to what ``ins_eval`` consumes (evaluator.py:127-137) -- ``label [H,W]`` int64 = argmax, ``conf [H,W]`` = max --
+    before the gather, and ``(rgb, label, conf, depth)`` is returned: 24 instead of 16 + 4*ins_num bytes per pixel cross the links.
     """
-    rank, world = world_info()
-    raygen = raygen or _default_raygen
-    render_chunk = render_chunk or _default_render_chunk
-    if z_fn is None:
-        from .networks import helpers
-        z_fn = lambda n, dev: helpers.z_val_sample(n, near, far, n_samples, device=dev)
-    row0, nrows = row_band(H, rank, world)
-    rays_o, rays_d = raygen(H, W, K, c2w, row0, nrows)
-    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
-    n_local = rays_o.shape[0]
-    dev = rays_o.device
-    rgb = ins = depth = None
-    z_full = z_fn(chunk, dev)
-    for s in range(0, n_local, chunk):
-        e = min(s + chunk, n_local)
-        z = z_full if e - s == chunk else z_fn(e - s, dev)       # ragged last chunk (tester.py:65-67)
-        c_rgb, c_ins, c_depth = render_chunk(rays_o[s:e], rays_d[s:e], z, models, args)
-        if rgb is None:                                          # preallocated band buffers, no repeated cat
-            rgb = torch.empty(n_local, 3, dtype=c_rgb.dtype, device=dev)
-            ins = torch.empty(n_local, c_ins.shape[-1], dtype=c_ins.dtype, device=dev)
-            depth = torch.empty(n_local, dtype=c_depth.dtype, device=dev)
-        rgb[s:e], ins[s:e], depth[s:e] = c_rgb, c_ins, c_depth
-    sizes = [row_band(H, r, world)[1] * W for r in range(world)]
-    if labels_only:
-        if label_conf is None:
-            from .networks import evaluator
-            label_conf = evaluator.ins_label_conf
-        label, conf = label_conf(ins)
-        rgb, depth = all_gather_cat(rgb, sizes), all_gather_cat(depth, sizes)
-        label, conf = all_gather_cat(label, sizes), all_gather_cat(conf, sizes)
-        return rgb.reshape(H, W, 3), label.reshape(H, W), conf.reshape(H, W), depth.reshape(H, W)
-    rgb, ins, depth = all_gather_cat(rgb, sizes), all_gather_cat(ins, sizes), all_gather_cat(depth, sizes)
-    return rgb.reshape(H, W, 3), ins.reshape(H, W, -1), depth.reshape(H, W)
+    fr = FrameRenderer(H, W, K, c2w, models, near, far, args, chunk=chunk, n_samples=n_samples, raygen=raygen,
+                       render_chunk=render_chunk, z_fn=z_fn, labels_only=labels_only, label_conf=label_conf)
+    for i in range(fr.n_chunks):
+        fr.step(i)
+    return fr.gather()
 
 
 def render_path(render_poses, hwk, models, args, gt_imgs=None, crop_mask=None, labels_only=False, **frame_kw):

@@ -45,10 +45,11 @@ def _z_fn(n, dev):
     return O.z_val_sample(n, 4.0, 15.0, 16).contiguous()
 
 
-def _frame():
+def _frame(h=H, labels_only=False):
     K, c2w, sd_c, sd_f = _scene()
-    return D.render_frame(H, W, K, c2w, (sd_c, sd_f), 4.0, 15.0, None, chunk=CHUNK, n_samples=16,
-                          raygen=_raygen, render_chunk=_render_chunk, z_fn=_z_fn)
+    kw = dict(labels_only=True, label_conf=lambda x: (x.argmax(-1), x.max(-1).values)) if labels_only else {}
+    return D.render_frame(h, W, K, c2w, (sd_c, sd_f), 4.0, 15.0, None, chunk=CHUNK, n_samples=16,
+                          raygen=_raygen, render_chunk=_render_chunk, z_fn=_z_fn, **kw)
 
 
 def _worker(rank, world, port, q):
@@ -56,7 +57,16 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        calls = []
+        real_gather = dist.all_gather
+        dist.all_gather = lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1]
         rgb, ins, depth = _frame()
+        n_coll = len(calls)                                  # ONE collective per frame: the packed band
+        # bands of unequal height (7 rows over 2 ranks = 4 + 3): padded gather + one indexed row copy; labels_only packing
+        odd = _frame(7)
+        odd_lab = _frame(7, labels_only=True)
+        n_coll_odd = len(calls) - n_coll
+        dist.all_gather = real_gather
         # gradient bucket all-reduce: rank r contributes (r+1) * ones
         lin = [torch.nn.Linear(3, 2), torch.nn.Linear(2, 1)]
         for m in lin:
@@ -89,7 +99,8 @@ def _worker(rank, world, port, q):
         # uneven all_gather_cat
         t = torch.arange(rank + 2, dtype=torch.float32)[:, None] + 10 * rank
         cat = D.all_gather_cat(t, sizes=[2, 3])
-        q.put((rank, rgb.numpy(), ins.numpy(), depth.numpy(), g_ok, nbytes, cat.numpy()))
+        q.put((rank, rgb.numpy(), ins.numpy(), depth.numpy(), g_ok, nbytes, cat.numpy(), n_coll, n_coll_odd,
+               [t.numpy() for t in odd], [t.numpy() for t in odd_lab]))
     finally:
         dist.destroy_process_group()
 
@@ -152,9 +163,14 @@ def test_two_rank_sharded_frame_equals_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, rgb, ins, depth, g_ok, nbytes, cat in res:
+    odd1 = [t.numpy() for t in _frame(7)]
+    lab1 = [t.numpy() for t in _frame(7, labels_only=True)]
+    for rank, rgb, ins, depth, g_ok, nbytes, cat, n_coll, n_coll_odd, odd, odd_lab in res:
         # rays are independent: sharding must not change a single bit
         assert np.array_equal(rgb, single[0]) and np.array_equal(ins, single[1]) and np.array_equal(depth, single[2])
+        assert n_coll == 1 and n_coll_odd == 2                         # one all-gather per frame, whatever the band heights
+        assert all(np.array_equal(a, b) for a, b in zip(odd, odd1))
+        assert all(np.array_equal(a, b) for a, b in zip(odd_lab, lab1)) and odd_lab[1].dtype == np.int64
         assert g_ok and nbytes == (3 * 2 + 2 + 2 + 1) * 4
         assert np.array_equal(cat[:, 0], np.array([0, 1, 10, 11, 12], dtype=np.float32))
 
