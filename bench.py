@@ -140,8 +140,8 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     all-gathered rgb / ins, penalizer sums and the 5.57 MB gradient arena all-reduced in place over RCCL; ``ro`` / ``rd``
     must then hold the same rays on every rank.  Also returns the per-kernel roofline of the three MFMA kernels of the
     fine-network pass, timed with HIP events on their stream (autograd.KERNEL_EVENTS): ``frac`` divides the MACs the kernel
-    EXECUTES (mac_counts) by the peak of the MFMA type it runs on; ``algorithmic_frac`` divides the reference's FLOP count of
-    the stage -- it exceeds ``frac`` where the head re-association removed work."""
+    EXECUTES (mac_counts) by the peak of the MFMA type it runs on; ``algorithmic_tflops`` is the reference's FLOP count of
+    the stage over the same time -- larger than ``achieved`` where the head re-association removed work."""
     from dm_nerf_amd import autograd as G, distributed as D
     ins_num = INS_NUM if ins_num is None else ins_num
     mc.train(); mf.train()
@@ -208,20 +208,21 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
             tf_ref = 2.0 * ref_mac[tag] * m_fine / (k_ms * 1e-3) / 1e12
             kernels.append({"kernel": names[tag], "launches": len(ms), "kernel_ms": k_ms, "mac_per_sample_executed": exec_mac[tag],
                             "mfma_products_per_mac": products, "achieved": tf, "peak": peak, "frac": tf / peak,
-                            "algorithmic_tflops": tf_ref, "algorithmic_frac": tf_ref / F32_MFMA_PEAK_TFLOPS})
+                            "algorithmic_tflops": tf_ref})
     worst = min(kernels, key=lambda k: k["frac"]) if kernels else None
     flop_exec = 2.0 * (fwd_exec + mac["dgrad"] + mac["wgrad"]) * products * (2 * S_COARSE + N_IMP) * n
     return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop_exec / dt / 1e12, "tflops_reference_flops": flop_ref / dt / 1e12,
-            "frac_of_mfma_peak": {"executed": flop_exec / dt / 1e12 / (peak * world), "reference_flops": flop_ref / dt / 1e12 / (F32_MFMA_PEAK_TFLOPS * world),
-                                  "peak": peak, "note": "whole step incl. losses, compositing, Adam; executed = MFMA work the three MLP kernels issue "
-                                                        "(mac_counts), reference_flops = SURVEY 8(d)'s 1013 MFLOP/ray against the f32 MFMA peak"},
+            "frac_of_mfma_peak": {"executed": flop_exec / dt / 1e12 / (peak * world), "peak": peak,
+                                  "note": "whole step incl. losses, compositing, Adam, on the MFMA work the three MLP kernels issue (mac_counts); "
+                                          "`tflops_reference_flops` = the same time against SURVEY 8(d)'s 1013 MFLOP/ray (the head re-association removed work, "
+                                          "so it is not a fraction of any roof)"},
             "final_loss": float(loss.detach()),
             "batch_rays": n, "ins_num": ins_num,
             "roofline": None if worst is None else {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "kernel": worst["kernel"],
                                                     "kernel_ms": worst["kernel_ms"], "achieved": worst["achieved"], "frac": worst["frac"],
                                                     "samples_per_launch": m_fine, "all": kernels,
                                                     "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; `kernel` = the one furthest below "
-                                                            "the roof on EXECUTED MACs; algorithmic_* = the reference's FLOP count of the stage over the same time"},
+                                                            "the roof on EXECUTED MACs; algorithmic_tflops = the reference's FLOP count of the stage over the same time"},
             "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"
                     + (f"; one batch sharded over {world} ranks (sharded_train_step)" if world > 1 else "")}
 
