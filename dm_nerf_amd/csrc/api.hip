@@ -64,7 +64,7 @@ extern "C" int dmnerf_render_rays_fwd(const dmnerf_render_args* a, void* stream)
             return dmn_check_launch("render_rays_fwd: z copy");
     }
     // coarse network + compositing (render.py:49-63)
-    auto mlp = a->fused_heads == 2 ? dmnerf_mlp_fwd_rays_split : (a->fused_heads ? dmnerf_mlp_fwd_rays_fused : dmnerf_mlp_fwd_rays);
+    auto mlp = a->fused_heads == 3 ? dmnerf_mlp_fwd_rays_f16 : a->fused_heads == 2 ? dmnerf_mlp_fwd_rays_split : (a->fused_heads ? dmnerf_mlp_fwd_rays_fused : dmnerf_mlp_fwd_rays);
     if ((rc = mlp(a->d_blob_coarse, a->ins_num, a->d_rays_o, a->d_rays_d, a->d_z_coarse, N, S, a->d_raw_coarse, stream))) return rc;
     if ((rc = dmnerf_composite_fwd(a->d_raw_coarse, a->d_z_coarse, a->d_rays_d, N, S, C, a->d_rgb_coarse, a->d_weights_ws,
                                    a->d_depth_coarse, a->d_ins_coarse, stream))) return rc;

@@ -180,6 +180,40 @@ DMN_HD inline SplitTLayout make_split_layout_t(int ins_num) {
     return S;
 }
 
+// ---- split-f16 ("f16x2") blobs (opt-in; mlp_f16_impl.h, mlp_bwd_f16.hip) ------------------------------------------
+// Every f32 weight w is split into TWO f16 planes, hi = f16(w), lo = f16(w - hi) (round to nearest; the lo plane lives in
+// the f16 subnormal range for |w| < 2^-4, which v_mfma_f32_32x32x16_f16 honours: scripts/micro/mfma_f16.hip); a product is
+// w_hi x_hi + w_hi x_lo + w_lo x_hi -- three MFMAs.  The stream is a flat sequence of GROUPS of 16 KiB:
+//   group = 8 hi tiles | 8 lo tiles,  tile i <-> (k-block kb0 + i / nob, out-block ob0 + i % nob),  tile = 64 lanes x 8 f16:
+//   group[(plane * 8 + i) * 512 + lane * 8 + q] = plane(W[32 ob + (lane & 31)][col(8 kb + q, lane >> 5)])
+// consumed in order by a ring of F16_RING group slots in LDS, F16_LA groups ahead.  The kernels walk the network OUT-BLOCK-
+// OUTER: a "pass" accumulates nob out-blocks over ALL their k-blocks (nob = 2 in the trunk: 4 passes x 4 groups per 256 -> 256
+// layer), so that the ReLU + split epilogue of one pass rides in the MFMA gaps of the next.
+// Forward order (fused heads, weights.py::fuse_heads):
+//   mlps.0 (4 passes x 1 group, PE k-order) | mlps.1..4 | mlps.5 (per pass: 4 groups h + 1 group pts) | mlps.6 | mlps.7 |
+//   rgb hidden' (nob 4: 8 groups h + 1 group dirs) | ins hidden' (nob 4: 8 groups) | rgb_linear (nob 1: 1 group) |
+//   density (nob 1: 2 groups) | ins_linear (nob OBX: OBX groups)                                      = 140 + OBX groups
+// Table (f32, TAB_FLOATS): every bias in accumulator order (bias_floats), in the order the passes need them; the bias of
+// mlps.0 is a stream column instead (the pad slot of the position encoding, which the kernel feeds with 1.0).
+constexpr int F16_GROUP_WORDS = 4096;            // 16 KiB
+constexpr int F16_RING = 8;                      // LDS ring: 8 group slots = 128 KiB
+constexpr int F16_LA = 6;                        // groups fetched ahead of the one being consumed
+constexpr int F16_TAB_RGBH = 8 * 256, F16_TAB_INSH = F16_TAB_RGBH + 128, F16_TAB_DEN = F16_TAB_INSH + 128,
+              F16_TAB_RGBO = F16_TAB_DEN + 32, F16_TAB_INSO = F16_TAB_RGBO + 32;            // + 32 OBX <= 2496 <= TAB_FLOATS
+struct F16Layout {
+    int C, OBI, OBX;
+    int n_groups;                 // groups of the forward stream
+    int64_t stream, total;        // word offsets: stream start (= TAB_FLOATS), total words incl. F16_LA landing groups
+};
+DMN_HD inline F16Layout make_f16_layout(int ins_num) {
+    F16Layout S{};
+    S.C = ins_num + 1; S.OBI = (S.C + 31) / 32; S.OBX = split_ob_ins(S.OBI);
+    S.n_groups = 4 + 4 * 16 + 20 + 2 * 16 + 9 + 8 + 2 + 1 + S.OBX;
+    S.stream = TAB_FLOATS;
+    S.total = S.stream + (int64_t)(S.n_groups + F16_LA) * F16_GROUP_WORDS;
+    return S;
+}
+
 // Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
 //   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
 //

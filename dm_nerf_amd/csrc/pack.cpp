@@ -187,6 +187,72 @@ extern "C" int dmnerf_build_pack_index_t_split(int ins_num, int32_t* idx, int64_
     return DMNERF_OK;
 }
 
+// ---- split-f16 blob (layout.h::F16Layout): table index (one int32 per float) + stream index (one int32 per f16 element =
+// source parameter | plane << 28, or -1), groups in the order mlp_f16_impl.h consumes them
+namespace {
+struct F16Group { const Lin* l; int nob, ob0, kb0; KMap km; int col_off; bool bias_pad; };   // bias_pad: the PE pad slot's column holds the bias
+
+void f16_forward_groups(const Params& P, int obx, std::vector<F16Group>& g) {
+    for (int p = 0; p < 4; ++p) g.push_back({&P.mlps[0], 2, 2 * p, 0, K_POS, 0, true});     // (the kernel feeds 1.0 in the pad slot)
+    for (int l = 1; l < 8; ++l)
+        for (int p = 0; p < 4; ++p) {
+            for (int q = 0; q < 4; ++q) g.push_back({&P.mlps[l], 2, 2 * p, 4 * q, K_ACC, 0, false});
+            if (l == 5) g.push_back({&P.mlps[5], 2, 2 * p, 0, K_POS, W, false});           // skip concat [h, pts] (dm_nerf.py:87)
+        }
+    for (int q = 0; q < 8; ++q) g.push_back({&P.rgb_hidden, 4, 0, 2 * q, K_ACC, 0, false});  // (fused with rgb_feature_linear by the caller)
+    g.push_back({&P.rgb_hidden, 4, 0, 0, K_DIR, W, false});                                // cat[rgb_feature, dirs] (dm_nerf.py:90)
+    for (int q = 0; q < 8; ++q) g.push_back({&P.ins_hidden, 4, 0, 2 * q, K_ACC, 0, false});  // (fused with ins_feature_linear)
+    g.push_back({&P.rgb_out, 1, 0, 0, K_ACC, 0, false});
+    for (int q = 0; q < 2; ++q) g.push_back({&P.density, 1, 0, 8 * q, K_ACC, 0, false});
+    for (int q = 0; q < obx; ++q) g.push_back({&P.ins_out, obx, 0, q * (8 / obx), K_ACC, 0, false});
+}
+
+void fill_f16_groups(int32_t* idx, const std::vector<F16Group>& groups) {
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const F16Group& G = groups[gi];
+        for (int plane = 0; plane < 2; ++plane)
+            for (int i = 0; i < 8; ++i) {
+                const int kb = G.kb0 + i / G.nob, ob = G.ob0 + i % G.nob;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 8; ++q) {
+                        const int col = kcol(G.km, 8 * kb + q, lane >> 5);
+                        int64_t src = col < 0 ? -1 : G.l->w(ob * 32 + (lane & 31), col + G.col_off);
+                        if (G.bias_pad && 8 * kb + q == 1 && (lane >> 5) == 1) src = G.l->b(ob * 32 + (lane & 31));
+                        idx[((int64_t)gi * 16 + plane * 8 + i) * 512 + lane * 8 + q] = src < 0 ? -1 : (int32_t)(src | ((int64_t)plane << 28));
+                    }
+            }
+    }
+}
+}  // namespace
+
+extern "C" int64_t dmnerf_blob_f16_words(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_f16_layout(ins_num).total;
+}
+
+// idx_tab [TAB_FLOATS]: float gather for the bias table; idx_stream [(total - TAB_FLOATS) * 2]: the f16 elements
+extern "C" int dmnerf_build_pack_index_f16(int ins_num, int32_t* idx_tab, int64_t n_tab, int32_t* idx_stream, int64_t n_stream) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "build_pack_index_f16: ins_num %d unsupported", ins_num);
+    const F16Layout S = make_f16_layout(ins_num);
+    const int64_t need = (S.total - S.stream) * 2;
+    if (!idx_tab || !idx_stream || n_tab != TAB_FLOATS || n_stream != need)
+        return dmn_fail(DMNERF_E_ARG, "build_pack_index_f16: need %d + %lld index slots, got %lld + %lld", TAB_FLOATS, (long long)need, (long long)n_tab, (long long)n_stream);
+    const Params P = make_params(ins_num);
+    for (int64_t i = 0; i < TAB_FLOATS; ++i) idx_tab[i] = -1;
+    for (int64_t i = 0; i < need; ++i) idx_stream[i] = -1;
+    for (int l = 1; l < 8; ++l) fill_bias(idx_tab, l * 256, P.mlps[l], 8);          // (mlps.0: its bias is a stream column; zeros here)
+    fill_bias(idx_tab, F16_TAB_RGBH, P.rgb_hidden, 4);
+    fill_bias(idx_tab, F16_TAB_INSH, P.ins_hidden, 4);
+    fill_bias(idx_tab, F16_TAB_DEN, P.density, 1);
+    fill_bias(idx_tab, F16_TAB_RGBO, P.rgb_out, 1);
+    fill_bias(idx_tab, F16_TAB_INSO, P.ins_out, S.OBX);
+    std::vector<F16Group> groups;
+    f16_forward_groups(P, S.OBX, groups);
+    if ((int)groups.size() != S.n_groups) return dmn_fail(DMNERF_E_ARG, "build_pack_index_f16: internal group count %d != %d", (int)groups.size(), S.n_groups);
+    fill_f16_groups(idx_stream, groups);
+    return DMNERF_OK;
+}
+
 extern "C" int64_t dmnerf_blob_t_floats(int ins_num) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
     return make_layout_t(ins_num).total;

@@ -3,7 +3,7 @@ import ctypes
 
 import torch
 
-from .. import _lib
+from .. import _lib, weights
 from . import helpers
 
 
@@ -129,11 +129,13 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     a = _lib.RenderArgs()
     # args.fuse_heads (extension, default off): inference with the activation-free feature linears folded into the
     # hidden layers (-19 % MACs; results equal up to f32 re-association)
-    # args.mfma_split (extension, default off): split-bf16 MFMA inference (f32-class accuracy, not bitwise the f32 chain)
+    # args.mfma_split (extension, default off): split-operand 16-bit MFMA inference (f32-class accuracy, not bitwise the f32
+    # chain): True / "bf16x3" = three bf16 planes, six products; "f16x2" = two f16 planes, three products
     fused = bool(getattr(args, "fuse_heads", False))
-    split = bool(getattr(args, "mfma_split", False))
-    a.fused_heads = 2 if split else (1 if fused else 0)
-    pick = (lambda mdl: mdl.blob_split()) if split else ((lambda mdl: mdl.blob_fused()) if fused else (lambda mdl: mdl.blob()))
+    split = weights.split_mode(args)
+    a.fused_heads = {"bf16x3": 2, "f16x2": 3}[split] if split else (1 if fused else 0)
+    pick = {"bf16x3": (lambda mdl: mdl.blob_split()), "f16x2": (lambda mdl: mdl.blob_f16())}[split] if split else \
+        ((lambda mdl: mdl.blob_fused()) if fused else (lambda mdl: mdl.blob()))
     a.d_blob_coarse = pick(model_coarse).data_ptr()
     a.d_blob_fine = pick(model_fine).data_ptr()
     a.ins_num = ins_num

@@ -110,6 +110,43 @@ def pack_blob_split(state, ins_num):
     return blob
 
 
+def split_mode(args):
+    """``args.mfma_split`` -> None (off) | "bf16x3" (True or "bf16x3": three bf16 planes, six products) | "f16x2" (two f16
+    planes, three products).  Both are f32-class, neither is the bitwise fmaf chain of the default kernels."""
+    m = getattr(args, "mfma_split", False)
+    if not m:
+        return None
+    if m is True or str(m) == "bf16x3":
+        return "bf16x3"
+    if str(m) == "f16x2":
+        return "f16x2"
+    raise ValueError(f"args.mfma_split = {m!r}: expected False, True / 'bf16x3' or 'f16x2'")
+
+
+def pack_blob_f16(state, ins_num):
+    """The opt-in split-f16 inference blob: [bias table f32 | two f16 planes of every (fused-heads) weight, 16 KiB groups]."""
+    lib = _lib.load()
+    flat = flat_params(state)
+    _lib.require_gpu(flat)
+    flat = fused_flat(flat, ins_num)
+    total = lib.dmnerf_blob_f16_words(ins_num)
+    if total <= 0:
+        raise ValueError(f"unsupported ins_num={ins_num}")
+    tab = 4096
+    key = (ins_num, str(flat.device), "f16")
+    if key not in _index_cache:
+        n = (total - tab) * 2
+        h_tab, h_str = np.empty(tab, dtype=np.int32), np.empty(n, dtype=np.int32)
+        _lib.check(lib.dmnerf_build_pack_index_f16(ins_num, h_tab.ctypes.data_as(ctypes.c_void_p), tab,
+                                                   h_str.ctypes.data_as(ctypes.c_void_p), n), "dmnerf_build_pack_index_f16")
+        _index_cache[key] = (torch.from_numpy(h_tab).to(flat.device), torch.from_numpy(h_str).to(flat.device))
+    idx_tab, idx = _index_cache[key]
+    blob = torch.empty(total, dtype=torch.float32, device=flat.device)
+    _lib.check(lib.dmnerf_pack_weights(_lib.ptr(flat), _lib.ptr(idx_tab), _lib.ptr(blob), tab, _lib.stream()), "dmnerf_pack_weights")
+    _lib.check(lib.dmnerf_pack_f16(_lib.ptr(flat), _lib.ptr(idx), _lib.ptr(blob[tab:]), total - tab, _lib.stream()), "dmnerf_pack_f16")
+    return blob
+
+
 HEAD_F_FLOATS = 128 * 256        # layout.h::HEAD_F_FLOATS
 TAB_T_FLOATS = 1024              # layout.h::TAB_T_FLOATS
 

@@ -250,6 +250,20 @@ int dmnerf_mlp_bwd_data_split(const float* d_blob_t_split, int ins_num, const fl
 int dmnerf_mlp_fwd_rays_split(const float* d_blob_split, int ins_num, const float* d_rays_o, const float* d_rays_d,
                               const float* d_z, int64_t N, int S, float* d_raw, void* stream);
 
+/* OPT-IN split-f16 ("f16x2") inference (args.mfma_split = "f16x2"): the same function as dmnerf_mlp_fwd_rays_fused
+ * (networks/dm_nerf.py:80-106 with the two activation-free feature linears folded in) on v_mfma_f32_32x32x16_f16 with every f32
+ * operand split into two f16 planes and THREE products per f32 product (csrc/mlp_f16_impl.h, split_f16.h): f32-class values
+ * (|d raw| <= 1e-5 (1 + |raw|), like the f32 kernels; not their bitwise chain), half the MFMAs of the bf16x3 mode; activations
+ * saturate at 65 504 (f16 range).  Blob: dmnerf_blob_f16_words 32-bit words = [4096-float bias table | stream of 16 KiB groups];
+ * dmnerf_build_pack_index_f16 fills the table's float gather index (h_idx_tab[4096], for dmnerf_pack_weights) and the stream's
+ * element index (h_idx_stream[(words - 4096) * 2]: source parameter | plane << 28, or -1), both addressing the FUSED flat
+ * parameter vector (dmnerf_fuse_heads); dmnerf_pack_f16 writes the stream words (n_words = dmnerf_blob_f16_words - 4096). */
+int64_t dmnerf_blob_f16_words(int ins_num);
+int dmnerf_build_pack_index_f16(int ins_num, int32_t* h_idx_tab, int64_t n_tab, int32_t* h_idx_stream, int64_t n_stream);
+int dmnerf_pack_f16(const float* d_flat, const int32_t* d_idx, float* d_stream_words, int64_t n_words, void* stream);
+int dmnerf_mlp_fwd_rays_f16(const float* d_blob_f16, int ins_num, const float* d_rays_o, const float* d_rays_d,
+                            const float* d_z, int64_t N, int S, float* d_raw, void* stream);
+
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
  * (int32, values 0..ins_num; other values are ignored) -> out4 = {ins_loss_sum, valid_ce, invalid_ce,
@@ -340,7 +354,7 @@ typedef struct {
      * kernel), so a caller can time it live without splitting the call; NULL = not recorded */
     void* ev_fine_mlp_begin;
     void* ev_fine_mlp_end;
-    /* 1: d_blob_coarse / d_blob_fine are fused-heads blobs (dmnerf_build_pack_index_fused); 2: split-bf16 blobs */
+    /* 1: d_blob_coarse / d_blob_fine are fused-heads blobs (dmnerf_build_pack_index_fused); 2: split-bf16 blobs; 3: split-f16 blobs */
     int fused_heads;
 } dmnerf_render_args;
 int dmnerf_render_rays_fwd(const dmnerf_render_args* args, void* stream);
