@@ -32,6 +32,11 @@ extern "C" int dmnerf_pack_f16(const float* d_flat, const int32_t* d_idx, float*
     return dmn_check_launch("pack_f16");
 }
 
+#ifdef DMN_F16_TRACE
+static long long* g_f16_trace = nullptr;
+extern "C" void dmnerf_f16_set_trace(long long* d_trace) { g_f16_trace = d_trace; }
+#endif
+
 extern "C" int dmnerf_mlp_fwd_rays_f16(const float* d_blob_f16, int ins_num, const float* d_rays_o, const float* d_rays_d,
                                        const float* d_z, int64_t N, int S, float* d_raw, void* stream) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_f16: ins_num %d unsupported", ins_num);
@@ -41,6 +46,9 @@ extern "C" int dmnerf_mlp_fwd_rays_f16(const float* d_blob_f16, int ins_num, con
     F16Args a{};
     a.blob = d_blob_f16; a.S = make_f16_layout(ins_num);
     a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z; a.raw = d_raw; a.M = N * S; a.Sr = S;
+#ifdef DMN_F16_TRACE
+    a.trace = g_f16_trace;
+#endif
     const int64_t nblk = (a.M + 31) / 32;
     const int64_t grid = (nblk + 3) / 4;
     if (grid > 0x7fffffffLL) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_f16: too many samples");

@@ -52,7 +52,15 @@ struct F16Args {
     float* save;            // SAVE: the training workspace of layout.h::SaveLayout
     int64_t M;
     int Sr;                 // samples per ray
+#ifdef DMN_F16_TRACE
+    long long* trace;       // diagnostic builds only (make f16var FLAGS=-DDMN_F16_TRACE): per-workgroup cycle stamps, scripts/diag_f16.py
+#endif
 };
+#ifdef DMN_F16_TRACE
+#define DMN_F16_STAMP(k) do { if (a.trace && threadIdx.x == 0) { a.trace[8 * blockIdx.x + (k)] = (long long)clock64(); if ((k) == 0 || (k) == 5) a.trace[8 * blockIdx.x + 6 + ((k) == 5)] = (long long)wall_clock64(); } } while (0)
+#else
+#define DMN_F16_STAMP(k) do {} while (0)
+#endif
 
 struct GStream {
     rsrc_t rs;
@@ -87,6 +95,9 @@ __device__ __forceinline__ void lds_read16_v(f32x4& v, unsigned addr) {
 
 // piece i (0..3) of group gidx + F16_LA: wave w fetches the 1 KiB pieces 4 i + w of its 16 KiB
 __device__ __forceinline__ void gs_fetch_piece(const GStream& ws, int slot_group, int i) {
+#ifdef DMN_F16_NODMA
+    return;                                                      // ablation (timing only): no weight traffic
+#endif
     float* dst = ws.ring + (slot_group & (F16_RING - 1)) * F16_GROUP_WORDS + ws.wave * 256 + i * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ws.rs, (DMN_LAS void*)dst, 16, (int)ws.voff, (int)(ws.off + i * 4096), 0, 0);
 }
@@ -97,39 +108,58 @@ struct NoSideC {
 };
 
 // The epilogue of a finished pass as side operations of the following one(s): bias + ReLU + split of NOBP accumulator blocks
-// (out-blocks OB0 ..) into the plane words of the next layer; NUM pairs at gap G0 + s STRIDE.  HASBIAS: bq holds the pass's
-// bias quads (read by the carrying pass's first group, complete by gap 24).
+// (out-blocks OB0 ..) into the plane words of the next layer.  A 32x32x16 MFMA hides ~5 single-issue instructions and every
+// gap already carries a tile read and its wait, so a pair's ~10 instructions are dealt out over THREE consecutive gaps:
+//   gap G0 + s STRIDE     : 2 v_accvgpr_read (the accumulators live in AGPRs, which the VALU cannot read) + 2 bias adds
+//   gap G0 + s STRIDE + 1 : 2 ReLUs + the hi word (v_cvt_pkrtz_f16_f32)
+//   gap G0 + s STRIDE + 2 : the 2 residuals (v_fma_mix_f32) + the lo word
+// for the NUM pairs s NUM .. s NUM + NUM - 1 (STRIDE >= 3).  HASBIAS: bq holds the pass's bias quads (read by the carrying
+// pass's first group, complete by gap 24).  (Measured: with a pair's instructions in ONE gap the trunk ran at 38.6 instead of
+// 32 cycles per MFMA, profiles/r03/diag_f16_r03d.txt.)
 template <int NOBP, int OB0, bool HASBIAS, bool RELU, int G0, int STRIDE, int NUM, int NWO, int NBQA>
 struct EpiSplit {
     f32x16 (&Y)[NOBP];
     f32x4 (&bq)[NBQA];
     unsigned (&Ohi)[NWO];
     unsigned (&Olo)[NWO];
+    float x0[NUM], x1[NUM];
     template <int GAP>
-    __device__ __forceinline__ void operator()(std::integral_constant<int, GAP>) const {
+    __device__ __forceinline__ void operator()(std::integral_constant<int, GAP>) {
         static_assert(!HASBIAS || G0 >= 24, "bias quads are complete from the second group on");
+        static_assert(STRIDE >= 3, "a pair takes three gaps");
         if constexpr (HASBIAS && GAP == G0) {
 #pragma unroll
             for (int q = 0; q < 4 * NOBP; ++q) asm volatile("" : "+v"(bq[q]));
         }
-        if constexpr (GAP >= G0 && (GAP - G0) % STRIDE == 0 && (GAP - G0) / STRIDE * NUM < 8 * NOBP) {
+        if constexpr (GAP >= G0 && (GAP - G0) % STRIDE < 3 && (GAP - G0) / STRIDE * NUM < 8 * NOBP) {
+            constexpr int ph = (GAP - G0) % STRIDE;
             static_for<NUM>([&](auto nc) {
-                constexpr int k = (GAP - G0) / STRIDE * NUM + decltype(nc)::value;
+                constexpr int n = decltype(nc)::value, k = (GAP - G0) / STRIDE * NUM + n;
                 if constexpr (k < 8 * NOBP) {
                     constexpr int b = k / 8, r = 2 * (k % 8);
-                    // the accumulators live in AGPRs (MFMA C / D) and the VALU cannot read those: read each element where it is
-                    // consumed (left to the register allocator, all 16 x NOBP copies land as one burst behind the pass)
-                    float x0, x1;
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(Y[b][r]));
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(Y[b][r + 1]));
-                    if constexpr (HASBIAS) {
-                        x0 += bq[b * 4 + (r >> 2)][r & 3];
-                        x1 += bq[b * 4 + ((r + 1) >> 2)][(r + 1) & 3];
-                    }
-                    if constexpr (RELU) { x0 = relu1(x0); x1 = relu1(x1); }
                     constexpr int w = (2 * (OB0 + b) + (r >> 3)) * 4 + ((r & 7) >> 1);
                     static_assert(w < NWO, "plane word");
-                    split_pair_f16(x0, x1, Ohi[w], Olo[w]);
+#ifdef DMN_F16_NOSIDE
+                    if (k > 0) return;                           // ablation (timing only): one pair per pass keeps the data flow alive
+#endif
+                    if constexpr (ph == 0) {
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0[n]) : "a"(Y[b][r]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1[n]) : "a"(Y[b][r + 1]));
+                        if constexpr (HASBIAS) {
+                            x0[n] += bq[b * 4 + (r >> 2)][r & 3];
+                            x1[n] += bq[b * 4 + ((r + 1) >> 2)][(r + 1) & 3];
+                        }
+                        asm volatile("" : "+v"(x0[n]), "+v"(x1[n]));    // the adds stay in this gap
+                    } else if constexpr (ph == 1) {
+                        if constexpr (RELU) { x0[n] = relu1(x0[n]); x1[n] = relu1(x1[n]); }
+                        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Ohi[w]) : "v"(x0[n]), "v"(x1[n]));
+                    } else {
+                        float r0, r1;
+                        asm volatile("v_fma_mix_f32 %0, -%2, 1.0, %3 op_sel_hi:[1,0,0]\n\t"
+                                     "v_fma_mix_f32 %1, -%2, 1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                                     : "=&v"(r0), "=&v"(r1) : "v"(Ohi[w]), "v"(x0[n]), "v"(x1[n]));
+                        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Olo[w]) : "v"(r0), "v"(r1));
+                    }
                 }
             });
         }
@@ -175,7 +205,9 @@ __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW]
         wait_lgkm<(NBQ > 15 ? 15 : NBQ)>();
         wait_vm<4 * (F16_LA - 2)>();
         asm volatile("" ::: "memory");
+#ifndef DMN_F16_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -231,6 +263,7 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
     const int64_t m = valid ? m_raw : a.M - 1;
     const int C = a.S.C;
 
+    DMN_F16_STAMP(0);
     float pt[3], vd[3];
     {
         const int64_t n = m / a.Sr;
@@ -285,6 +318,7 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
     ws.nxt = ws.lane16 + F16_GROUP_BYTES;
     static_for<8>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_read16_async<i * 1024>(ws.H[i], ws.cur); });
 
+    DMN_F16_STAMP(1);
     f32x16 acc0[2], acc1[2];                   // the two accumulator sets of the trunk passes (even / odd pass)
     unsigned PA[2][64], PB[2][64];             // the two plane sets: 256 features as (hi, lo) words of f16 pairs
     f32x4 bq[16];                              // bias quads of the pass being post-processed
@@ -292,15 +326,17 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
     // (whose table entries are zero: its bias sits in the stream) on
     unsigned baddr = lds_addr(tab) + half * 64 + 6 * 32 * 4;
 
-    // ---- mlps.0 : 63 -> 256, four passes of one group; the epilogue of pass p - 1 rides in pass p
+    // ---- mlps.0 : 63 -> 256, four passes of one group; the epilogue of pass p - 1 rides in pass p (from gap 3 on: its last MFMA
+    // must have retired before the asm accumulator reads, which the compiler's hazard recognizer does not see)
     f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiSplit<2, 0, false, true, 2, 1, 1, 64, 16>{acc0, bq, PA[0], PA[1]});
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, EpiSplit<2, 2, false, true, 2, 1, 1, 64, 16>{acc1, bq, PA[0], PA[1]});
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiSplit<2, 4, false, true, 2, 1, 1, 64, 16>{acc0, bq, PA[0], PA[1]});
+    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiSplit<2, 0, false, true, 3, 3, 3, 64, 16>{acc0, bq, PA[0], PA[1]});
+    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, EpiSplit<2, 2, false, true, 3, 3, 3, 64, 16>{acc1, bq, PA[0], PA[1]});
+    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiSplit<2, 4, false, true, 3, 3, 3, 64, 16>{acc0, bq, PA[0], PA[1]});
 
+    DMN_F16_STAMP(2);
     // ---- mlps.1 .. mlps.7: layer X reads A and writes B, layer Y reads B and writes A; pass p accumulates out-blocks 2p, 2p+1
     // in set p & 1 while the other set (pass p - 1, or the previous layer's pass 3) is post-processed into its plane words
-    auto layer = [&](unsigned (&Pin)[2][64], unsigned (&Pout)[2][64], bool pe_on) {
+    auto layer = [&](unsigned (&Pin)[2][64], unsigned (&Pout)[2][64], bool pe_on) __attribute__((always_inline)) {
         f16_pass<2, 4, 0, 8, 0, true>(ws, Pin[0], Pin[1], acc0, bq, baddr, EpiSplit<2, 6, true, true, 24, 3, 1, 64, 16>{acc1, bq, Pin[0], Pin[1]});
         baddr += 256;
         if (pe_on) f16_pass<2, 1, 0, 0, 96, false>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
@@ -330,6 +366,7 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
     layer(PA, PB, false);
 #endif
 
+    DMN_F16_STAMP(3);
     // ---- heads on h_7 = planes B (its last two out-blocks arrive under the first groups of the rgb hidden layer)
     f32x16 accR[4], accI[4], accO[1], accD[1], accL[OBX];
     unsigned G1[2][32], G2[2][32];
@@ -346,6 +383,7 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
     // ins_linear (:103)
     f16_pass<OBX, OBX, 0, 0, 0, true>(ws, G2[0], G2[1], accL, bq, baddr, NoSideC{});
 
+    DMN_F16_STAMP(4);
     // ---- outputs: cat[rgb, density, ins] (dm_nerf.py:105); biases of the three output layers from the table
     float* __restrict__ out_row = a.raw + m * (4 + C);
     if (valid) {
@@ -365,6 +403,7 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the last (landing-zone) fetches
+    DMN_F16_STAMP(5);
 }
 
 }  // namespace

@@ -546,10 +546,12 @@ def test_fused_heads_inference_matches_layerwise(A):
     assert float(((a['ins_fine'].argmax(-1) != b['ins_fine'].argmax(-1)).float().mean())) <= 1e-2
 
 
-def test_split_bf16_inference_is_f32_class(A):
-    """Opt-in split-bf16 MFMA path (three bf16 planes per operand, six products in f32): same tolerance as the f32
-    kernels, |d raw| <= 1e-5 (1 + |raw|) against the oracle, for 1, 2 and 3 logit blocks and a ragged batch."""
-    for ins_num, seed, N, S in ((13, 3, 37, 64), (59, 4, 9, 21), (93, 5, 6, 33)):
+@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+def test_split_bf16_inference_is_f32_class(A, split):
+    """Opt-in split-operand MFMA paths (bf16x3: three bf16 planes per operand, six products; f16x2: two f16 planes, three
+    products; f32 accumulation): same tolerance as the f32 kernels, |d raw| <= 1e-5 (1 + |raw|) against the oracle, for 1, 2
+    and 3 logit blocks and ragged batches (incl. one that ends inside a 128-sample workgroup and one of a single sample)."""
+    for ins_num, seed, N, S in ((13, 3, 37, 64), (59, 4, 9, 21), (93, 5, 6, 33), (13, 6, 1, 1), (120, 7, 3, 50)):
         sd = O.make_weights(seed, ins_num, gain=1.7, sigma_bias=0.3)
         m = A.M.DM_NeRF(8, 256, 63, 27, [4], ins_num)
         m.load_state_dict(sd); m = m.cuda()
@@ -558,15 +560,16 @@ def test_split_bf16_inference_is_f32_class(A):
         z = torch.sort(torch.rand(N, S, generator=g) * 5 + 1, -1)[0]
         lib = A.lib.load()
         raw_s = torch.empty(N, S, 4 + ins_num + 1, device="cuda")
-        ro_d, rd_d, z_d, blob = dev(ro), dev(rd), dev(z), m.blob_split()
-        A.lib.check(lib.dmnerf_mlp_fwd_rays_split(A.lib.ptr(blob), ins_num, A.lib.ptr(ro_d), A.lib.ptr(rd_d), A.lib.ptr(z_d),
+        ro_d, rd_d, z_d, blob = dev(ro), dev(rd), dev(z), (m.blob_split() if split == "bf16x3" else m.blob_f16())
+        fn = lib.dmnerf_mlp_fwd_rays_split if split == "bf16x3" else lib.dmnerf_mlp_fwd_rays_f16
+        A.lib.check(fn(A.lib.ptr(blob), ins_num, A.lib.ptr(ro_d), A.lib.ptr(rd_d), A.lib.ptr(z_d),
                                                 N, S, A.lib.ptr(raw_s), A.lib.stream()), "split")
         pts = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
         vd = rd / torch.norm(rd, dim=-1, keepdim=True)
         x = torch.cat([O.embed(pts.reshape(-1, 3), 10), O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1)
         want = O.mlp_forward(sd, x).reshape(N, S, -1)
         got = cpu(raw_s)
-        assert bool(((got - want).abs() <= 1e-5 * (1 + want.abs())).all()), (ins_num, float(((got - want).abs() / (1 + want.abs())).max()))
+        assert bool(((got - want).abs() <= 1e-5 * (1 + want.abs())).all()), (split, ins_num, float(((got - want).abs() / (1 + want.abs())).max()))
     # through dm_nerf
     ins_num = 13
     sd_c, sd_f = O.make_weights(11, ins_num, gain=1.7, sigma_bias=0.3), O.make_weights(12, ins_num, gain=1.7, sigma_bias=0.3)
@@ -578,15 +581,15 @@ def test_split_bf16_inference_is_f32_class(A):
     rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0).cuda()
     z = A.H.z_val_sample(256, 4.0, 15.0, 64)
     base = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None)
-    split = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, mfma_split=True)
+    sargs = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, mfma_split=split)
     with torch.no_grad():
-        a, b = A.R.dm_nerf(rays, None, None, mc, mf, z, base), A.R.dm_nerf(rays, None, None, mc, mf, z, split)
+        a, b = A.R.dm_nerf(rays, None, None, mc, mf, z, base), A.R.dm_nerf(rays, None, None, mc, mf, z, sargs)
     assert float((a['raw_coarse'] - b['raw_coarse']).abs().max()) <= 1e-5 * (1 + float(a['raw_coarse'].abs().max()))
     assert float((a['rgb_coarse'] - b['rgb_coarse']).abs().max()) <= 5e-6
     assert float((a['rgb_fine'] - b['rgb_fine']).abs().max()) <= 2e-3       # through the ill-conditioned inverse-CDF step
 
 
-@pytest.mark.parametrize("mode", ["fuse_heads", "mfma_split"])
+@pytest.mark.parametrize("mode", ["fuse_heads", "mfma_split", "mfma_split=f16x2"])
 @pytest.mark.parametrize("ins_num,near,far", [(13, 4.0, 15.0), (59, 0.0, 4.7), (93, 0.0, 4.7)])
 def test_opt_in_inference_modes_full_dict_vs_oracle(A, mode, ins_num, near, far, capsys):
     """The two opt-in inference modes (never the default, never the headline metric) held to the DEFAULT path's contract on
@@ -601,7 +604,8 @@ def test_opt_in_inference_modes_full_dict_vs_oracle(A, mode, ins_num, near, far,
     sel = torch.from_numpy(np.random.RandomState(2000 + ins_num).choice(480 * 640, 1024, replace=False))
     rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
     z = O.z_val_sample(1024, near, far, 64).contiguous()
-    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, **{mode: True})
+    key, _, val = mode.partition("=")
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, **{key: (val or True)})
     with torch.no_grad():
         got = {k: cpu(v) for k, v in A.R.dm_nerf(dev(rays), None, None, mc, mf, dev(z), args).items()}
         want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0.)

@@ -116,6 +116,83 @@ def test_transposed_split_index_addresses_the_right_parameters(ins_num):
     assert (idx[(n_inso + 4 + 56) * SLOT_ELEMS:] == -1).all()      # landing slots
 
 
+@pytest.mark.parametrize("ins_num", [13, 59, 93, 120])
+def test_f16_index_addresses_the_right_parameters(ins_num):
+    """The split-f16 forward blob (layout.h::F16Layout, csrc/mlp_f16_impl.h): a flat stream of 16 KiB groups = 8 hi tiles + 8 lo
+    tiles, tile i <-> (k-block kb0 + i / nob, out-block ob0 + i % nob), in the order the kernel's passes consume them; the bias
+    of mlps.0 sits in the stream column of the position encoding's pad slot, every other bias in the table."""
+    lib = _lib.load()
+    total = lib.dmnerf_blob_f16_words(ins_num)
+    C = ins_num + 1
+    obx = {1: 1, 2: 2, 3: 4, 4: 4}[(C + 31) // 32]
+    n_groups = 140 + obx
+    assert total == TAB + (n_groups + 6) * 4096                    # + F16_LA landing groups
+    n = (total - TAB) * 2
+    tab, idx = np.empty(TAB, dtype=np.int32), np.empty(n, dtype=np.int32)
+    _lib.check(lib.dmnerf_build_pack_index_f16(ins_num, tab.ctypes.data_as(ctypes.c_void_p), TAB, idx.ctypes.data_as(ctypes.c_void_p), n), "f16 index")
+    shapes = {"mlps.0": (256, 63), **{f"mlps.{i}": (256, 319 if i == 5 else 256) for i in range(1, 8)},
+              "rgb_feature_linear": (256, 256), "ins_feature_linear": (256, 256), "rgb_feature_linears.0": (128, 283),
+              "ins_feature_linears.0": (128, 256), "density_linear": (1, 256), "ins_linear": (C, 128), "rgb_linear": (3, 128)}
+    off, o = {}, 0
+    for m in W.PARAM_MODULES:
+        off[m] = o
+        o += shapes[m][0] * shapes[m][1] + shapes[m][0]
+
+    def pefeat(p, h, L):
+        if p == 0:
+            return h
+        if p == 1:
+            return -1 if h else 2
+        q = p - 2
+        return -1 if q >= 3 * L else 3 + 6 * (q // 3) + 3 * h + q % 3
+
+    # the kernel's pass order: (module, nob, ob0, kb0, k-order, column offset, bias in the pad slot)
+    groups = [("mlps.0", 2, 2 * p, 0, "pos", 0, True) for p in range(4)]
+    for l in range(1, 8):
+        for p in range(4):
+            groups += [(f"mlps.{l}", 2, 2 * p, 4 * q, "acc", 0, False) for q in range(4)]
+            if l == 5:
+                groups.append(("mlps.5", 2, 2 * p, 0, "pos", 256, False))
+    groups += [("rgb_feature_linears.0", 4, 0, 2 * q, "acc", 0, False) for q in range(8)] + [("rgb_feature_linears.0", 4, 0, 0, "dir", 256, False)]
+    groups += [("ins_feature_linears.0", 4, 0, 2 * q, "acc", 0, False) for q in range(8)]
+    groups += [("rgb_linear", 1, 0, 0, "acc", 0, False)] + [("density_linear", 1, 0, 8 * q, "acc", 0, False) for q in range(2)]
+    groups += [("ins_linear", obx, 0, q * (8 // obx), "acc", 0, False) for q in range(obx)]
+    assert len(groups) == n_groups
+    rng = np.random.RandomState(ins_num)
+    for gi in sorted(set(rng.randint(0, n_groups, 40)) | {0, 3, 4, 84, 88, 100, n_groups - 1}):
+        mod, nob, ob0, kb0, order, col0, bias_pad = groups[gi]
+        rows, ld = shapes[mod]
+        for plane in range(2):
+            for i in range(8):
+                kb, ob = kb0 + i // nob, ob0 + i % nob
+                for lane in (0, 5, 31, 32, 63):
+                    for q in range(8):
+                        p_, h = 8 * kb + q, lane >> 5
+                        col = cfeat(p_, h) if order == "acc" else pefeat(p_, h, 10 if order == "pos" else 4)
+                        row = ob * 32 + (lane & 31)
+                        ncols = ld - col0 if order != "acc" else min(ld, 256 if mod.startswith("mlps") or "feature" in mod else ld)
+                        if row >= rows or col < 0 or col >= ncols:
+                            want = -1
+                            if bias_pad and p_ == 1 and h == 1 and row < rows:
+                                want = (off[mod] + rows * ld + row) | (plane << 28)          # the bias behind the weight matrix
+                        else:
+                            want = (off[mod] + row * ld + col0 + col) | (plane << 28)
+                        e = (gi * 16 + plane * 8 + i) * 512 + lane * 8 + q
+                        assert idx[e] == want, (gi, mod, plane, i, lane, q, idx[e], want)
+    assert (idx[n_groups * 16 * 512:] == -1).all()                 # landing groups are zero
+    # table: biases in accumulator order, pass order; mlps.0 has none (zeros)
+    assert (tab[:256] == -1).all()
+    for l in (1, 5, 7):
+        for ob in (0, 7):
+            for half in (0, 1):
+                for r in (0, 5, 15):
+                    assert tab[l * 256 + (ob * 2 + half) * 16 + r] == off[f"mlps.{l}"] + 256 * shapes[f"mlps.{l}"][1] + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * half
+    assert tab[2048] == off["rgb_feature_linears.0"] + 128 * 283 and tab[2048 + 128] == off["ins_feature_linears.0"] + 128 * 256
+    assert tab[2304] == off["density_linear"] + 256 and (tab[2305:2336] == -1).all()
+    assert [tab[2336 + r] for r in (0, 1, 2)] == [off["rgb_linear"] + 3 * 128 + c for c in (0, 1, 2)] and tab[2336 + 3] == -1
+    assert tab[2368] == off["ins_linear"] + C * 128
+
+
 def test_fuse_heads_is_the_same_function():
     import torch
     from oracle import ref_cpu as O
