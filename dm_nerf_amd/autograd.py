@@ -174,9 +174,11 @@ class MLPRaysFunction(torch.autograd.Function):
         ins_num = model.ins_num
         raw = torch.empty(N, S, 4 + ins_num + 1, dtype=torch.float32, device=z.device)
         save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
-        blob = None if mode == "split" else model.blob()          # (the f32 dgrad reads it; the split kernels have their own blobs)
+        blob = None if mode in ("split", "f16") else model.blob()  # (the f32 dgrad reads it; the split kernels have their own blobs)
         if mode == "split":
             fwd_blob, fn = model.blob_split(), lib.dmnerf_mlp_fwd_rays_train_split
+        elif mode == "f16":
+            fwd_blob, fn = model.blob_f16(), lib.dmnerf_mlp_fwd_rays_train_f16
         elif mode == "fused":
             fwd_blob, fn = model.blob_fused(), lib.dmnerf_mlp_fwd_rays_train_fused
         else:
@@ -186,7 +188,8 @@ class MLPRaysFunction(torch.autograd.Function):
                           N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
         ctx.model, ctx.M, ctx.save = model, M, save
         ctx.blob, ctx.flat = blob, model.flat()                                   # the weights this forward used
-        ctx.blob_t, ctx.blob_ts = (None, model.blob_t_split()) if mode == "split" else (model.blob_t(), None)
+        ctx.blob_t, ctx.blob_ts = (None, model.blob_t_split()) if mode in ("split", "f16") else (model.blob_t(), None)
+        ctx.mode = mode
         return raw
 
     @staticmethod
@@ -300,12 +303,13 @@ def _params(model):
     return [p for _, p in model.named_parameters()]
 
 
-def run_network_train(model, rays_o, rays_d, z, fused=False, split=False):
+def run_network_train(model, rays_o, rays_d, z, fused=False, split=None):
     """Differentiable (w.r.t. the parameters) fused points + encoding + MLP.  Opt-in variants: ``fused`` (``args.fuse_heads``)
     runs the FORWARD on the fused-heads blob (-19 % MACs; values equal up to f32 re-association, not bit-equal to the inference
-    default; default f32 backward); ``split`` (``args.mfma_split``) runs forward, data gradients and weight gradients on the
-    split-bf16 MFMA kernels (fused heads + six bf16 products per f32 product: f32-class values)."""
-    mode = "split" if split else "fused" if fused else None
+    default; default f32 backward); ``split`` (``weights.split_mode(args)``: "bf16x3" | "f16x2") runs forward, data gradients and
+    weight gradients on the split-operand 16-bit MFMA kernels (fused heads + six bf16 / three f16 products per f32 product:
+    f32-class values)."""
+    mode = {"bf16x3": "split", "f16x2": "f16", True: "split"}[split] if split else ("fused" if fused else None)
     if not model._fused_ok():                              # another network shape: layer by layer, its own autograd Function
         from . import generic
         return generic.run_network(model, rays_o, rays_d, z, train=True)
@@ -364,7 +368,8 @@ def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=No
     from .networks.render import check_draws             # RNG order of the reference: [N,S] then [N,n_imp]; shapes validated
     t_rand, u, _ = check_draws(t_rand, u, N, S, n_imp, perturb, z_in.device)
     z_coarse = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
-    fused, split = bool(getattr(args, "fuse_heads", False)), bool(getattr(args, "mfma_split", False))
+    from . import weights
+    fused, split = bool(getattr(args, "fuse_heads", False)), weights.split_mode(args)
     raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse, fused, split)
     rgb_coarse, weights_coarse, depth_coarse, ins_coarse = CompositeFunction.apply(raw_coarse, z_coarse, rays_d)
     with torch.no_grad():                              # z_samples.detach()  (render.py:68)

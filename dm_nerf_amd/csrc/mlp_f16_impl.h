@@ -107,72 +107,99 @@ struct NoSideC {
     __device__ __forceinline__ void operator()(std::integral_constant<int, G>) const {}
 };
 
-// The epilogue of a finished pass as side operations of the following one(s): bias + ReLU + split of NOBP accumulator blocks
-// (out-blocks OB0 ..) into the plane words of the next layer.  A 32x32x16 MFMA hides ~5 single-issue instructions and every
-// gap already carries a tile read and its wait, so a pair's ~10 instructions are dealt out over THREE consecutive gaps:
-//   gap G0 + s STRIDE     : 2 v_accvgpr_read (the accumulators live in AGPRs, which the VALU cannot read) + 2 bias adds
-//   gap G0 + s STRIDE + 1 : 2 ReLUs + the hi word (v_cvt_pkrtz_f16_f32)
-//   gap G0 + s STRIDE + 2 : the 2 residuals (v_fma_mix_f32) + the lo word
-// for the NUM pairs s NUM .. s NUM + NUM - 1 (STRIDE >= 3).  HASBIAS: bq holds the pass's bias quads (read by the carrying
-// pass's first group, complete by gap 24).  (Measured: with a pair's instructions in ONE gap the trunk ran at 38.6 instead of
-// 32 cycles per MFMA, profiles/r03/diag_f16_r03d.txt.)
-template <int NOBP, int OB0, bool HASBIAS, bool RELU, int G0, int STRIDE, int NUM, int NWO, int NBQA>
-struct EpiSplit {
+// The epilogue of a finished pass as side operations of the following one(s): bias + ReLU (+ SAVE: f32 row store and 1-bit ReLU
+// mask) + split of NOBP accumulator blocks (out-blocks OB0 ..) into the plane words of the next layer.  A 32x32x16 MFMA hides ~5
+// single-issue instructions and every gap already carries a tile read and its wait, so a pair's instructions are dealt out
+// over NPH consecutive gaps, pair k at gaps G0 + NPH k ..:
+//   phase 0 : 2 v_accvgpr_read (the accumulators live in AGPRs, which the VALU cannot read) + 2 bias adds
+//   phase 1 : 2 ReLUs (+ SAVE: the two TID-addressed row stores; else: the hi word)
+//   SAVE 2  : mask bits (compare + add-with-carry per element) + the hi word
+//   last    : the 2 residuals (v_fma_mix_f32) + the lo word
+// (Measured: with a pair's instructions in ONE gap the trunk ran at 38.6 instead of 32 cycles per MFMA, profiles/r03/.)
+// HASQ: bq[QB0 ..] holds the pass's bias quads, 4 per block.  G0 >= 3: the pass's last MFMA must have retired before the asm
+// accumulator reads, which the compiler's hazard recognizer does not see.
+struct SaveCtx {                                // SAVE: where a pass's rows and mask word go
+    RowIO io;                                   // the layer's saved tensor (rows of this wave's 32-sample block)
+    rsrc_t bits_rs;
+    int bits_voff;                              // (blk * BITS_WORDS_PER_BLOCK + lane * words per lane) * 4
+};
+template <bool SAVE, int NOBP, int OB0, int QB0, bool HASQ, bool RELU, int G0, int NUM, int NWO, int NBQA>
+struct EpiFwd {                                 // NUM pairs per burst of NPH gaps (1 where the carrying pass is long enough)
+    static constexpr int NPH = SAVE ? 4 : 3;
     f32x16 (&Y)[NOBP];
     f32x4 (&bq)[NBQA];
     unsigned (&Ohi)[NWO];
     unsigned (&Olo)[NWO];
-    float x0[NUM], x1[NUM];
+    const SaveCtx* sv;                          // SAVE only
+    int bits_soff;                              // SAVE only: byte offset of the pass's first mask word behind bits_voff
+    float xs0[NUM] = {}, xs1[NUM] = {};
+    unsigned mw = 0u;
     template <int GAP>
     __device__ __forceinline__ void operator()(std::integral_constant<int, GAP>) {
-        static_assert(!HASBIAS || G0 >= 24, "bias quads are complete from the second group on");
-        static_assert(STRIDE >= 3, "a pair takes three gaps");
-        if constexpr (HASBIAS && GAP == G0) {
+        static_assert(G0 >= 3, "the finished pass's last MFMA must have retired");
+        if constexpr (HASQ && GAP == G0) {
 #pragma unroll
-            for (int q = 0; q < 4 * NOBP; ++q) asm volatile("" : "+v"(bq[q]));
+            for (int q = 0; q < 4 * NOBP; ++q) asm volatile("" : "+v"(bq[QB0 + q]));
         }
-        if constexpr (GAP >= G0 && (GAP - G0) % STRIDE < 3 && (GAP - G0) / STRIDE * NUM < 8 * NOBP) {
-            constexpr int ph = (GAP - G0) % STRIDE;
-            static_for<NUM>([&](auto nc) {
-                constexpr int n = decltype(nc)::value, k = (GAP - G0) / STRIDE * NUM + n;
-                if constexpr (k < 8 * NOBP) {
-                    constexpr int b = k / 8, r = 2 * (k % 8);
-                    constexpr int w = (2 * (OB0 + b) + (r >> 3)) * 4 + ((r & 7) >> 1);
-                    static_assert(w < NWO, "plane word");
+        if constexpr (GAP >= G0 && (GAP - G0) / NPH * NUM < 8 * NOBP)
+            static_for<NUM>([&](auto nc) { one<(GAP - G0) % NPH, (GAP - G0) / NPH * NUM + decltype(nc)::value, decltype(nc)::value>(); });
+    }
+    template <int ph, int k, int n>
+    __device__ __forceinline__ void one() {
+        float& x0 = xs0[n];
+        float& x1 = xs1[n];
+        if constexpr (k < 8 * NOBP) {
+            constexpr int b = k / 8, r = 2 * (k % 8);
+            constexpr int w = (2 * (OB0 + b) + (r >> 3)) * 4 + ((r & 7) >> 1);
+            static_assert(w < NWO, "plane word");
 #ifdef DMN_F16_NOSIDE
-                    if (k > 0) return;                           // ablation (timing only): one pair per pass keeps the data flow alive
+            if (k > 0) return;                                   // ablation (timing only): one pair per pass keeps the data flow alive
 #endif
-                    if constexpr (ph == 0) {
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0[n]) : "a"(Y[b][r]));
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1[n]) : "a"(Y[b][r + 1]));
-                        if constexpr (HASBIAS) {
-                            x0[n] += bq[b * 4 + (r >> 2)][r & 3];
-                            x1[n] += bq[b * 4 + ((r + 1) >> 2)][(r + 1) & 3];
-                        }
-                        asm volatile("" : "+v"(x0[n]), "+v"(x1[n]));    // the adds stay in this gap
-                    } else if constexpr (ph == 1) {
-                        if constexpr (RELU) { x0[n] = relu1(x0[n]); x1[n] = relu1(x1[n]); }
-                        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Ohi[w]) : "v"(x0[n]), "v"(x1[n]));
-                    } else {
-                        float r0, r1;
-                        asm volatile("v_fma_mix_f32 %0, -%2, 1.0, %3 op_sel_hi:[1,0,0]\n\t"
-                                     "v_fma_mix_f32 %1, -%2, 1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                                     : "=&v"(r0), "=&v"(r1) : "v"(Ohi[w]), "v"(x0[n]), "v"(x1[n]));
-                        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Olo[w]) : "v"(r0), "v"(r1));
-                    }
+            if constexpr (ph == 0) {
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(Y[b][r]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(Y[b][r + 1]));
+                if constexpr (HASQ) {
+                    x0 += bq[QB0 + b * 4 + (r >> 2)][r & 3];
+                    x1 += bq[QB0 + b * 4 + ((r + 1) >> 2)][(r + 1) & 3];
                 }
-            });
+                asm volatile("" : "+v"(x0), "+v"(x1));           // the adds stay in this gap
+            } else if constexpr (ph == 1) {
+                if constexpr (RELU) { x0 = relu1(x0); x1 = relu1(x1); }
+                asm volatile("" : "+v"(x0), "+v"(x1));
+                if constexpr (SAVE) {
+                    DMN_ACT_STORE_B32(f2u(x0), sv->io.rs, run_off(0, r), (int)(sv->io.soff + (OB0 + b) * 4096), DMN_STORE_AUX);
+                    DMN_ACT_STORE_B32(f2u(x1), sv->io.rs, run_off(0, r + 1), (int)(sv->io.soff + (OB0 + b) * 4096), DMN_STORE_AUX);
+                } else {
+                    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Ohi[w]) : "v"(x0), "v"(x1));
+                }
+            } else if constexpr (SAVE && ph == 2) {
+                if constexpr ((k & 15) == 0) mw = 0u;
+                asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mw) : "v"(x0), "v"(x1) : "vcc");
+                asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Ohi[w]) : "v"(x0), "v"(x1));
+                if constexpr ((k & 15) == 15)                    // 32 elements = one mask word per lane (element p = 32 w + i is bit 31 - i)
+                    __builtin_amdgcn_raw_buffer_store_b32(mw, sv->bits_rs, sv->bits_voff, bits_soff + (k >> 4) * 4, 0);
+            } else {
+                float r0, r1;
+                asm volatile("v_fma_mix_f32 %0, -%2, 1.0, %3 op_sel_hi:[1,0,0]\n\t"
+                             "v_fma_mix_f32 %1, -%2, 1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                             : "=&v"(r0), "=&v"(r1) : "v"(Ohi[w]), "v"(x0), "v"(x1));
+                asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(Olo[w]) : "v"(r0), "v"(r1));
+            }
         }
     }
 };
 
 // One group = 24 MFMAs: tile i <-> (k-block KB0 + i / NOB of the planes, accumulator block i % NOB).
-// ZEROC: first group of a pass (C = 0 for the first MFMA of every block).  NBQ: bias quads read at gaps 8..15 (from baddr).
-template <int NOB, int KB0, bool ZEROC, int NBQ, int GAP0, int NW, int NBQA, class Side>
+// ZEROC: first group of a pass (C = 0 for the first MFMA of every block).  NBQ: bias quads read at gaps 8..15 from baddr into
+// bq[QB0 ..].  VMY: VMEM operations other than weight pieces (activation stores) that are guaranteed to be younger than the
+// pieces of group gidx + 2 at the hand-over (a LOWER bound: fewer means waiting for a few of the oldest younger pieces too).
+template <int NOB, int KB0, bool ZEROC, int NBQ, int QB0, int GAP0, int VMY, int NW, int NBQA, class Side>
 __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW], const unsigned (&Plo)[NW], f32x16 (&acc)[NOB],
                                           f32x4 (&bq)[NBQA], unsigned baddr, Side&& side) {
     static_assert(8 % NOB == 0 && (KB0 + 8 / NOB) * 4 <= NW, "B planes too small");
-    static_assert(NBQ <= 16 && NBQ <= NBQA, "bias quads");
+    static_assert(NBQ <= 16 && QB0 + NBQ <= NBQA, "bias quads");
+    static_assert(4 * (F16_LA - 2) + VMY <= 63, "vmcnt");
     constexpr int BPG = (NBQ + 7) / 8;                           // bias quads per gap
     constexpr int LGK_LO = 8 + NBQ > 15 ? 15 : 8 + NBQ;          // reads younger than lo tile j at gap 16 + j (clamped: waits for more)
     // ---- hi tiles: x_hi then x_lo
@@ -185,7 +212,7 @@ __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW]
         } else {
             static_for<BPG>([&](auto sc) {
                 constexpr int q = j * BPG + decltype(sc)::value;
-                if constexpr (q < NBQ) lds_read16_v<(q >> 2) * 128 + (q & 3) * 16>(bq[q], baddr);
+                if constexpr (q < NBQ) lds_read16_v<(q >> 2) * 128 + (q & 3) * 16>(bq[QB0 + q], baddr);
             });
         }
         if constexpr ((i & 3) == 2) gs_fetch_piece(ws, ws.gidx + F16_LA, i >> 2);
@@ -203,7 +230,7 @@ __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW]
     // order: the 4 (F16_LA - 2) youngest pieces belong to later groups), and the barrier publishes both facts.
     if (ws.gidx & 1) {
         wait_lgkm<(NBQ > 15 ? 15 : NBQ)>();
-        wait_vm<4 * (F16_LA - 2)>();
+        wait_vm<4 * (F16_LA - 2) + VMY>();
         asm volatile("" ::: "memory");
 #ifndef DMN_F16_NOBAR
         __builtin_amdgcn_s_barrier();
@@ -227,13 +254,14 @@ __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW]
     ws.nxt = ws.lane16 + (unsigned)(((ws.gidx + 1) & (F16_RING - 1)) * F16_GROUP_BYTES);
 }
 
-// NG consecutive groups on the same accumulator blocks: k-blocks KB0 .. of the planes, 8 / NOB per group
-template <int NOB, int NG, int KB0, int NBQ, int GAP0, bool ZERO_FIRST, int NW, int NBQA, class Side>
+// NG consecutive groups on the same accumulator blocks: k-blocks KB0 .. of the planes, 8 / NOB per group; the first one reads
+// NBQ bias quads into bq[QB0 ..]
+template <int NOB, int NG, int KB0, int NBQ, int QB0, int GAP0, bool ZERO_FIRST, int VMY, int NW, int NBQA, class Side>
 __device__ __forceinline__ void f16_pass(GStream& ws, const unsigned (&Phi)[NW], const unsigned (&Plo)[NW], f32x16 (&acc)[NOB],
                                          f32x4 (&bq)[NBQA], unsigned baddr, Side&& side) {
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        f16_group<NOB, KB0 + g * (8 / NOB), (ZERO_FIRST && g == 0), (g == 0 ? NBQ : 0), GAP0 + 24 * g>(ws, Phi, Plo, acc, bq, baddr, side);
+        f16_group<NOB, KB0 + g * (8 / NOB), (ZERO_FIRST && g == 0), (g == 0 ? NBQ : 0), QB0, GAP0 + 24 * g, VMY>(ws, Phi, Plo, acc, bq, baddr, side);
     });
 }
 
@@ -296,20 +324,41 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
         ws.off += F16_GROUP_BYTES;
     }                                                                    // from now on `off` = group gidx + F16_LA
 
+    // SAVE (opt-in training forward): the f32 workspace of layout.h::SaveLayout that the backward kernels consume -- pe, de,
+    // the ReLU outputs h_0 .. h_7, g1, g2 as block-major rows (TID-addressed stores, mlp_common.h::RowIO) and the 1-bit masks
+    const SaveLayout SL = make_save_layout(a.M);
+    const int64_t MP = save_row_len(a.M);
+    rsrc_t bits_rs = uniform_rsrc(SAVE ? a.save + SL.bits : a.blob, SAVE ? (int64_t)(BITS_WORDS_PER_BLOCK / 32) * MP : 0);
+    auto save_ctx = [&](int64_t tensor_off, int rows, int words_per_lane, int word0) -> SaveCtx {
+        SaveCtx c;
+        c.io.rs = bits_rs; c.io.soff = 0u; c.bits_rs = bits_rs; c.bits_voff = 0;      // (inference: never used)
+        if constexpr (SAVE) {
+            c.io = make_rowio(a.save + tensor_off, rows, MP, blk, lane);
+            c.bits_rs = bits_rs;
+            c.bits_voff = (int)((blk * BITS_WORDS_PER_BLOCK + word0 + lane * words_per_lane) * 4);
+        }
+        return c;
+    };
+
     // encodings as planes.  The pad slot of the position encoding (k-pair 1, upper half) carries 1.0: the stream holds the bias
-    // of mlps.0 in that column (pack.cpp), so the first layer needs no bias pass
+    // of mlps.0 in that column (pack.cpp), so the first layer needs no bias table
     unsigned Ppe[2][16], Pde[2][8];
     {
         f32x16 pe[2], de[1];
         encode<POS_L, 2>(pt, pe, half);
         encode<DIR_L, 1>(vd, de, half);
+        if constexpr (SAVE) {
+            store_encoded_rows<POS_L, 2>(a.save + SL.pe, MP, blk, lane, pe);
+            store_encoded_rows<DIR_L, 1>(a.save + SL.de, MP, blk, lane, de);
+        }
         pe[0][1] = half ? 1.f : pe[0][1];
         split_blocks_f16<2>(pe, Ppe[0], Ppe[1]);
         split_blocks_f16<1>(de, Pde[0], Pde[1]);
     }
 
-    // groups 0 and 1 landed (the pieces of groups 2 .. 5 may still fly), table visible; hi tiles of group 0
-    wait_vm<4 * (F16_LA - 2)>();
+    // groups 0 and 1 landed (the pieces of groups 2 .. 5 -- and, SAVE, the 90 younger encoding stores -- may still fly), table
+    // visible; hi tiles of group 0
+    if constexpr (SAVE) wait_vm<63>(); else wait_vm<4 * (F16_LA - 2)>();
     wait_lgkm<0>();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -321,67 +370,80 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
     DMN_F16_STAMP(1);
     f32x16 acc0[2], acc1[2];                   // the two accumulator sets of the trunk passes (even / odd pass)
     unsigned PA[2][64], PB[2][64];             // the two plane sets: 256 features as (hi, lo) words of f16 pairs
-    f32x4 bq[16];                              // bias quads of the pass being post-processed
-    // bias table walk: the pending pass's 32 NOB floats at baddr (this lane's half), in pass order from mlps.0's last pass
-    // (whose table entries are zero: its bias sits in the stream) on
-    unsigned baddr = lds_addr(tab) + half * 64 + 6 * 32 * 4;
+    f32x4 bq[16];                              // bias quads: trunk pass p reads ITS OWN 8 into half p & 1 (used one pass later)
+    // bias table walk (this lane's half): mlps.1's first pass, then pass by pass
+    unsigned baddr = lds_addr(tab) + half * 64 + 256 * 4;
+    // activation stores guaranteed younger than the awaited weight pieces at a trunk hand-over: the window back to their issue is
+    // 98 gaps, a pass issues 33 stores in gaps 3..66 of its 96 (mlps.5: 120) -- at least 20 fall into any window
+    constexpr int VMT = SAVE ? 16 : 0;
+    constexpr int NU0 = SAVE ? 4 : 3;          // mlps.0's one-group passes carry their predecessor's epilogue NU0 pairs at a time
 
-    // ---- mlps.0 : 63 -> 256, four passes of one group; the epilogue of pass p - 1 rides in pass p (from gap 3 on: its last MFMA
-    // must have retired before the asm accumulator reads, which the compiler's hazard recognizer does not see)
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiSplit<2, 0, false, true, 3, 3, 3, 64, 16>{acc0, bq, PA[0], PA[1]});
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, EpiSplit<2, 2, false, true, 3, 3, 3, 64, 16>{acc1, bq, PA[0], PA[1]});
-    f16_pass<2, 1, 0, 0, 0, true>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiSplit<2, 4, false, true, 3, 3, 3, 64, 16>{acc0, bq, PA[0], PA[1]});
+    // ---- mlps.0 : 63 -> 256, four passes of one group; the epilogue of pass p - 1 rides in pass p
+    const SaveCtx sv0 = save_ctx(SL.h, 256, 4, 0);
+    f16_pass<2, 1, 0, 0, 0, 0, true, 0>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
+    f16_pass<2, 1, 0, 0, 0, 0, true, 0>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiFwd<SAVE, 2, 0, 0, false, true, 3, NU0, 64, 16>{acc0, bq, PA[0], PA[1], &sv0, 0});
+    f16_pass<2, 1, 0, 0, 0, 0, true, 0>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, EpiFwd<SAVE, 2, 2, 0, false, true, 3, NU0, 64, 16>{acc1, bq, PA[0], PA[1], &sv0, 4});
+    f16_pass<2, 1, 0, 0, 0, 0, true, 0>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, EpiFwd<SAVE, 2, 4, 0, false, true, 3, NU0, 64, 16>{acc0, bq, PA[0], PA[1], &sv0, 8});
 
     DMN_F16_STAMP(2);
     // ---- mlps.1 .. mlps.7: layer X reads A and writes B, layer Y reads B and writes A; pass p accumulates out-blocks 2p, 2p+1
-    // in set p & 1 while the other set (pass p - 1, or the previous layer's pass 3) is post-processed into its plane words
-    auto layer = [&](unsigned (&Pin)[2][64], unsigned (&Pout)[2][64], bool pe_on) __attribute__((always_inline)) {
-        f16_pass<2, 4, 0, 8, 0, true>(ws, Pin[0], Pin[1], acc0, bq, baddr, EpiSplit<2, 6, true, true, 24, 3, 1, 64, 16>{acc1, bq, Pin[0], Pin[1]});
+    // in set p & 1 and reads its own bias quads, while the other set (pass p - 1, or the previous layer's pass 3) is
+    // post-processed into its plane words (and, SAVE, stored as h_l).  LAYER = index of the layer that is being accumulated.
+    auto layer = [&](auto lc, unsigned (&Pin)[2][64], unsigned (&Pout)[2][64], auto hasq_prev) __attribute__((always_inline)) {
+        constexpr int LAYER = decltype(lc)::value;
+        constexpr bool PE_ON = LAYER == 5;                               // skip concat [h, pts] (dm_nerf.py:87)
+        constexpr bool HQP = decltype(hasq_prev)::value;                 // (mlps.0 has no table bias)
+        const SaveCtx svp = save_ctx(SL.h + (int64_t)(LAYER - 1) * 256 * MP, 256, 4, 0);      // the previous layer's outputs
+        const SaveCtx svl = save_ctx(SL.h + (int64_t)LAYER * 256 * MP, 256, 4, 0);
+        f16_pass<2, 4, 0, 8, 0, 0, true, VMT>(ws, Pin[0], Pin[1], acc0, bq, baddr,
+                                              EpiFwd<SAVE, 2, 6, 8, HQP, true, 3, 1, 64, 16>{acc1, bq, Pin[0], Pin[1], &svp, (LAYER - 1) * 1024 + 12});
         baddr += 256;
-        if (pe_on) f16_pass<2, 1, 0, 0, 96, false>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
-        f16_pass<2, 4, 0, 8, 0, true>(ws, Pin[0], Pin[1], acc1, bq, baddr, EpiSplit<2, 0, true, true, 24, 3, 1, 64, 16>{acc0, bq, Pout[0], Pout[1]});
+        if constexpr (PE_ON) f16_pass<2, 1, 0, 0, 0, 96, false, VMT>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
+        f16_pass<2, 4, 0, 8, 8, 0, true, VMT>(ws, Pin[0], Pin[1], acc1, bq, baddr,
+                                              EpiFwd<SAVE, 2, 0, 0, true, true, 3, 1, 64, 16>{acc0, bq, Pout[0], Pout[1], &svl, LAYER * 1024 + 0});
         baddr += 256;
-        if (pe_on) f16_pass<2, 1, 0, 0, 96, false>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, NoSideC{});
-        f16_pass<2, 4, 0, 8, 0, true>(ws, Pin[0], Pin[1], acc0, bq, baddr, EpiSplit<2, 2, true, true, 24, 3, 1, 64, 16>{acc1, bq, Pout[0], Pout[1]});
+        if constexpr (PE_ON) f16_pass<2, 1, 0, 0, 0, 96, false, VMT>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, NoSideC{});
+        f16_pass<2, 4, 0, 8, 0, 0, true, VMT>(ws, Pin[0], Pin[1], acc0, bq, baddr,
+                                              EpiFwd<SAVE, 2, 2, 8, true, true, 3, 1, 64, 16>{acc1, bq, Pout[0], Pout[1], &svl, LAYER * 1024 + 4});
         baddr += 256;
-        if (pe_on) f16_pass<2, 1, 0, 0, 96, false>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
-        f16_pass<2, 4, 0, 8, 0, true>(ws, Pin[0], Pin[1], acc1, bq, baddr, EpiSplit<2, 4, true, true, 24, 3, 1, 64, 16>{acc0, bq, Pout[0], Pout[1]});
+        if constexpr (PE_ON) f16_pass<2, 1, 0, 0, 0, 96, false, VMT>(ws, Ppe[0], Ppe[1], acc0, bq, baddr, NoSideC{});
+        f16_pass<2, 4, 0, 8, 8, 0, true, VMT>(ws, Pin[0], Pin[1], acc1, bq, baddr,
+                                              EpiFwd<SAVE, 2, 4, 0, true, true, 3, 1, 64, 16>{acc0, bq, Pout[0], Pout[1], &svl, LAYER * 1024 + 8});
         baddr += 256;
-        if (pe_on) f16_pass<2, 1, 0, 0, 96, false>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, NoSideC{});
+        if constexpr (PE_ON) f16_pass<2, 1, 0, 0, 0, 96, false, VMT>(ws, Ppe[0], Ppe[1], acc1, bq, baddr, NoSideC{});
     };
-#ifdef DMN_F16_LOOP
-#pragma nounroll
-    for (int it = 0; it < 4; ++it) {
-        layer(PA, PB, it == 2);                                          // mlps.1 / 3 / 5 (skip concat [h, pts], dm_nerf.py:87) / 7
-        if (it == 3) break;
-        layer(PB, PA, false);                                            // mlps.2 / 4 / 6
-    }
-#else
     // straight-line: the group index, hence the ring slot and the hand-over parity, are compile-time constants and the whole
     // network is one basic block -- no control-flow merge at which the register allocator could copy a tile in flight
-    layer(PA, PB, false); layer(PB, PA, false);
-    layer(PA, PB, false); layer(PB, PA, false);
-    layer(PA, PB, true);  layer(PB, PA, false);                          // mlps.5: skip concat [h, pts] (dm_nerf.py:87)
-    layer(PA, PB, false);
-#endif
+    typedef std::true_type T_;
+    layer(std::integral_constant<int, 1>{}, PA, PB, std::false_type{});
+    layer(std::integral_constant<int, 2>{}, PB, PA, T_{});
+    layer(std::integral_constant<int, 3>{}, PA, PB, T_{});
+    layer(std::integral_constant<int, 4>{}, PB, PA, T_{});
+    layer(std::integral_constant<int, 5>{}, PA, PB, T_{});
+    layer(std::integral_constant<int, 6>{}, PB, PA, T_{});
+    layer(std::integral_constant<int, 7>{}, PA, PB, T_{});
 
     DMN_F16_STAMP(3);
     // ---- heads on h_7 = planes B (its last two out-blocks arrive under the first groups of the rgb hidden layer)
     f32x16 accR[4], accI[4], accO[1], accD[1], accL[OBX];
     unsigned G1[2][32], G2[2][32];
+    const SaveCtx sv7 = save_ctx(SL.h + (int64_t)7 * 256 * MP, 256, 4, 0);
+    const SaveCtx svg1 = save_ctx(SL.g1, 128, 2, 2048), svg2 = save_ctx(SL.g2, 128, 2, 2176);
     // rgb hidden' = relu(W' h + W_dirs dirs + b')   (rgb_feature_linear folded in)
-    f16_pass<4, 8, 0, 8, 0, true>(ws, PB[0], PB[1], accR, bq, baddr, EpiSplit<2, 6, true, true, 24, 3, 1, 64, 16>{acc1, bq, PB[0], PB[1]});
-    baddr += 256;
-    f16_pass<4, 1, 0, 0, 192, false>(ws, Pde[0], Pde[1], accR, bq, baddr, NoSideC{});
-    // ins hidden' = relu(W'' h + b''); carries the rgb hidden epilogue
-    f16_pass<4, 8, 0, 16, 0, true>(ws, PB[0], PB[1], accI, bq, baddr, EpiSplit<4, 0, true, true, 24, 5, 1, 32, 16>{accR, bq, G1[0], G1[1]});
+    f16_pass<4, 8, 0, 0, 0, 0, true, 0>(ws, PB[0], PB[1], accR, bq, baddr,
+                                        EpiFwd<SAVE, 2, 6, 8, true, true, 3, 1, 64, 16>{acc1, bq, PB[0], PB[1], &sv7, 7 * 1024 + 12});
+    f16_pass<4, 1, 0, 0, 0, 192, false, 0>(ws, Pde[0], Pde[1], accR, bq, baddr, NoSideC{});
+    // ins hidden' = relu(W'' h + b''); reads the rgb hidden layer's bias quads and carries its epilogue (g1)
+    f16_pass<4, 8, 0, 16, 0, 0, true, 0>(ws, PB[0], PB[1], accI, bq, baddr,
+                                         EpiFwd<SAVE, 4, 0, 0, true, true, 24, 1, 32, 16>{accR, bq, G1[0], G1[1], &svg1, 0});
     baddr += 512;
-    // rgb_linear (dm_nerf.py:102) on the rgb hidden planes, then density_linear (:101) on h_7: together they carry the ins hidden epilogue
-    f16_pass<1, 1, 0, 16, 0, true>(ws, G1[0], G1[1], accO, bq, baddr, NoSideC{});
-    f16_pass<1, 2, 0, 0, 24, true>(ws, PB[0], PB[1], accD, bq, baddr, EpiSplit<4, 0, true, true, 24, 3, 2, 32, 16>{accI, bq, G2[0], G2[1]});
+    // rgb_linear (dm_nerf.py:102) on the rgb hidden planes, then density_linear (:101) on h_7: together they carry the ins
+    // hidden layer's epilogue (g2), whose bias quads the first of them reads
+    f16_pass<1, 1, 0, 16, 0, 0, true, 0>(ws, G1[0], G1[1], accO, bq, baddr, NoSideC{});
+    f16_pass<1, 2, 0, 0, 0, 24, true, 0>(ws, PB[0], PB[1], accD, bq, baddr,
+                                         EpiFwd<SAVE, 4, 0, 0, true, true, 24, (SAVE ? 3 : 2), 32, 16>{accI, bq, G2[0], G2[1], &svg2, 0});
     // ins_linear (:103)
-    f16_pass<OBX, OBX, 0, 0, 0, true>(ws, G2[0], G2[1], accL, bq, baddr, NoSideC{});
+    f16_pass<OBX, OBX, 0, 0, 0, 0, true, 0>(ws, G2[0], G2[1], accL, bq, baddr, NoSideC{});
 
     DMN_F16_STAMP(4);
     // ---- outputs: cat[rgb, density, ins] (dm_nerf.py:105); biases of the three output layers from the table

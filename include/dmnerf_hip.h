@@ -264,6 +264,12 @@ int dmnerf_pack_f16(const float* d_flat, const int32_t* d_idx, float* d_stream_w
 int dmnerf_mlp_fwd_rays_f16(const float* d_blob_f16, int ins_num, const float* d_rays_o, const float* d_rays_d,
                             const float* d_z, int64_t N, int S, float* d_raw, void* stream);
 
+/* OPT-IN training forward on the split-f16 path (args.mfma_split = "f16x2" with grad enabled): dmnerf_mlp_fwd_rays_f16 plus
+ * the f32 workspace d_save of dmnerf_mlp_fwd_rays_train (dmnerf_train_save_floats(N S) floats: pe, de, h_0..h_7, g1, g2 as
+ * block-major rows + 1-bit ReLU masks), which every backward kernel of this library consumes. */
+int dmnerf_mlp_fwd_rays_train_f16(const float* d_blob_f16, int ins_num, const float* d_rays_o, const float* d_rays_d,
+                                  const float* d_z, int64_t N, int S, float* d_raw, float* d_save, void* stream);
+
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
  * (int32, values 0..ins_num; other values are ignored) -> out4 = {ins_loss_sum, valid_ce, invalid_ce,

@@ -307,13 +307,15 @@ def test_penalizer_golden_value_and_gradient(A, golden):
         tclose(grad[..., 4:] / 1.5, g[f"{k}_grad"], f"penalizer grad {k}", rel=2e-5)
 
 
-@pytest.mark.parametrize("mode", ["fuse_heads", "mfma_split"])
+@pytest.mark.parametrize("mode", ["fuse_heads", "mfma_split", "mfma_split=f16x2"])
 def test_opt_in_fused_heads_training(A, mode):
-    """``args.fuse_heads`` / ``args.mfma_split`` in training mode (the split-bf16 forward is the fused-heads function on the bf16
-    MFMA, f32-class; it writes the same f32 workspace for the same f32 backward).  For ``fuse_heads``: the forward runs on the fused-heads blob (the two activation-free feature linears
+    """``args.fuse_heads`` / ``args.mfma_split`` (True = "bf16x3", or "f16x2") in training mode (the split forwards are the fused-heads
+    function on the 16-bit MFMA, f32-class; they write the same f32 workspace as the f32 forward).  For ``fuse_heads``: the forward runs on the fused-heads blob (the two activation-free feature linears
     folded into the hidden layers), the backward is the same re-associated one.  Forward inside the MLP contract against the
     oracle (NOT bit-equal to the default path: that is why it is opt-in); per-tensor gradients against PyTorch autograd of the
     oracle; a dm_nerf step through the flag moves the loss like the default step."""
+    key, _, val = mode.partition("=")
+    split = {"mfma_split": "bf16x3", "mfma_split=f16x2": "f16x2"}.get(mode)
     for ins_num, seed, N, S in ((13, 15, 8, 64), (59, 16, 5, 33)):
         sd = O.make_weights(seed, ins_num, gain=1.7)
         g = torch.Generator().manual_seed(seed)
@@ -322,7 +324,7 @@ def test_opt_in_fused_heads_training(A, mode):
         cot = torch.randn(N, S, 4 + ins_num + 1, generator=g)
         raw_want, want = _oracle_mlp_grads(sd, rays_o, rays_d, z, cot)
         m = model_from(A, sd, ins_num)
-        raw = A.G.run_network_train(m, rays_o.cuda(), rays_d.cuda(), z.cuda(), fused=mode == "fuse_heads", split=mode == "mfma_split")
+        raw = A.G.run_network_train(m, rays_o.cuda(), rays_d.cuda(), z.cuda(), fused=mode == "fuse_heads", split=split)
         tclose(raw, raw_want, "raw (fused training forward)", rel=1e-5)
         (raw * cot.cuda()).sum().backward()
         for k, p in m.named_parameters():
@@ -343,7 +345,7 @@ def test_opt_in_fused_heads_training(A, mode):
     for fused in (False, True):
         mc, mf = model_from(A, sd_c, ins_num), model_from(A, sd_f, ins_num)
         opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
-        args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, **{mode: fused})
+        args = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, **{key: ((val or True) if fused else False)})
         tr = []
         for _ in range(3):
             out = A.R.dm_nerf(rays, None, None, mc, mf, z, args)
