@@ -188,7 +188,13 @@ class MLPRaysFunction(torch.autograd.Function):
                           N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
         ctx.model, ctx.M, ctx.save = model, M, save
         ctx.blob, ctx.flat = blob, model.flat()                                   # the weights this forward used
-        ctx.blob_t, ctx.blob_ts = (None, model.blob_t_split()) if mode in ("split", "f16") else (model.blob_t(), None)
+        ctx.blob_t = ctx.blob_ts = None
+        if mode == "split":
+            ctx.blob_ts = model.blob_t_split()
+        elif mode == "f16":
+            ctx.blob_ts = model.blob_t_f16()
+        else:
+            ctx.blob_t = model.blob_t()
         ctx.mode = mode
         return raw
 
@@ -217,8 +223,9 @@ def _mlp_backward(ctx, g_raw):
     split = getattr(ctx, "blob_ts", None) is not None            # opt-in: split-bf16 backward kernels (args.mfma_split)
     with _timed("mlp_bwd_data", M):
         if split:
-            _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
-                                                     _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split")
+            f_dgrad = lib.dmnerf_mlp_bwd_data_f16 if getattr(ctx, "mode", None) == "f16" else lib.dmnerf_mlp_bwd_data_split
+            _lib.check(f_dgrad(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                               _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split / _f16")
         else:
             _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")

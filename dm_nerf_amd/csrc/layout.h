@@ -214,6 +214,24 @@ DMN_HD inline F16Layout make_f16_layout(int ins_num) {
     return S;
 }
 
+// Split-f16 blob of the OPT-IN data-gradient kernel (mlp_bwd_f16.hip): W^T groups in the F16Layout group format
+// (A tile rows = the layer's INPUTS 32 ob + (lane & 31), k = its OUTPUTS in accumulator order cfeat(8 kb + q, lane >> 5)):
+//   ins_linear^T (nob 4: the 128 g2 rows; 2 OBI k-blocks = OBI groups) | F^T (4 passes x 2 groups, nob 2: 8 k-blocks = dg1) |
+//   mlps.7^T .. mlps.1^T (4 passes x 4 groups each; mlps.5: its h columns)                             = 120 + OBI groups
+// the table in front is the f32 backward blob's (TAB_T_FLOATS: the two VALU heads).
+struct F16TLayout {
+    int C, OBI, n_groups;
+    int64_t stream, total;        // word offsets (stream = TAB_T_FLOATS), total incl. F16_LA landing groups
+};
+DMN_HD inline F16TLayout make_f16_layout_t(int ins_num) {
+    F16TLayout S{};
+    S.C = ins_num + 1; S.OBI = (S.C + 31) / 32;
+    S.n_groups = S.OBI + 8 + 7 * 16;
+    S.stream = 1024;
+    S.total = S.stream + (int64_t)(S.n_groups + F16_LA) * F16_GROUP_WORDS;
+    return S;
+}
+
 // Backward (dgrad) blob: the same segments with W^T as the A operand, dx^T = W^T . dy^T.
 //   seg[((g*OB + ob)*64 + lane)*4 + kk] = W[out = cfeat(4g+kk, lane>>5)][in = ob*32 + (lane&31)]
 //

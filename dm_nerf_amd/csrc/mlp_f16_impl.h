@@ -192,9 +192,9 @@ struct EpiFwd {                                 // NUM pairs per burst of NPH ga
 
 // One group = 24 MFMAs: tile i <-> (k-block KB0 + i / NOB of the planes, accumulator block i % NOB).
 // ZEROC: first group of a pass (C = 0 for the first MFMA of every block).  NBQ: bias quads read at gaps 8..15 from baddr into
-// bq[QB0 ..].  VMY: VMEM operations other than weight pieces (activation stores) that are guaranteed to be younger than the
+// bq[QB0 ..] (4 per block, blocks QSTR bytes apart: 128 in the bias table).  VMY: VMEM operations other than weight pieces (activation stores) that are guaranteed to be younger than the
 // pieces of group gidx + 2 at the hand-over (a LOWER bound: fewer means waiting for a few of the oldest younger pieces too).
-template <int NOB, int KB0, bool ZEROC, int NBQ, int QB0, int GAP0, int VMY, int NW, int NBQA, class Side>
+template <int NOB, int KB0, bool ZEROC, int NBQ, int QB0, int GAP0, int VMY, int QSTR, int NW, int NBQA, class Side>
 __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW], const unsigned (&Plo)[NW], f32x16 (&acc)[NOB],
                                           f32x4 (&bq)[NBQA], unsigned baddr, Side&& side) {
     static_assert(8 % NOB == 0 && (KB0 + 8 / NOB) * 4 <= NW, "B planes too small");
@@ -212,7 +212,7 @@ __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW]
         } else {
             static_for<BPG>([&](auto sc) {
                 constexpr int q = j * BPG + decltype(sc)::value;
-                if constexpr (q < NBQ) lds_read16_v<(q >> 2) * 128 + (q & 3) * 16>(bq[QB0 + q], baddr);
+                if constexpr (q < NBQ) lds_read16_v<(q >> 2) * QSTR + (q & 3) * 16>(bq[QB0 + q], baddr);
             });
         }
         if constexpr ((i & 3) == 2) gs_fetch_piece(ws, ws.gidx + F16_LA, i >> 2);
@@ -256,12 +256,12 @@ __device__ __forceinline__ void f16_group(GStream& ws, const unsigned (&Phi)[NW]
 
 // NG consecutive groups on the same accumulator blocks: k-blocks KB0 .. of the planes, 8 / NOB per group; the first one reads
 // NBQ bias quads into bq[QB0 ..]
-template <int NOB, int NG, int KB0, int NBQ, int QB0, int GAP0, bool ZERO_FIRST, int VMY, int NW, int NBQA, class Side>
+template <int NOB, int NG, int KB0, int NBQ, int QB0, int GAP0, bool ZERO_FIRST, int VMY, int QSTR = 128, int NW, int NBQA, class Side>
 __device__ __forceinline__ void f16_pass(GStream& ws, const unsigned (&Phi)[NW], const unsigned (&Plo)[NW], f32x16 (&acc)[NOB],
                                          f32x4 (&bq)[NBQA], unsigned baddr, Side&& side) {
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        f16_group<NOB, KB0 + g * (8 / NOB), (ZERO_FIRST && g == 0), (g == 0 ? NBQ : 0), QB0, GAP0 + 24 * g, VMY>(ws, Phi, Plo, acc, bq, baddr, side);
+        f16_group<NOB, KB0 + g * (8 / NOB), (ZERO_FIRST && g == 0), (g == 0 ? NBQ : 0), QB0, GAP0 + 24 * g, VMY, QSTR>(ws, Phi, Plo, acc, bq, baddr, side);
     });
 }
 

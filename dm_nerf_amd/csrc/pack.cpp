@@ -253,6 +253,46 @@ extern "C" int dmnerf_build_pack_index_f16(int ins_num, int32_t* idx_tab, int64_
     return DMNERF_OK;
 }
 
+// ---- split-f16 W^T blob (layout.h::F16TLayout); sources: [flat parameters | F] like dmnerf_build_pack_index_t
+extern "C" int64_t dmnerf_blob_t_f16_words(int ins_num) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
+    return make_f16_layout_t(ins_num).total;
+}
+
+extern "C" int dmnerf_build_pack_index_t_f16(int ins_num, int32_t* idx, int64_t n_idx) {
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "build_pack_index_t_f16: ins_num %d unsupported", ins_num);
+    const F16TLayout S = make_f16_layout_t(ins_num);
+    const int64_t need = (S.total - S.stream) * 2;
+    if (!idx || n_idx != need) return dmn_fail(DMNERF_E_ARG, "build_pack_index_t_f16: need %lld index slots, got %lld", (long long)need, (long long)n_idx);
+    const Params P = make_params(ins_num);
+    for (int64_t i = 0; i < need; ++i) idx[i] = -1;
+    Lin F;
+    F.w_off = P.total; F.b_off = -1; F.out = HW; F.in = W;
+    struct TG { const Lin* l; int nob, ob0, kb0; };
+    std::vector<TG> groups;
+    for (int q = 0; q < S.OBI; ++q) groups.push_back({&P.ins_out, 4, 0, 2 * q});
+    for (int p = 0; p < 4; ++p)
+        for (int q = 0; q < 2; ++q) groups.push_back({&F, 2, 2 * p, 4 * q});
+    const Lin* stage[7] = {&P.mlps[7], &P.mlps[6], &P.mlps[5], &P.mlps[4], &P.mlps[3], &P.mlps[2], &P.mlps[1]};
+    for (int s = 0; s < 7; ++s)
+        for (int p = 0; p < 4; ++p)
+            for (int q = 0; q < 4; ++q) groups.push_back({stage[s], 2, 2 * p, 4 * q});
+    if ((int)groups.size() != S.n_groups) return dmn_fail(DMNERF_E_ARG, "build_pack_index_t_f16: internal group count");
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const TG& G = groups[gi];
+        for (int plane = 0; plane < 2; ++plane)
+            for (int i = 0; i < 8; ++i) {
+                const int kb = G.kb0 + i / G.nob, ob = G.ob0 + i % G.nob;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 8; ++q) {
+                        const int64_t src = G.l->w(cfeat(8 * kb + q, lane >> 5), ob * 32 + (lane & 31));
+                        idx[((int64_t)gi * 16 + plane * 8 + i) * 512 + lane * 8 + q] = src < 0 ? -1 : (int32_t)(src | ((int64_t)plane << 28));
+                    }
+            }
+    }
+    return DMNERF_OK;
+}
+
 extern "C" int64_t dmnerf_blob_t_floats(int ins_num) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return -1;
     return make_layout_t(ins_num).total;

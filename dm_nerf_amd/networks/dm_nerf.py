@@ -105,7 +105,7 @@ class DM_NeRF(nn.Module):
         ``.data`` (``p.data.add_(...)``, hand-written optimizers, EMA / weight-clipping code) do not bump ``_version``:
         call this after them, or the kernels keep using the stale copy."""
         self._blob_key = self._blob_t_key = self._flat_key = None
-        self._blob_f_key = self._blob_s_key = self._blob_ts_key = self._blob_h_key = None
+        self._blob_f_key = self._blob_s_key = self._blob_ts_key = self._blob_h_key = self._blob_th_key = None
 
     def flat(self):
         """The parameters as ONE flat f32 vector in state_dict order (what the packers gather from and what the backward's
@@ -159,6 +159,16 @@ class DM_NeRF(nn.Module):
             self._blob_h = weights.pack_blob_f16(state, self.ins_num)
             self._blob_h_key = key
         return self._blob_h
+
+    def blob_t_f16(self):
+        """Split-f16 W^T blob of the opt-in data-gradient kernel (training with ``args.mfma_split = "f16x2"``)."""
+        self._check_supported()
+        state = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in state.values())
+        if getattr(self, "_blob_th", None) is None or key != self._blob_th_key:
+            self._blob_th = weights.pack_blob_t_f16(self.flat(), self.ins_num)
+            self._blob_th_key = key
+        return self._blob_th
 
     def blob_t_split(self):
         """Split-bf16 W^T blob of the opt-in data-gradient kernel (training with ``args.mfma_split``)."""

@@ -175,6 +175,30 @@ def pack_blob_t_split(flat, ins_num):
     return blob
 
 
+def pack_blob_t_f16(flat, ins_num):
+    """The opt-in split-f16 data-gradient blob: [VALU-head table of the W^T blob | two f16 planes of every W^T, 16 KiB groups]."""
+    lib = _lib.load()
+    _lib.require_gpu(flat)
+    total = lib.dmnerf_blob_t_f16_words(ins_num)
+    if total <= 0:
+        raise ValueError(f"unsupported ins_num={ins_num}")
+    ext = torch.empty(flat.numel() + HEAD_F_FLOATS, dtype=torch.float32, device=flat.device)
+    ext[:flat.numel()] = flat
+    _lib.check(lib.dmnerf_head_product(_lib.ptr(flat), ins_num, _lib.ptr(ext[flat.numel():]), _lib.stream()), "dmnerf_head_product")
+    key = (ins_num, str(flat.device), "f16_t")
+    if key not in _index_cache:
+        n = (total - TAB_T_FLOATS) * 2
+        host = np.empty(n, dtype=np.int32)
+        _lib.check(lib.dmnerf_build_pack_index_t_f16(ins_num, host.ctypes.data_as(ctypes.c_void_p), n), "dmnerf_build_pack_index_t_f16")
+        _index_cache[key] = torch.from_numpy(host).to(flat.device)
+    idx = _index_cache[key]
+    blob = torch.empty(total, dtype=torch.float32, device=flat.device)
+    idx_tab = pack_index(ins_num, flat.device, True)[:TAB_T_FLOATS].contiguous()
+    _lib.check(lib.dmnerf_pack_weights(_lib.ptr(ext), _lib.ptr(idx_tab), _lib.ptr(blob), TAB_T_FLOATS, _lib.stream()), "dmnerf_pack_weights")
+    _lib.check(lib.dmnerf_pack_f16(_lib.ptr(ext), _lib.ptr(idx), _lib.ptr(blob[TAB_T_FLOATS:]), total - TAB_T_FLOATS, _lib.stream()), "dmnerf_pack_f16")
+    return blob
+
+
 def pack_blob(state, ins_num, out=None, transposed=False, fused=False, flat=None):
     """Build (or refresh in place) the kernel blob for one DM_NeRF model (``transposed``: the W^T
     blob of the backward data-gradient kernel; ``fused``: the inference blob with the feature linears folded

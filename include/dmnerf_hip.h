@@ -270,6 +270,16 @@ int dmnerf_mlp_fwd_rays_f16(const float* d_blob_f16, int ins_num, const float* d
 int dmnerf_mlp_fwd_rays_train_f16(const float* d_blob_f16, int ins_num, const float* d_rays_o, const float* d_rays_d,
                                   const float* d_z, int64_t N, int S, float* d_raw, float* d_save, void* stream);
 
+/* OPT-IN split-f16 data-gradient kernel (training with args.mfma_split = "f16x2"): the blob is [the first 1024 floats of the
+ * W^T blob (dmnerf_build_pack_index_t: the two VALU heads' table) | W^T stream of 16 KiB groups, two f16 planes]; the index (two
+ * int32 per stream word: source | plane << 28) addresses [flat parameters | F] like dmnerf_build_pack_index_t; dmnerf_pack_f16
+ * writes the stream.  Reads and writes exactly what dmnerf_mlp_bwd_data reads and writes (networks/dm_nerf.py:80-106 backward),
+ * f32-class, not its bitwise chain. */
+int64_t dmnerf_blob_t_f16_words(int ins_num);
+int dmnerf_build_pack_index_t_f16(int ins_num, int32_t* h_idx, int64_t n_idx);
+int dmnerf_mlp_bwd_data_f16(const float* d_blob_t_f16, int ins_num, const float* d_save, const float* d_graw, int64_t M,
+                            float* d_dsave, float* d_graw_t, void* stream);
+
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
  * (int32, values 0..ins_num; other values are ignored) -> out4 = {ins_loss_sum, valid_ce, invalid_ce,

@@ -356,8 +356,9 @@ def test_opt_in_fused_heads_training(A, mode):
     assert np.allclose(losses[True], losses[False], rtol=1e-4) and losses[True][2] < losses[True][0], losses
 
 
-def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A):
-    """The opt-in split-bf16 data-gradient kernel (csrc/mlp_bwd_split.hip) against the default f32 one on the SAME saved
+@pytest.mark.parametrize("flavour", ["bf16x3", "f16x2"])
+def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A, flavour):
+    """The opt-in split data-gradient kernels (csrc/mlp_bwd_split.hip: bf16x3; csrc/mlp_bwd_f16.hip: f16x2) against the default f32 one on the SAME saved
     forward and the same dL/draw: every dy tensor of the workspace (31 weight quarters' worth of products, masks applied) and
     the transposed d raw.  f32-class: per tensor  max|diff| <= 1e-5 * max|f32 result|  (six bf16 products per f32 product,
     f32 accumulation; the d raw copy is bit-equal).  Ragged M (tail block) and every logit-block count (OBI 1..3)."""
@@ -381,8 +382,9 @@ def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A):
             dsave = torch.full_like(save, float("nan"))
             gt = torch.full((Mp // 32, 4 + C, 32), float("nan"), device="cuda")
             if split:
-                _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(m.blob_t_split()), ins_num, _lib.ptr(save), _lib.ptr(graw), M_,
-                                                         _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd split")
+                fn, blob_t = (lib.dmnerf_mlp_bwd_data_split, m.blob_t_split()) if flavour == "bf16x3" else (lib.dmnerf_mlp_bwd_data_f16, m.blob_t_f16())
+                _lib.check(fn(_lib.ptr(blob_t), ins_num, _lib.ptr(save), _lib.ptr(graw), M_,
+                              _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd split")
             else:
                 _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(m.blob()), _lib.ptr(m.blob_t()), ins_num, _lib.ptr(save), _lib.ptr(graw), M_,
                                                    _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd")
@@ -400,7 +402,34 @@ def test_split_dgrad_kernel_vs_f32_dgrad_kernel(A):
         for s in range(lo, hi, step):
             x, y = a[s:s + step], b[s:s + step]
             scale = float(x.abs().max())
-            assert float((x - y).abs().max()) <= 1e-5 * scale + 1e-12, (ins_num, s // step, float((x - y).abs().max()), scale)
+            assert float((x - y).abs().max()) <= 1e-5 * scale + 1e-12, (flavour, ins_num, s // step, float((x - y).abs().max()), scale)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_split_backward_kernels_vs_oracle_autograd(A, mode, capsys):
+    """The opt-in split modes' BACKWARD against the oracle directly (not only against their f32 twins): forward + dgrad + wgrad of
+    the mode on the MLP alone (run_network_train), per-parameter gradients vs PyTorch autograd of the oracle's mlp_forward on the
+    same inputs and the same cotangent, ins_num 13 and 93, ragged sample counts.  Tolerance: the default path's
+    (max|diff| <= 2e-4 max|want| per tensor); the observed worst ratio is printed."""
+    worst = {}
+    for ins_num, seed, N, S in ((13, 71, 37, 64), (93, 72, 11, 50)):
+        sd = O.make_weights(seed, ins_num, gain=1.7)
+        g = torch.Generator().manual_seed(seed)
+        rays_o, rays_d = torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+        z = torch.sort(torch.rand(N, S, generator=g) * 5 + 1, -1)[0]
+        cot = torch.randn(N, S, 4 + ins_num + 1, generator=g)
+        raw_want, want = _oracle_mlp_grads(sd, rays_o, rays_d, z, cot)
+        m = model_from(A, sd, ins_num)
+        raw = A.G.run_network_train(m, rays_o.cuda(), rays_d.cuda(), z.cuda(), split=mode)
+        tclose(raw, raw_want, f"raw ({mode} training forward)", rel=1e-5)
+        (raw * cot.cuda()).sum().backward()
+        for k, p in m.named_parameters():
+            tclose(p.grad, want[k], f"grad {k} ({mode}, ins={ins_num})")
+            scale = float(want[k].abs().max())
+            if scale > 0:
+                worst[ins_num] = max(worst.get(ins_num, 0.0), float((p.grad.cpu() - want[k]).abs().max()) / scale)
+    with capsys.disabled():
+        print(f"\n[{mode} backward vs oracle autograd] worst per-tensor max|diff| / max|want|: {worst}")
 
 
 def test_split_wgrad_kernel_vs_f32_wgrad_kernel(A):
