@@ -203,6 +203,18 @@ class MLPRaysFunction(torch.autograd.Function):
         return (None, None, None, None, None) + _mlp_backward(ctx, g_raw)
 
 
+_scale_buffers = {}
+
+
+def _grad_scale_buffer(device):
+    """Per device: the 4 floats of dmnerf_grad_scale ({2^s, 2^-s, scratch, scratch}; zeroed once, the kernel keeps the scratch zero).
+    One buffer serves every backward on the device: the launches that write and read it are ordered on the stream."""
+    key = str(device)
+    if key not in _scale_buffers:
+        _scale_buffers[key] = torch.zeros(4, dtype=torch.float32, device=device)
+    return _scale_buffers[key]
+
+
 def _mlp_backward(ctx, g_raw):
     """dgrad + wgrad of one saved forward (rays or pre-embedded rows): the parameter gradients as views of one flat vector."""
     lib = _lib.load()
@@ -221,11 +233,16 @@ def _mlp_backward(ctx, g_raw):
     Mp = _row_len(M)
     gt = torch.empty(Mp // 32, 4 + C, 32, dtype=torch.float32, device=g.device)   # d raw, block-major, written by the kernel
     split = getattr(ctx, "blob_ts", None) is not None            # opt-in: split-bf16 backward kernels (args.mfma_split)
+    f16 = getattr(ctx, "mode", None) == "f16"
+    scale = _grad_scale_buffer(g.device) if f16 else None         # {2^s, 2^-s}: the f16 backward runs on 2^s dL/draw (f16 range)
     with _timed("mlp_bwd_data", M):
-        if split:
-            f_dgrad = lib.dmnerf_mlp_bwd_data_f16 if getattr(ctx, "mode", None) == "f16" else lib.dmnerf_mlp_bwd_data_split
-            _lib.check(f_dgrad(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
-                               _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split / _f16")
+        if f16:
+            _lib.check(lib.dmnerf_grad_scale(_lib.ptr(g), g.numel(), _lib.ptr(scale), _lib.stream()), "dmnerf_grad_scale")
+            _lib.check(lib.dmnerf_mlp_bwd_data_f16(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                                                   _lib.ptr(dsave), _lib.ptr(gt), _lib.ptr(scale), _lib.stream()), "dmnerf_mlp_bwd_data_f16")
+        elif split:
+            _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
+                                                     _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split")
         else:
             _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
@@ -238,9 +255,14 @@ def _mlp_backward(ctx, g_raw):
     if flat is None:
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)
     with _timed("mlp_bwd_weights", M):
-        f_wgrad = lib.dmnerf_mlp_bwd_weights_split if split else lib.dmnerf_mlp_bwd_weights
-        _lib.check(f_wgrad(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs), n_outs,
-                           _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat), _lib.stream()), "dmnerf_mlp_bwd_weights")
+        if f16:
+            _lib.check(lib.dmnerf_mlp_bwd_weights_split_scaled(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs),
+                                                               n_outs, _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat), _lib.ptr(scale),
+                                                               _lib.stream()), "dmnerf_mlp_bwd_weights_split_scaled")
+        else:
+            f_wgrad = lib.dmnerf_mlp_bwd_weights_split if split else lib.dmnerf_mlp_bwd_weights
+            _lib.check(f_wgrad(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs), n_outs,
+                               _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat), _lib.stream()), "dmnerf_mlp_bwd_weights")
     ctx.save = None
     return tuple(split_flat_grads(model, flat))
 

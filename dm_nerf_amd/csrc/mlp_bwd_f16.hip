@@ -20,8 +20,46 @@ struct BwdHArgs {
     const float* graw;     // [M, 4+C]
     float* dsave;          // gradients, same SaveLayout
     float* graw_t;         // d raw block-major [blk][4+C][32]
+    const float* scale;    // nullable: {2^s, 2^-s} from dmnerf_grad_scale -- dL/draw is multiplied by 2^s on the way in
     int64_t M;
 };
+
+// f16 has 5 exponent bits: the data gradients of a real training step (dL/draw ~ 1e-4 / rays, dy smaller still) would sit in
+// its subnormal range.  The whole backward is LINEAR in dL/draw, so it runs on 2^s dL/draw with s = 6 - ceil(log2 max|dL/draw|)
+// (max 64: three decades of headroom for growth through the layers, 2^-2 .. 64 at full two-plane precision) and the weight-
+// gradient reduction multiplies by 2^-s -- both exact.  One pass over dL/draw; the last block to finish writes the factors.
+__global__ void grad_scale_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out4) {
+    unsigned mx = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned u = __float_as_uint(g[i]) & 0x7fffffffu;
+        mx = (u < 0x7f800000u && u > mx) ? u : mx;               // (inf / nan do not set the scale)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
+    unsigned* scratch = reinterpret_cast<unsigned*>(out4) + 2;    // [2] = running max (bits), [3] = blocks done; both zero between calls
+    if ((threadIdx.x & 63) == 0) atomicMax(scratch, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(scratch + 1, 1u) == gridDim.x - 1) {
+            const unsigned all = atomicMax(scratch, 0u);
+            float sc = 1.f;
+            if (all != 0u) {
+                int e;
+                (void)frexpf(__uint_as_float(all), &e);          // max = f 2^e, f in [0.5, 1)  ->  2^(6 - e) max in [32, 64)
+                int s = 6 - e;
+                s = s > 120 ? 120 : (s < -120 ? -120 : s);
+                sc = ldexpf(1.f, s);
+            }
+            out4[0] = sc;
+            out4[1] = 1.f / sc;
+            scratch[0] = 0u;
+            scratch[1] = 0u;
+            __threadfence();
+        }
+    }
+}
+
 
 // The epilogue of a finished dgrad pass, dealt out over the MFMA gaps of the next one like mlp_f16_impl.h::EpiFwd:
 //   phase 0 : 2 v_accvgpr_read (+ HASQ: the density term  w_d g_sigma, one fma each)
@@ -116,8 +154,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_f16_kernel(const BwdHArgs a) {
 
     // ---- incoming gradient (tail lanes: zero), d raw transposed, bit masks, table: as mlp_bwd.hip
     const float* __restrict__ gr = a.graw + m * (4 + L.C);
-    const float g_rgb[3] = {valid ? gr[0] : 0.f, valid ? gr[1] : 0.f, valid ? gr[2] : 0.f};
-    const float g_sigma = valid ? gr[3] : 0.f;
+    const float gsc = a.scale ? a.scale[0] : 1.f;                // power of two: every product below is exact
+    const float g_rgb[3] = {valid ? gr[0] * gsc : 0.f, valid ? gr[1] * gsc : 0.f, valid ? gr[2] * gsc : 0.f};
+    const float g_sigma = valid ? gr[3] * gsc : 0.f;
     const int GR = 4 + L.C;
     rsrc_t grs = uniform_rsrc(a.graw_t, a.graw_t ? (int64_t)GR * MP : 0);
     const int gv = (int)((blk * GR * 32 + (lane & 31)) * 4);
@@ -131,7 +170,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_f16_kernel(const BwdHArgs a) {
                 const int ch = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const bool in = ch < L.C;
                 const float v = gr[4 + (in ? ch : L.C - 1)];
-                gi[b][r] = (in && valid) ? v : 0.f;
+                gi[b][r] = (in && valid) ? v * gsc : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b32(f2u(gi[b][r]), grs, in ? gv + (4 + ch) * 128 : 0x7ffffff0, 0, 0);
             }
         split_blocks_f16<OBI>(gi, Pgi[0], Pgi[1]);
@@ -270,15 +309,22 @@ __global__ __launch_bounds__(256) void mlp_bwd_f16_kernel(const BwdHArgs a) {
 
 }  // namespace
 
+extern "C" int dmnerf_grad_scale(const float* d_graw, int64_t n, float* d_scale4, void* stream) {
+    if (!d_graw || !d_scale4 || n < 1) return dmn_fail(DMNERF_E_ARG, "grad_scale: bad argument");
+    const unsigned blocks = (unsigned)((n + 1023) / 1024 < 512 ? (n + 1023) / 1024 : 512);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_graw, n, d_scale4);
+    return dmn_check_launch("grad_scale");
+}
+
 extern "C" int dmnerf_mlp_bwd_data_f16(const float* d_blob_t_f16, int ins_num, const float* d_save, const float* d_graw, int64_t M,
-                                       float* d_dsave, float* d_graw_t, void* stream) {
+                                       float* d_dsave, float* d_graw_t, const float* d_scale, void* stream) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data_f16: ins_num %d unsupported", ins_num);
     if (M < 0 || M > DMNERF_MAX_TRAIN_SAMPLES) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data_f16: M=%lld outside [0,%lld]", (long long)M, (long long)DMNERF_MAX_TRAIN_SAMPLES);
     if (M == 0) return DMNERF_OK;
     if (!d_blob_t_f16 || !d_save || !d_graw || !d_dsave) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_data_f16: null pointer");
     BwdHArgs a{};
     a.blob = d_blob_t_f16; a.L = make_layout(ins_num); a.LT = make_layout_t(ins_num); a.S = make_f16_layout_t(ins_num);
-    a.save = d_save; a.graw = d_graw; a.dsave = d_dsave; a.graw_t = d_graw_t; a.M = M;
+    a.save = d_save; a.graw = d_graw; a.dsave = d_dsave; a.graw_t = d_graw_t; a.scale = d_scale; a.M = M;
     const int64_t nblk = (M + 31) / 32;
     dim3 g((unsigned)((nblk + 3) / 4)), b(256);
     constexpr size_t lds_bytes = (size_t)(F16_RING_FLOATS + TAB_T_FLOATS) * sizeof(float);

@@ -177,9 +177,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
 }
 
 // Adds the per-slice partials in slice order into the flat gradient vector.
+// unscale: null, or the factor 2^-s that undoes the power-of-two scaling the split-f16 data-gradient kernel applied to dL/draw
+// (every operand of every job on the dy side carries it: the sums are linear in it)
 __global__ void wgrad_reduce_kernel(float* __restrict__ part, const WgOut* __restrict__ outs, int n_outs,
-                                    float* __restrict__ grad_flat) {
+                                    float* __restrict__ grad_flat, const float* __restrict__ unscale) {
     const WgOut o = outs[blockIdx.y];
+    const float us = unscale ? *unscale : 1.f;
     float* __restrict__ grad = o.to_scratch ? part : grad_flat;        // (the bias of a scratch output still goes to the gradient)
     const int64_t n_w = (int64_t)o.rowsA * o.rowsB;
     const int64_t n_all = n_w + (o.bias_out_off >= 0 ? o.rowsA : 0);
@@ -199,13 +202,13 @@ __global__ void wgrad_reduce_kernel(float* __restrict__ part, const WgOut* __res
             }
             for (; k < o.n_slices; ++k) s += p[k * o.slice_stride];
             const int ro = o.perm_a ? row_feature(r) : r, co = o.perm_b ? row_feature(c) : c;
-            grad[o.out_off + (int64_t)ro * o.ld_out + o.col_off + co] = s;
+            grad[o.out_off + (int64_t)ro * o.ld_out + o.col_off + co] = s * us;
         } else {
             const int r = (int)(e - n_w);
             const float* p = part + o.bias_part_off + r;
             for (int k = 0; k < o.n_slices; ++k)
                 for (int q = 0; q < o.bias_sub; ++q) s += p[k * o.bias_slice_stride + (int64_t)q * o.ldb];
-            grad_flat[o.bias_out_off + (o.perm_a ? row_feature(r) : r)] = s;
+            grad_flat[o.bias_out_off + (o.perm_a ? row_feature(r) : r)] = s * us;
         }
     }
 }
@@ -398,8 +401,9 @@ extern "C" int dmnerf_mlp_bwd_weights(const float* d_save, const float* d_dsave,
     return dmn_wgrad_finish(d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, (hipStream_t)stream);
 }
 
-int dmn_wgrad_finish(const void* d_outs, int n_outs, const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, hipStream_t stream) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, (unsigned)n_outs), dim3(256), 0, stream, d_part, (const WgOut*)d_outs, n_outs, d_grad_flat);
+int dmn_wgrad_finish(const void* d_outs, int n_outs, const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, hipStream_t stream,
+                     const float* d_unscale) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, (unsigned)n_outs), dim3(256), 0, stream, d_part, (const WgOut*)d_outs, n_outs, d_grad_flat, d_unscale);
     const int rc = dmn_check_launch("mlp_bwd_weights: reduce");
     if (rc) return rc;
     // rgb_feature_linear(s) / ins_feature_linear(s) from G, Q and the hidden layers' bias gradients (heads.hip)

@@ -11,7 +11,8 @@
 using namespace dmn;
 
 // wgrad.hip: second stage (fixed-order sum of the per-slice partials) + the feature-linear gradients from G / Q (heads.hip)
-int dmn_wgrad_finish(const void* d_outs, int n_outs, const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, hipStream_t stream);
+int dmn_wgrad_finish(const void* d_outs, int n_outs, const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, hipStream_t stream,
+                     const float* d_unscale = nullptr);
 
 namespace {
 

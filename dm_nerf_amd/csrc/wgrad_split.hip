@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(const WgArgs a) {
 
 }  // namespace
 
-extern "C" int dmnerf_mlp_bwd_weights_split(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
-                                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
-                                            const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream) {
+static int wgrad_split_launch(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                              const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                              const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, const float* d_unscale, void* stream) {
     if (!d_save || !d_dsave || !d_graw_t || !d_jobs || !d_outs || !d_params_flat || !d_part || !d_grad_flat || M < 1 || n_jobs < 1 || n_outs < 1)
         return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights_split: bad argument");
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights_split: ins_num %d unsupported", ins_num);
@@ -333,5 +333,18 @@ extern "C" int dmnerf_mlp_bwd_weights_split(const float* d_save, const float* d_
     hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)n_jobs), dim3(256), lds_bytes, (hipStream_t)stream, a);
     const int rc = dmn_check_launch("mlp_bwd_weights_split");
     if (rc) return rc;
-    return dmn_wgrad_finish(d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, (hipStream_t)stream);
+    return dmn_wgrad_finish(d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, (hipStream_t)stream, d_unscale);
+}
+
+extern "C" int dmnerf_mlp_bwd_weights_split(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                                            const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream) {
+    return wgrad_split_launch(d_save, d_dsave, d_graw_t, M, d_jobs, n_jobs, d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, nullptr, stream);
+}
+
+// the same kernel with the gradient unscaling of the split-f16 chain (d_scale: dmnerf_grad_scale's {2^s, 2^-s})
+extern "C" int dmnerf_mlp_bwd_weights_split_scaled(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                                                   const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                                                   const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, const float* d_scale, void* stream) {
+    return wgrad_split_launch(d_save, d_dsave, d_graw_t, M, d_jobs, n_jobs, d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, d_scale ? d_scale + 1 : nullptr, stream);
 }

@@ -274,11 +274,24 @@ int dmnerf_mlp_fwd_rays_train_f16(const float* d_blob_f16, int ins_num, const fl
  * W^T blob (dmnerf_build_pack_index_t: the two VALU heads' table) | W^T stream of 16 KiB groups, two f16 planes]; the index (two
  * int32 per stream word: source | plane << 28) addresses [flat parameters | F] like dmnerf_build_pack_index_t; dmnerf_pack_f16
  * writes the stream.  Reads and writes exactly what dmnerf_mlp_bwd_data reads and writes (networks/dm_nerf.py:80-106 backward),
- * f32-class, not its bitwise chain. */
+ * f32-class, not its bitwise chain.
+ */
 int64_t dmnerf_blob_t_f16_words(int ins_num);
 int dmnerf_build_pack_index_t_f16(int ins_num, int32_t* h_idx, int64_t n_idx);
+/* Gradient scaling.  f16 has 5 exponent bits and the data gradients of a real training step sit far below its normal range, so
+ * the split-f16 backward runs on 2^s dL/draw (the whole backward is linear in it; s = 6 - ceil(log2 max|dL/draw|), exact) and
+ * the weight-gradient reduction multiplies by 2^-s: dmnerf_grad_scale reduces max|d_graw[0..n)| and writes d_scale4 = {2^s,
+ * 2^-s, scratch, scratch} (4 floats the caller zeroes ONCE; the kernel leaves the scratch words zero); d_scale = that buffer,
+ * or null for s = 0.  With a scale, every row the kernel writes (d_dsave, d_graw_t) carries the factor 2^s. */
+int dmnerf_grad_scale(const float* d_graw, int64_t n, float* d_scale4, void* stream);
 int dmnerf_mlp_bwd_data_f16(const float* d_blob_t_f16, int ins_num, const float* d_save, const float* d_graw, int64_t M,
-                            float* d_dsave, float* d_graw_t, void* stream);
+                            float* d_dsave, float* d_graw_t, const float* d_scale, void* stream);
+/* dmnerf_mlp_bwd_weights_split on operands that carry the factor 2^s of dmnerf_grad_scale: the second stage multiplies every
+ * gradient by d_scale[1] = 2^-s (null: 1). */
+int dmnerf_mlp_bwd_weights_split_scaled(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                                        const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                                        const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat,
+                                        const float* d_scale, void* stream);
 
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]
