@@ -5,7 +5,7 @@ from dm_nerf_amd import _lib
 from dm_nerf_amd.networks import dm_nerf as M
 from oracle import ref_cpu as O
 lib = _lib.load()
-for ins_num, N, S, seed in ((13, 8, 64, 15), (13, 37, 64, 71), (13, 64, 192, 3)):
+for ins_num, N, S, seed in ((13, 6, 64, 71), (13, 6, 64, 74), (13, 6, 64, 75), (13, 6, 64, 76)):
     sd = O.make_weights(seed, ins_num, gain=1.7)
     m = M.DM_NeRF(8, 256, 63, 27, [4], ins_num); m.load_state_dict(sd); m = m.cuda()
     g = torch.Generator().manual_seed(seed)
