@@ -96,7 +96,7 @@ SIGNATURES = {
     "dmnerf_build_pack_index_t_f16": (c_int, [c_int, c_vp, c_i64]),
     "dmnerf_grad_scale": (c_int, [c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_mlp_bwd_data_f16": (c_int, [c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
-    "dmnerf_mlp_bwd_weights_split_scaled": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_mlp_bwd_weights_f16": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_mlp_fwd_rays_train_f16": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_blob_fused_floats": (c_i64, [c_int]),
     "dmnerf_build_pack_index_fused": (c_int, [c_int, c_vp, c_i64]),

@@ -256,9 +256,9 @@ def _mlp_backward(ctx, g_raw):
         flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g.device)
     with _timed("mlp_bwd_weights", M):
         if f16:
-            _lib.check(lib.dmnerf_mlp_bwd_weights_split_scaled(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs),
+            _lib.check(lib.dmnerf_mlp_bwd_weights_f16(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs),
                                                                n_outs, _lib.ptr(ctx.flat), ins_num, _lib.ptr(part), _lib.ptr(flat), _lib.ptr(scale),
-                                                               _lib.stream()), "dmnerf_mlp_bwd_weights_split_scaled")
+                                                               _lib.stream()), "dmnerf_mlp_bwd_weights_f16")
         else:
             f_wgrad = lib.dmnerf_mlp_bwd_weights_split if split else lib.dmnerf_mlp_bwd_weights
             _lib.check(f_wgrad(_lib.ptr(ctx.save), _lib.ptr(dsave), _lib.ptr(gt), M, _lib.ptr(jobs), n_jobs, _lib.ptr(outs), n_outs,

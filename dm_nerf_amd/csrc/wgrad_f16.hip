@@ -1,24 +1,21 @@
-// wgrad_split.hip -- OPT-IN weight-gradient kernel on the split-bf16 MFMA path (training with args.mfma_split).
+// wgrad_f16.hip -- OPT-IN weight-gradient kernel on the split-f16 MFMA path (training with args.mfma_split = "f16x2").
 //
-// The split-K plan, the LDS ring and its LDS-DMA, the wave partition of an output tile, the partial-tile epilogue and the
-// second stage are those of wgrad.hip (wgrad_common.h); only the product changes: both operands of  dW = dy . x^T  are f32
-// activations, so a lane's 8 samples of a row (two ds_read_b128) are split ON THE FLY into three planes of packed bf16
-// pairs (split_bf16.h) and one 16-sample step of a tile pair is six v_mfma_f32_32x32x16_bf16 (hi hi, hi mid, hi lo, mid hi,
-// mid mid, lo hi) instead of eight v_mfma_f32_32x32x2_f32: 96 NBA NBB MFMA cycles per 32-sample chunk instead of 256 NBA NBB.
-// Measured: a 32-sample chunk of a 256 x 256 job 7 025 -> 4 436 ns (its MFMAs alone: 2 560 ns at 2.4 GHz); the
-// skinny jobs were HBM- / hand-over-bound already and do not move.
+// wgrad_split.hip with two f16 planes instead of three bf16 planes: the split-K plan, the LDS ring and its LDS-DMA, the wave
+// partition of an output tile, the partial-tile epilogue and the second stage are those of wgrad.hip (wgrad_common.h); both
+// operands of  dW = dy . x^T  are f32 activations, so a lane's 8 samples of a row (two ds_read_b128) are split ON THE FLY into
+// two planes of packed f16 pairs (split_f16.h: v_cvt_pkrtz_f16_f32 + v_fma_mix_f32, 4 instructions per pair instead of 11)
+// and one 16-sample step of a tile pair is THREE v_mfma_f32_32x32x16_f16 (hi hi, hi lo, lo hi): 48 NBA NBB MFMA cycles per
+// 32-sample chunk instead of 96 (bf16x3) / 256 (f32).  The dy operand carries the power-of-two factor of dmnerf_grad_scale
+// (f16 range), which the second stage removes.  With the MFMA time halved again the 256 x 256 jobs sit on the HBM stream of
+// their operands (64 KiB per chunk and workgroup: 2.7 us at 6.3 TB/s against 1.3 us of MFMA issue), so the schedule below
+// keeps wgrad_split.hip's structure and only has to stay under that shadow:
 //
-// Schedule: a chunk is 2 steps of 16 samples; a step is IS "items" (GA A blocks against the wave's SBn B blocks = 6 GA SBn
-// MFMAs, at least four accumulators in rotation wherever the tile has them).  While the MFMAs of item i run, the raw A
-// operands of item i + 1 are split and the LDS reads of item i + 2 are issued; the B operands of the NEXT step are read in a
-// step's first item (the hand-over item when that step belongs to the next chunk) and split over the rest of the step.  All
-// of it is placed per MFMA gap: a one-wave-per-SIMD kernel hides ~5 single-issue instructions per MFMA, so the split of an
-// operand pair is cut into two units of 5 / 6 instructions and the units of a chunk are spread evenly (no packed f32 VALU:
-// split_bf16.h::split_pair_scalar's arithmetic, this file is built with -fno-slp-vectorize).  B planes are double-buffered
-// by step, A planes and raw operands by item.  The ring hand-over sits at the start of the chunk's last-but-one item (every
-// read of the chunk has returned by then), the refill pieces follow it three gaps apart.
-// f32-class results (not the bitwise fmaf chain of wgrad.hip), hence opt-in.
-#include "split_bf16.h"
+// a chunk is 2 steps of 16 samples; a step is IS "items" (GA A blocks against the wave's SBn B blocks = 3 GA SBn MFMAs).  While
+// the MFMAs of item i run, the raw A operands of item i + 1 are split and the LDS reads of item i + 2 are issued; the B
+// operands of the NEXT step are read in a step's first item (the hand-over item when that step belongs to the next chunk) and
+// split over the rest of the step.  An item has NG slots = its MFMAs, or a few more where the tile is too small to give every
+// read its own slot.  f32-class results (not the bitwise fmaf chain of wgrad.hip), hence opt-in.
+#include "split_f16.h"
 #include "wgrad_common.h"
 
 extern long long* g_dmn_wgrad_trace;      // wgrad.hip
@@ -48,17 +45,18 @@ struct SplitS {
 // v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md), so the split of an operand pair is cut into two units of 5 / 6 VALU
 // instructions (stage 1: hi word + first residuals; stage 2: mid and lo words) and the units are spread evenly.
 constexpr int spread(int u, int n, int g0, int g1) { return g0 + (int)((long long)u * (g1 - g0) / n); }      // unit u of n over gaps [g0, g1)
-#ifndef DMN_WGS_REFILL_SPREAD
-#define DMN_WGS_REFILL_SPREAD 3            // gaps per refill piece after the hand-over
+#ifndef DMN_WGH_REFILL_SPREAD
+#define DMN_WGH_REFILL_SPREAD 3            // gaps per refill piece after the hand-over
 #endif
 constexpr int refill_gap(int p, int NG2, int NL) {
-    const int g = p * DMN_WGS_REFILL_SPREAD;
-    return (NL - 1) * DMN_WGS_REFILL_SPREAD < NG2 ? g : p * NG2 / NL;
+    const int g = p * DMN_WGH_REFILL_SPREAD;
+    return (NL - 1) * DMN_WGH_REFILL_SPREAD < NG2 ? g : p * NG2 / NL;
 }
-constexpr int TERM_A[6] = {0, 0, 0, 1, 1, 2}, TERM_B[6] = {0, 1, 2, 0, 1, 0};
+constexpr int NT = 3;                      // products per f32 product: hi hi, hi lo, lo hi
+constexpr int TERM_A[NT] = {0, 0, 1}, TERM_B[NT] = {0, 1, 0};
 
 template <int NBA, int NBB>
-__device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, float* lds) {
+__device__ __forceinline__ void run_job_f16(const WgArgs& a, const WgJob& jb, float* lds) {
     typedef SplitS<NBA, NBB> SP;
     typedef Ring<NBA, NBB> RG;
     constexpr int SAn = SP::SAn, SBn = SP::SBn, NPAIR = SAn * SBn;
@@ -69,17 +67,18 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
     constexpr int NACC = GA * SBn;
     constexpr int IS = SAn / GA;                   // items per 16-sample step (1 or 4)
     constexpr int NI = 2 * IS;                     // items per chunk
-    constexpr int NG = 6 * NACC;                   // MFMAs per item
+    constexpr int NGM = NT * NACC;                 // MFMAs per item
     constexpr int NUA = 8 * GA, NUB = 8 * SBn, NUS = 2 * GA;      // split units of an item's A blocks / of a step's B blocks; row-sum units
     constexpr int NRA = 2 * GA, NRB = 2 * SBn;     // LDS reads of an item's A blocks / of a step's B blocks
     constexpr int RB = IS == 1 ? 2 : 1;            // raw B buffers
     constexpr int NL = NBA + NBB;                  // DMA pieces per wave per chunk (1 KiB each)
     constexpr int H = NI - 2;                      // the hand-over sits at the start of this item
-    constexpr int WB = NRA + NRB + 6;              // IS > 1: gap (of the item that issues a step's B reads) from which its B units may run
+    constexpr int NG = NGM >= NRA + NRB && 2 * NGM >= NL ? NGM : (NRA + NRB > (NL + 1) / 2 ? NRA + NRB : (NL + 1) / 2);   // slots per item
+    constexpr int WB = NRA + NRB + 4;              // IS > 1: slot (counted from the item that issues a step's B reads) from which its B units may run
     constexpr int D = RG::D, BUF = RG::BUF;
     static_assert(IS == 1 || IS == 4, "items per step");
     static_assert((D - 1) * NL <= 63, "vmcnt range");
-    static_assert(NG >= NRA + NRB && 2 * NG >= NL && (IS == 1 || WB < NG), "gaps for the reads / the refill");
+    static_assert(NG >= NRA + NRB && 2 * NG >= NL && (IS == 1 || WB < 2 * NG), "slots for the reads / the refill");
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = lds_addr(lds);
@@ -123,26 +122,22 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
     const int my_rank = SP::share_rank(w);
 
     f32x4 rawA[2][GA][2], rawB[RB][SBn][2];           // [item parity][block][read], [step parity if RB == 2][block][read]
-    unsigned PA[2][GA][3][4], PB[2][SBn][3][4];         // [item parity][block][plane][word], [step parity][block][plane][word]
-    float tA[GA][4][2], tB[SBn][4][2];                  // first residuals of the pairs between their two units
+    unsigned PA[2][GA][2][4], PB[2][SBn][2][4];         // [item parity][block][plane][word], [step parity][block][plane][word]
+    float tA[GA][4], tB[SBn][4];                        // first residual of a pair between its two units
 
-    // unit u = 2 q + stage of the block (r -> P): stage 0 = hi word + first residuals, stage 1 = mid and lo words.  The pins
-    // keep a unit in ITS gap (without them the compiler sinks the work to its first use).
-    auto unit = [](const f32x4 (&r)[2], unsigned (&P)[3][4], float (&t)[4][2], auto uc) {
+    // unit u = 2 q + stage of the block (r -> P): stage 0 = hi word + the first residual, stage 1 = the second residual + lo word
+    // (2 instructions each; the residual x - hi is ONE v_fma_mix_f32 reading the f16 half of the packed word).  volatile asm
+    // keeps a unit in ITS slot.
+    auto unit = [](const f32x4 (&r)[2], unsigned (&P)[2][4], float (&t)[4], auto uc) {
         constexpr int u = decltype(uc)::value, q = u >> 1;
+        const float x0 = r[q >> 1][2 * (q & 1)], x1 = r[q >> 1][2 * (q & 1) + 1];
         if constexpr ((u & 1) == 0) {
-            const float x0 = r[q >> 1][2 * (q & 1)], x1 = r[q >> 1][2 * (q & 1) + 1];
-            const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-            P[0][q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-            t[q][0] = x0 - __uint_as_float(u0 & 0xffff0000u);
-            t[q][1] = x1 - __uint_as_float(u1 & 0xffff0000u);
-            asm volatile("" : "+v"(P[0][q]), "+v"(t[q][0]), "+v"(t[q][1]));
+            asm volatile("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+                         "v_fma_mix_f32 %1, -%0, 1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(P[0][q]), "=&v"(t[q]) : "v"(x0), "v"(x1));
         } else {
-            const unsigned v0 = __float_as_uint(t[q][0]), v1 = __float_as_uint(t[q][1]);
-            P[1][q] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-            const float q0 = t[q][0] - __uint_as_float(v0 & 0xffff0000u), q1 = t[q][1] - __uint_as_float(v1 & 0xffff0000u);
-            P[2][q] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-            asm volatile("" : "+v"(P[1][q]), "+v"(P[2][q]));
+            float t1;
+            asm volatile("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(t1) : "v"(P[0][q]), "v"(x1));
+            asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(P[1][q]) : "v"(t[q]), "v"(t1));
         }
     };
     auto read_a = [&](auto itc, auto gc, unsigned slot) {           // read g of the A blocks of item `it` (ring slot at byte `slot`)
@@ -223,7 +218,8 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
             // IS > 1: the B operands of the next step are read in the step's first item -- the hand-over item when the step
             // belongs to the next chunk -- and split from gap WB of that item to the end of the step
             constexpr int ibr = s == 0 ? 0 : H;                          // (IS > 1) item of step s that issues them
-            constexpr int bspan = (NI / 2 - (ibr - s * IS)) * NG - WB;   // gaps their units are spread over
+            constexpr int bspan = (NI / 2 - (ibr - s * IS)) * NG - WB;   // slots their units are spread over
+            static_assert(IS == 1 || bspan >= 4, "B units");
             wait_a(std::integral_constant<int, i1>{});
             if constexpr (IS == 1) wait_b(std::integral_constant<int, s1>{});
             if constexpr (i == H) {
@@ -242,9 +238,9 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
                 if constexpr (g < NRA) read_a(std::integral_constant<int, i2>{}, gc, n2 ? nb : sb);
                 if constexpr (IS == 1) {
                     if constexpr (g >= NRA && g < NRA + NRB) read_b(std::integral_constant<int, s2>{}, std::integral_constant<int, g - NRA>{}, n2 ? nb : sb);
-                } else if constexpr (i == ibr) {
-                    if constexpr (g >= NRA && g < NRA + NRB) read_b(std::integral_constant<int, sn>{}, std::integral_constant<int, g - NRA>{}, s == 1 ? nb : sb);
-                    if constexpr (g == WB) wait_b(std::integral_constant<int, sn>{});      // (issued >= 6 gaps ago)
+                } else {
+                    if constexpr (i == ibr && g >= NRA && g < NRA + NRB) read_b(std::integral_constant<int, sn>{}, std::integral_constant<int, g - NRA>{}, s == 1 ? nb : sb);
+                    if constexpr (i >= ibr && (i - ibr) * NG + g == WB) wait_b(std::integral_constant<int, sn>{});      // (issued >= 4 slots ago)
                 }
                 // -- split units of the A blocks of item i + 1
                 static_for<NUA>([&](auto uc) {
@@ -266,16 +262,17 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
                 if constexpr (i >= H)                                     // refill the released slot with chunk c + D
                     static_for<NL>([&](auto pc) {
                         constexpr int p = decltype(pc)::value;
-#ifdef DMN_WGS_NODMA           // timing experiment: no refills (stale operands)
+#ifdef DMN_WGH_NODMA           // timing experiment: no refills (stale operands)
                         if constexpr (false)
 #endif
                         if constexpr (refill_gap(p, 2 * NG, NL) == (i - H) * NG + g) dma_piece(rfA, rfB, sb, p);
                     });
                 constexpr int ai = (ig * GA + ka) * SBn + ib;
-#ifdef DMN_WGS_NOMFMA          // timing experiment: everything but the MFMAs (one in six kept for the dependences)
+#ifdef DMN_WGH_NOMFMA          // timing experiment: everything but the MFMAs (one in six kept for the dependences)
                 if constexpr (term == 0)
 #endif
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b(PA[i & 1][ka][TERM_A[term]]), as_b(PB[s & 1][ib][TERM_B[term]]), acc[ai], 0, 0, 0);
+                if constexpr (g < NGM)
+                    acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_bh(PA[i & 1][ka][TERM_A[term < NT ? term : 0]]), as_bh(PB[s & 1][ib][TERM_B[term < NT ? term : 0]]), acc[ai], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -295,20 +292,20 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
     store_partials<SP, NBA, NBB>(a, jb, acc, bs, w, half, li, want_bias, my_rank);
 }
 
-__global__ __launch_bounds__(256) void wgrad_split_kernel(const WgArgs a) {
+__global__ __launch_bounds__(256) void wgrad_f16_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WgJob jb = a.jobs[blockIdx.x];
     if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = (long long)wall_clock64();
     switch (jb.cls) {                                  // workgroup-uniform
-        case C_8_8: run_job_split<8, 8>(a, jb, lds); break;
-        case C_4_8: run_job_split<4, 8>(a, jb, lds); break;
-        case C_8_2: run_job_split<8, 2>(a, jb, lds); break;
-        case C_4_1: run_job_split<4, 1>(a, jb, lds); break;
-        case C_1_8: run_job_split<1, 8>(a, jb, lds); break;
-        case C_1_4: run_job_split<1, 4>(a, jb, lds); break;
-        case C_2_4: run_job_split<2, 4>(a, jb, lds); break;
-        case C_3_4: run_job_split<3, 4>(a, jb, lds); break;
-        case C_4_4: run_job_split<4, 4>(a, jb, lds); break;
+        case C_8_8: run_job_f16<8, 8>(a, jb, lds); break;
+        case C_4_8: run_job_f16<4, 8>(a, jb, lds); break;
+        case C_8_2: run_job_f16<8, 2>(a, jb, lds); break;
+        case C_4_1: run_job_f16<4, 1>(a, jb, lds); break;
+        case C_1_8: run_job_f16<1, 8>(a, jb, lds); break;
+        case C_1_4: run_job_f16<1, 4>(a, jb, lds); break;
+        case C_2_4: run_job_f16<2, 4>(a, jb, lds); break;
+        case C_3_4: run_job_f16<3, 4>(a, jb, lds); break;
+        case C_4_4: run_job_f16<4, 4>(a, jb, lds); break;
         default: break;
     }
     if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = (long long)wall_clock64();
@@ -316,28 +313,23 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(const WgArgs a) {
 
 }  // namespace
 
-static int wgrad_split_launch(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
-                              const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
-                              const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, const float* d_unscale, void* stream) {
+extern "C" int dmnerf_mlp_bwd_weights_f16(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                                          const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                                          const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, const float* d_scale, void* stream) {
     if (!d_save || !d_dsave || !d_graw_t || !d_jobs || !d_outs || !d_params_flat || !d_part || !d_grad_flat || M < 1 || n_jobs < 1 || n_outs < 1)
-        return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights_split: bad argument");
-    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights_split: ins_num %d unsupported", ins_num);
+        return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights_f16: bad argument");
+    if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_bwd_weights_f16: ins_num %d unsupported", ins_num);
     WgArgs a{};
     a.src[0] = d_save; a.src[1] = d_dsave; a.src[2] = d_graw_t;
     a.part = d_part; a.jobs = (const WgJob*)d_jobs; a.Mp = save_row_len(M); a.trace = g_dmn_wgrad_trace;
     const size_t lds_bytes = WG_LDS_BYTES;
     static DmnOncePerDevice once;
-    if (hipError_t e = once.run([&] { return hipFuncSetAttribute((const void*)wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); });
+    if (hipError_t e = once.run([&] { return hipFuncSetAttribute((const void*)wgrad_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); });
         e != hipSuccess)
-        return dmn_fail_hip(e, "mlp_bwd_weights_split: hipFuncSetAttribute");
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)n_jobs), dim3(256), lds_bytes, (hipStream_t)stream, a);
-    const int rc = dmn_check_launch("mlp_bwd_weights_split");
+        return dmn_fail_hip(e, "mlp_bwd_weights_f16: hipFuncSetAttribute");
+    hipLaunchKernelGGL(wgrad_f16_kernel, dim3((unsigned)n_jobs), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    const int rc = dmn_check_launch("mlp_bwd_weights_f16");
     if (rc) return rc;
-    return dmn_wgrad_finish(d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, (hipStream_t)stream, d_unscale);
-}
-
-extern "C" int dmnerf_mlp_bwd_weights_split(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
-                                            const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
-                                            const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat, void* stream) {
-    return wgrad_split_launch(d_save, d_dsave, d_graw_t, M, d_jobs, n_jobs, d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, nullptr, stream);
+    // the dy operands carry the factor 2^s of dmnerf_grad_scale: the second stage multiplies by d_scale[1] = 2^-s
+    return dmn_wgrad_finish(d_outs, n_outs, d_params_flat, ins_num, d_part, d_grad_flat, (hipStream_t)stream, d_scale ? d_scale + 1 : nullptr);
 }

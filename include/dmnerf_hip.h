@@ -286,12 +286,14 @@ int dmnerf_build_pack_index_t_f16(int ins_num, int32_t* h_idx, int64_t n_idx);
 int dmnerf_grad_scale(const float* d_graw, int64_t n, float* d_scale4, void* stream);
 int dmnerf_mlp_bwd_data_f16(const float* d_blob_t_f16, int ins_num, const float* d_save, const float* d_graw, int64_t M,
                             float* d_dsave, float* d_graw_t, const float* d_scale, void* stream);
-/* dmnerf_mlp_bwd_weights_split on operands that carry the factor 2^s of dmnerf_grad_scale: the second stage multiplies every
- * gradient by d_scale[1] = 2^-s (null: 1). */
-int dmnerf_mlp_bwd_weights_split_scaled(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
-                                        const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
-                                        const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat,
-                                        const float* d_scale, void* stream);
+/* OPT-IN split-f16 weight-gradient kernel: dmnerf_mlp_bwd_weights on the f16 MFMA (both operands split on the fly into two f16
+ * planes, three products per f32 product; plans of dmnerf_wgrad_plan / _plan_split are both valid).  The dy-side operands
+ * (d_dsave, d_graw_t) carry the factor 2^s of dmnerf_grad_scale; the second stage multiplies every gradient by d_scale[1] = 2^-s
+ * (d_scale null: 1). */
+int dmnerf_mlp_bwd_weights_f16(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
+                               const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
+                               const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat,
+                               const float* d_scale, void* stream);
 
 /* ---- evaluator.py (the object-code loss, no host round trip) ---------------------------
  * ins_criterion (networks/evaluator.py:19-74): pred [N, ins_num] (rendered object codes in (0,1)), labels [N]

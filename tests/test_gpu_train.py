@@ -468,7 +468,7 @@ def test_split_backward_kernels_vs_oracle_autograd(A, mode, capsys):
 
 
 def test_split_wgrad_kernel_vs_f32_wgrad_kernel(A):
-    """The opt-in split-bf16 weight-gradient kernel (csrc/wgrad_split.hip) against the default f32 one on the SAME saved
+    """The opt-in split weight-gradient kernels (csrc/wgrad_split.hip: bf16x3; csrc/wgrad_f16.hip: f16x2) against the default f32 one on the SAME saved
     forward and the same dy (f32 dgrad): every parameter gradient, per tensor  max|diff| <= 2e-5 * max|f32 result|  (both sum
     ~10^3 .. 10^4 products per entry in f32; six bf16 products per f32 product).  Both plans (f32- and split-balanced) are valid
     for both kernels; ragged M and every logit-block count."""
@@ -493,22 +493,24 @@ def test_split_wgrad_kernel_vs_f32_wgrad_kernel(A):
                                            _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "bwd")
         flat = m.flat()
         grads = {}
-        for kern in ("f32", "split"):
+        for kern in ("f32", "split", "f16"):
             for plan in ("f32", "split"):
                 jobs, n_jobs, outs, n_outs, pf = A.G.wgrad_plan(ins_num, M_, raw.device, split=plan == "split")
                 part = torch.full((pf,), float("nan"), device="cuda")
                 out = torch.full((lib.dmnerf_param_count(ins_num),), float("nan"), device="cuda")
-                fn = lib.dmnerf_mlp_bwd_weights_split if kern == "split" else lib.dmnerf_mlp_bwd_weights
+                fn = {"f32": lib.dmnerf_mlp_bwd_weights, "split": lib.dmnerf_mlp_bwd_weights_split, "f16": lib.dmnerf_mlp_bwd_weights_f16}[kern]
+                extra = (None,) if kern == "f16" else ()                  # (no gradient scale: same operands for every kernel)
                 _lib.check(fn(_lib.ptr(save), _lib.ptr(dsave), _lib.ptr(gt), M_, _lib.ptr(jobs), n_jobs, _lib.ptr(outs), n_outs,
-                              _lib.ptr(flat), ins_num, _lib.ptr(part), _lib.ptr(out), _lib.stream()), kern)
+                              _lib.ptr(flat), ins_num, _lib.ptr(part), _lib.ptr(out), *extra, _lib.stream()), kern)
                 torch.cuda.synchronize()
                 assert not bool(torch.isnan(out).any()), (kern, plan)
                 grads[kern, plan] = A.G.split_flat_grads(m, out)
         names = [k for k, _ in m.named_parameters()]
-        for plan in ("f32", "split"):
-            for k, a, b in zip(names, grads["f32", "f32"], grads["split", plan]):
-                scale = float(a.abs().max())
-                err = float((a - b).abs().max())
-                assert err <= 2e-5 * scale + 1e-9, (ins_num, plan, k, err, scale)
+        for kern in ("split", "f16"):
+            for plan in ("f32", "split"):
+                for k, a, b in zip(names, grads["f32", "f32"], grads[kern, plan]):
+                    scale = float(a.abs().max())
+                    err = float((a - b).abs().max())
+                    assert err <= 2e-5 * scale + 1e-9, (ins_num, kern, plan, k, err, scale)
         for k, a, b in zip(names, grads["f32", "f32"], grads["f32", "split"]):      # the f32 kernel on the other plan: slice order only
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-9, (ins_num, k)
