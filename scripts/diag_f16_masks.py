@@ -1,3 +1,8 @@
+"""GPU box: the training forward of the split-f16 mode against the fused-heads f32 training forward on the same inputs -- every
+saved tensor of the SaveLayout workspace (pe, de, h_0..h_7, g1, g2) and the 1-bit ReLU masks, per layer: how many mask bits
+differ (a pre-activation within rounding distance of zero gets a different ReLU bit from two f32-class forwards; ReLU's
+derivative is discontinuous there, so such a bit moves single gradient entries by O(dy) -- see
+tests/test_gpu_train.py::test_split_backward_kernels_vs_oracle_autograd)."""
 import sys, os
 sys.path.insert(0, "/root/repo")
 import torch, numpy as np
@@ -5,7 +10,7 @@ from dm_nerf_amd import _lib
 from dm_nerf_amd.networks import dm_nerf as M
 from oracle import ref_cpu as O
 lib = _lib.load()
-for ins_num, N, S, seed in ((13, 6, 64, 71), (13, 6, 64, 74), (13, 6, 64, 75), (13, 6, 64, 76)):
+for ins_num, N, S, seed in ((13, 6, 64, 71), (13, 6, 64, 74), (13, 37, 64, 71), (13, 64, 192, 3), (59, 64, 192, 4)):
     sd = O.make_weights(seed, ins_num, gain=1.7)
     m = M.DM_NeRF(8, 256, 63, 27, [4], ins_num); m.load_state_dict(sd); m = m.cuda()
     g = torch.Generator().manual_seed(seed)
