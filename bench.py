@@ -241,22 +241,53 @@ def split_kernel_names(mode, obi):
     return {"mlp_fwd_train": f"mlp_split_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_split_kernel<{obi}>", "mlp_bwd_weights": "wgrad_split_kernel + reduce + unfuse"}
 
 
+def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=None):
+    """The same optimisation step as `train_leg` replayed from ONE HIP graph (dm_nerf_amd.graphed.GraphedTrainStep: forward,
+    losses, every backward kernel, Adam, weight re-packing in a single launch; bit-equal to the eager step,
+    tests/test_gpu_driver.py) on a batch of ``n`` rays: ms per step and the eager figure next to it."""
+    from dm_nerf_amd.graphed import GraphedTrainStep
+    ins_num = INS_NUM if ins_num is None else ins_num
+    mc.train(); mf.train()
+    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=torch.tensor(5e-4, device=dev), betas=(0.9, 0.999), capturable=True)
+    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
+                                 mfma_split=mfma_split)
+    g = torch.Generator(device=dev).manual_seed(0)
+    target = torch.rand(n, 3, device=dev, generator=g)
+    labels = torch.randint(0, 9, (n,), device=dev, generator=g)
+    rays = torch.stack([ro[:n], rd[:n]])
+    zz = z[:n].contiguous()
+    torch.manual_seed(0); torch.cuda.manual_seed(0)
+    gs = GraphedTrainStep((mc, mf), opt, args, ins_num, rays, zz, target, labels)
+    gs.step(); gs.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = gs.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    mc.eval(); mf.eval()
+    return {"ms_per_step": dt * 1e3, "rays_per_s": n / dt, "batch_rays": n, "final_loss": float(loss)}
+
+
 def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full):
     """What ONE GPU can say about the 8-GPU strong-scaling run (SURVEY 8(e) caveat): the complete optimisation step at the
-    per-rank shard of an 8-way split of the shipped batch sizes -- 384 rays (N_train 3072 / 8) and 512 rays (4096 / 8).
-    predicted_strong_efficiency_8 = (t_full / 8) / t_shard: the fixed per-step cost (launch overheads, the loss / Adam
-    kernels that do not shrink with the batch) is what keeps it below 1; the exchange itself (0.2 MB gather + one 5.57 MB
-    all-reduce) is not in it."""
+    per-rank shard of an 8-way split of the shipped batch sizes -- 384 rays (N_train 3072 / 8) and 512 rays (4096 / 8) -- eager
+    and as one HIP graph (graph_train_leg).  predicted_strong_efficiency_8 = (t_full / 8) / t_shard: the fixed per-step cost
+    (launch overheads, the loss / Adam kernels that do not shrink with the batch) is what keeps it below 1; the exchange itself
+    (0.2 MB gather + one 5.57 MB all-reduce) is not in it."""
     out = {}
     for n in (384, 512):
         r = train_leg(mc, mf, ro, rd, z, steps, dev, n=n)
-        out[f"n{n}"] = {"ms_per_step": r["ms_per_step"], "rays_per_s": r["rays_per_s"],
+        gr = graph_train_leg(mc, mf, ro, rd, z, steps, dev, n)
+        out[f"n{n}"] = {"ms_per_step": r["ms_per_step"], "rays_per_s": r["rays_per_s"], "graph_ms_per_step": gr["ms_per_step"],
                         "kernel_ms": {k["kernel"].split("<")[0].split(" ")[0]: k["kernel_ms"] for k in (r["roofline"] or {}).get("all", [])}}
     out["full_batch_rays"] = n_full
     out["full_batch_ms"] = t_full_ms
-    out["predicted_strong_efficiency_8"] = {"n512_of_4096": (t_full_ms / 8.0) / out["n512"]["ms_per_step"] * (4096.0 / n_full)}
-    out["note"] = ("full optimisation step (same recipe as `train`) at the per-rank shard of an 8-way strong split; efficiency = "
-                   "(t_full / 8) / t_shard with t_full rescaled to 4096 rays")
+    full = t_full_ms * (4096.0 / n_full)
+    out["predicted_strong_efficiency_8"] = {"eager_n512_of_4096": (full / 8.0) / out["n512"]["ms_per_step"],
+                                            "graph_n512_of_4096": (full / 8.0) / out["n512"]["graph_ms_per_step"]}
+    out["note"] = ("full optimisation step (same recipe as `train`) at the per-rank shard of an 8-way strong split, eager and as one HIP graph; "
+                   "efficiency = (t_full / 8) / t_shard with t_full = the eager 4096-ray step")
     return out
 
 
@@ -667,6 +698,8 @@ def main():
                 res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
             if not a.no_extras:
                 res["train_loop"] = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
+                res["train_graph"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS)
+                res["train_graph"]["note"] = "the `train` step (4096 rays) replayed from one HIP graph (GraphedTrainStep)"
                 res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS)
                 if INS_NUM != 59:
                     t9 = train_leg(mc9, mf9, ro, rd, z, a.train_steps, dev, ins_num=59)
@@ -681,6 +714,7 @@ def main():
                                         f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
                     tl = train_loop_leg(mc, mf, dev, a.train_steps, mfma_split=mode)
                     res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
+                    res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
         if train_multi is not None:
             res["train"] = train_multi
     if world > 1:

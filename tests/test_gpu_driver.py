@@ -120,3 +120,53 @@ def test_render_step_is_graph_capturable(A):
     for k in ("rgb_fine", "ins_fine", "depth_fine", "z_vals_fine", "raw_fine", "raw_coarse"):
         assert torch.equal(got[k], want[k]), k
     assert float(got["rgb_fine"].std()) > 0
+
+
+@pytest.mark.parametrize("mode", [None, "f16x2"])
+def test_training_step_is_graph_capturable(A, mode):
+    """The whole optimisation step -- dm_nerf with saved activations, img2mse + Hungarian-matched ins_criterion + emptiness
+    penalizer on both levels, composite / dgrad / wgrad backward, Adam, weight re-packing -- records into ONE HIP graph
+    (dm_nerf_amd.graphed.GraphedTrainStep) and replays on new batches: parameters after three replayed steps are bit-equal to
+    three eager steps from the same start on the same batches and the same jitter stream."""
+    from dm_nerf_amd import distributed as D
+    from dm_nerf_amd.graphed import GraphedTrainStep
+    N, ins_num = 96, 13
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(50.0, -65.0, 7.0))
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for s in (1000, 90000, 200000, 5000):
+        batches.append((torch.stack([ro[s:s + N], rd[s:s + N]]).cuda(), torch.rand(N, 3, generator=g).cuda(),
+                        torch.randint(0, 5, (N,), generator=g).cuda()))
+    z = A.H.z_val_sample(N, 4.0, 15.0, 64, device="cuda")
+    args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
+                                 mfma_split=mode or False)
+
+    def fresh():
+        mc, mf = models(A)
+        mc.train(); mf.train()
+        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=torch.tensor(5e-4, device="cuda"), capturable=True)
+        return mc, mf, opt
+
+    # eager
+    mc, mf, opt = fresh()
+    torch.cuda.manual_seed(123)
+    eager_losses = []
+    for rays, tgt, lab in batches[1:]:
+        eager_losses.append(D.sharded_train_step(rays, z, tgt, lab, (mc, mf), args, opt, ins_num)[0].clone())
+    want = [p.detach().clone() for m in (mc, mf) for p in m.parameters()]
+    # graphed: constructed (and warmed up) on another batch, then the same three batches
+    mc2, mf2, opt2 = fresh()
+    gs = GraphedTrainStep((mc2, mf2), opt2, args, ins_num, batches[0][0], z, batches[0][1], batches[0][2])
+    start = [p.detach().clone() for m in models(A) for p in m.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(start, [p for m in (mc2, mf2) for p in m.parameters()])), "warm-up was not undone"
+    torch.cuda.manual_seed(123)
+    graph_losses = []
+    for rays, tgt, lab in batches[1:]:
+        graph_losses.append(gs.step(rays, z, tgt, lab).clone())
+    torch.cuda.synchronize()
+    got = [p.detach() for m in (mc2, mf2) for p in m.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(eager_losses, graph_losses)), (eager_losses, graph_losses)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    assert not torch.equal(want[0], start[0])                                   # the steps really moved the weights
