@@ -105,6 +105,22 @@ def split_flat_grads(model, flat):
     return out
 
 
+# model -> (arena, slot): a WEAK registry (an attribute on the modules would travel with copy.deepcopy / torch.save of the model
+# and tie model and arena into a reference cycle)
+import weakref
+
+_arena_of = weakref.WeakKeyDictionary()
+
+
+def arena_slot(model):
+    """(arena, slot index) of the GradArena this model belongs to, or None."""
+    ent = _arena_of.get(model)
+    if ent is None:
+        return None
+    arena = ent[0]()
+    return None if arena is None else (arena, ent[1])
+
+
 class GradArena:
     """ONE flat f32 buffer holding the gradients of several models back to back, in ``named_parameters`` order (coarse
     model first: 2 x 696 338 floats = 5.57 MB at ins_num 13).  The weight-gradient kernel already produces one flat
@@ -114,7 +130,11 @@ class GradArena:
 
     ``begin_step()`` marks every slot free; the first backward launch of a model in that step takes the slot, further
     launches of the same model (batches beyond DMNERF_MAX_TRAIN_SAMPLES run as several) use scratch vectors that
-    autograd ADDS into the installed views, i.e. into the arena."""
+    autograd ADDS into the installed views, i.e. into the arena.
+
+    The gradients of a sharded step ALIAS the arena: the next ``begin_step()`` + backward overwrites any ``p.grad`` tensor a
+    caller kept from the previous step (clone it for logging / accumulation across steps).  The models refer to their arena
+    weakly (``arena_slot``); the caller -- ``distributed.sharded_train_step`` keeps it in a small cache -- owns it."""
 
     def __init__(self, models):
         self.models = list(models)
@@ -125,7 +145,7 @@ class GradArena:
         self.slots, o = [], 0
         for m, n in zip(self.models, sizes):
             self.slots.append(self.flat[o:o + n])
-            m._grad_arena = (self, len(self.slots) - 1)
+            _arena_of[m] = (weakref.ref(self), len(self.slots) - 1)
             o += n
         self.free = [False] * len(self.models)
 
@@ -152,14 +172,20 @@ class GradArena:
         return o == self.flat.numel()
 
 
+_arena_cache = []          # strong references to the most recent arenas (a training run has one)
+
+
 def grad_arena(models):
-    """The arena shared by exactly these models (created on first use, kept on the models)."""
+    """The arena shared by exactly these models (created on first use; the last few are kept alive here)."""
     models = list(models)
-    cur = getattr(models[0], "_grad_arena", None)
+    cur = arena_slot(models[0])
     if cur is not None and len(cur[0].models) == len(models) and all(a is b for a, b in zip(cur[0].models, models)) \
             and cur[0].flat.device == next(models[0].parameters()).device:
         return cur[0]
-    return GradArena(models)
+    arena = GradArena(models)
+    _arena_cache.append(arena)
+    del _arena_cache[:-4]
+    return arena
 
 
 class MLPRaysFunction(torch.autograd.Function):
@@ -223,7 +249,7 @@ def _mlp_backward(ctx, g_raw):
     C = ins_num + 1
     if M == 0:                                                   # an empty batch (e.g. a rank's empty shard): zero gradients
         ctx.save = None
-        arena = getattr(model, "_grad_arena", None)
+        arena = arena_slot(model)
         flat = arena[0].take(arena[1]) if arena is not None and arena[0].flat.device == g_raw.device else None
         if flat is None:
             flat = torch.empty(lib.dmnerf_param_count(ins_num), dtype=torch.float32, device=g_raw.device)
@@ -249,7 +275,7 @@ def _mlp_backward(ctx, g_raw):
     jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device, split=split)
     part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
     flat = None
-    arena = getattr(model, "_grad_arena", None)                  # data-parallel step: write into the shared all-reduce buffer
+    arena = arena_slot(model)                                    # data-parallel step: write into the shared all-reduce buffer
     if arena is not None and arena[0].flat.device == g.device:
         flat = arena[0].take(arena[1])
     if flat is None:

@@ -90,9 +90,10 @@ def allreduce_grads(models, average=False, arena=None):
 
     With a ``GradArena`` (dm_nerf_amd.autograd) whose slots the backward kernels filled, the parameters' ``.grad`` ARE
     views of one buffer and that buffer is all-reduced in place: no ``cat``, no copies.  Otherwise the bucket is built
-    over ALL parameters of the models, zero-filling those without a gradient, so that every rank contributes the same
-    number of elements whatever it rendered (a rank whose slice produced no gradient for some tensor must not shrink
-    its bucket), and the result is copied back."""
+    over all parameters that require a gradient, zero-filling those this rank has none for, so that every rank contributes
+    the same number of elements whatever it rendered (a rank whose slice produced no gradient for some tensor must not shrink
+    its bucket); one flag per parameter rides in the same message, and a tensor no rank had a gradient for keeps ``grad = None``
+    (single-process semantics: the optimizer skips it).  The result is copied back."""
     rank, world = world_info()
     if world == 1:
         return 0
@@ -101,22 +102,31 @@ def allreduce_grads(models, average=False, arena=None):
         if average:
             arena.flat /= world
         return arena.flat.numel() * arena.flat.element_size()
-    params = [p for m in models for p in m.parameters()]
+    # parameters that do not require a gradient take no part (identically on every rank: requires_grad is model structure)
+    params = [p for m in models for p in m.parameters() if p.requires_grad]
     if not params:
         return 0
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    # one flat message: the gradients (zeros where this rank has none, so that every rank contributes the same count whatever
+    # it rendered) followed by one flag per parameter -- after the sum a flag of zero means NO rank had a gradient for that
+    # tensor, and it stays None as in a single process (an optimizer skips it; zero-filling would let Adam's moments or weight
+    # decay move a parameter nobody differentiated)
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in params] + [has])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    n_grad = flat.numel() - len(params)
+    any_rank = flat[n_grad:].tolist()
     if average:
-        flat /= world
+        flat[:n_grad] /= world
     o = 0
-    for p in params:
+    for p, flag in zip(params, any_rank):
         n = p.numel()
-        if p.grad is None:
-            p.grad = flat[o:o + n].view_as(p).clone()
-        else:
-            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        if flag > 0:
+            if p.grad is None:
+                p.grad = flat[o:o + n].view_as(p).to(p.dtype).clone()
+            else:
+                p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
-    return flat.numel() * flat.element_size()
+    return n_grad * flat.element_size()
 
 
 def data_parallel_backward(loss_local, models, n_local, n_global):

@@ -61,6 +61,10 @@ def apply_patches(module):
 
 
 class _Loader(importlib.abc.Loader):
+    """The reference's own loader with ONE change: after the module body has run, the hot-path names are rebound.  Everything
+    else -- ``get_source`` / ``get_code`` / ``get_filename`` / ``is_package`` / ``get_data``, which ``inspect.getsource``,
+    ``linecache`` tracebacks, ``pkgutil`` and ``runpy`` ask the module's ``__loader__`` for -- is the inner loader's."""
+
     def __init__(self, inner):
         self.inner = inner
 
@@ -70,6 +74,17 @@ class _Loader(importlib.abc.Loader):
     def exec_module(self, module):
         self.inner.exec_module(module)          # the reference's module body runs unmodified ...
         apply_patches(module)                   # ... then the hot-path names point here
+
+    def __getattr__(self, name):                # (only called for attributes this class does not define)
+        return getattr(self.inner, name)
+
+
+def _looks_like_reference(origin):
+    """Is this file part of a DM-NeRF checkout?  A top-level ``config.py`` or ``networks/`` package of some OTHER project on
+    sys.path must not be patched: the reference's layout has ``networks/render.py`` + ``networks/dm_nerf.py`` next to ``config.py``."""
+    d = os.path.dirname(os.path.abspath(origin))
+    root = os.path.dirname(d) if os.path.basename(d) == "networks" else d
+    return all(os.path.isfile(os.path.join(root, *rel)) for rel in (("config.py",), ("networks", "render.py"), ("networks", "dm_nerf.py")))
 
 
 class _Finder(importlib.abc.MetaPathFinder):
@@ -85,6 +100,8 @@ class _Finder(importlib.abc.MetaPathFinder):
                 origin = os.path.abspath(spec.origin or "")
                 if origin.startswith(os.path.dirname(os.path.abspath(__file__)) + os.sep):
                     return None
+                if not spec.origin or not _looks_like_reference(spec.origin):
+                    return None                                      # some other project's module of the same name
                 spec.loader = _Loader(spec.loader)
                 return spec
         return None

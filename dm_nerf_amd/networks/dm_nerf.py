@@ -119,13 +119,14 @@ class DM_NeRF(nn.Module):
         return self._flat
 
     def blob(self):
-        """Kernel-layout weights, refreshed if any parameter was updated in place or replaced (see ``invalidate_blobs``)."""
+        """Kernel-layout weights, refreshed if any parameter was updated in place or replaced (see ``invalidate_blobs``): a NEW
+        tensor whenever a parameter changed, like ``flat`` -- a pending backward (two forwards around an optimizer step,
+        ``retain_graph``) keeps the blob ITS forward used, so its data gradients and its weight gradients see the same weights."""
         self._check_supported()
         state = dict(self.named_parameters())
         key = tuple((p.data_ptr(), p._version) for p in state.values())
         if self._blob is None or key != self._blob_key:
-            self._blob = weights.pack_blob(state, self.ins_num, flat=self.flat(), out=self._blob if self._blob is not None
-                                           and self._blob.device == next(iter(state.values())).device else None)
+            self._blob = weights.pack_blob(state, self.ins_num, flat=self.flat())
             self._blob_key = key
         return self._blob
 

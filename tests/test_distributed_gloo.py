@@ -85,6 +85,18 @@ def _worker(rank, world, port, q):
         nb2 = D.allreduce_grads(lin)
         g_ok = g_ok and nb2 == nbytes and bool((lin[1].bias.grad == 1.0).all()) and bool((lin[0].weight.grad == 1.0).all()) \
             and bool((lin[0].bias.grad == 3.0).all())
+        # a tensor NO rank has a gradient for keeps grad = None (single-process semantics: the optimizer skips it), and a
+        # parameter that does not require a gradient takes no part at all
+        for m in lin:
+            for p in m.parameters():
+                p.grad = torch.full_like(p, float(rank + 1))
+        lin[1].weight.grad = None
+        lin[0].bias.requires_grad_(False)
+        lin[0].bias.grad = None
+        nb3 = D.allreduce_grads(lin)
+        g_ok = g_ok and lin[1].weight.grad is None and lin[0].bias.grad is None and bool((lin[0].weight.grad == 3.0).all()) \
+            and nb3 == nbytes - 2 * 4
+        lin[0].bias.requires_grad_(True)
         # ray-sharded training step == single-process gradients (mean-squared error over the global batch)
         torch.manual_seed(0)
         lin2 = torch.nn.Linear(3, 3)

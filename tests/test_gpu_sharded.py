@@ -44,7 +44,8 @@ def _two_steps():
         losses.append(float(loss))
     flat = torch.cat([p.detach().reshape(-1) for m in models for p in m.parameters()]).cpu().numpy()
     # multi-rank: the gradients of BOTH models live in one arena that was all-reduced in place (no cat / copy_)
-    arena = getattr(models[0], "_grad_arena", None)
+    from dm_nerf_amd import autograd as G
+    arena = G.arena_slot(models[0])
     in_place = None if arena is None else bool(arena[0].resident() and arena[0].flat.numel() * 4 == nbytes
                                                and models[1].mlps[0].weight.grad.data_ptr() == arena[0].slots[1].data_ptr())
     return losses, flat, nbytes, in_place
