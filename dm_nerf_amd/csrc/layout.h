@@ -281,7 +281,9 @@ struct SaveLayout {
     int64_t pe, de;      // embed(pts) [63][M], embed(viewdirs) [27][M]
     int64_t h;           // relu outputs of mlps.0..7: [8][256][M]
     // (rgb_feature / ins_feature are NOT saved: their weight gradients come from G = dg1 . h_7^T, Q = dg2 . h_7^T)
-    int64_t g1, g2;      // relu outputs of rgb_feature_linears.0 / ins_feature_linears.0: [128][M] each
+    int64_t g1, g2;      // relu outputs of rgb_feature_linears.0 / ins_feature_linears.0: [128][M] each.  In the GRADIENT workspace (same
+                         // offsets) the two regions are ONE block-major tensor of 256 rows, dg1 = rows 0..127, dg2 = rows 128..255 of every
+                         // 32-sample block, so that the weight-gradient kernel streams h_7 once against [dg1 ; dg2] (G and Q of heads.hip)
     int64_t bits;        // ReLU bit masks, BITS_WORDS_PER_BLOCK words per block (forward workspace only)
     int64_t total;
 };

@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const BwdArgs a) {
             }
         }
         apply_mask<4>(dg1, g1bits, t4);
-        store_rows<4>(make_rowio(a.dsave + SL.g1, 128, srows * MP, blk, lane), dg1);      // burst (once per block)
+        store_rows<4>(make_rowio(a.dsave + SL.g1, 256, srows * MP, blk, lane), dg1);          // (dg1 | dg2: one 256-row tensor, layout.h)      // burst (once per block)
         // d h_7 (rgb branch) = F^T dg1, F = rgb_hidden[:, :256] . rgb_feature (layout.h): one 128 -> 256 GEMM, two
         // quarters; dg2 is saved meanwhile (32 + 32 spread stores)
-        const RowIO g2io = make_rowio(a.dsave + SL.g2, 128, srows * MP, blk, lane);
+        const RowIO g2io = make_rowio(a.dsave + SL.g1, 256, srows * MP, blk, lane, 4);
         auto st_g2 = [&](int k0) { return [&, k0](int k) { store_row_one(g2io, dg2, k0 + k); }; };
         gemm_quarter<0, 8, 8, 8, true, 32>(ws, dg1, acc, lane, st_g2(0));
         gemm_quarter<8, 8, 8, 8, false, 32>(ws, dg1, acc, lane, st_g2(32));

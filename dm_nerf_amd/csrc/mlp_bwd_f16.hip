@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_f16_kernel(const BwdHArgs a) {
     // ---- dg1 = relu'(g1) . (W_rgbo^T g_rgb) on the VALU (3 terms per element): rows for the weight gradient + planes
     unsigned Pg1[2][32];
     {
-        const RowIO gio = make_rowio(a.dsave + SL.g1, 128, MP, blk, lane);
+        const RowIO gio = make_rowio(a.dsave + SL.g1, 256, MP, blk, lane);              // (dg1 | dg2: one 256-row tensor, layout.h)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_f16_kernel(const BwdHArgs a) {
     // ---- dg2 = relu'(g2) . (W_io^T g_ins)   (nothing flows on to h_7: the ins branch starts from h.detach(), dm_nerf.py:95)
     f16_pass<4, OBI, 0, 0, 0, 0, true, 0>(ws, Pgi[0], Pgi[1], accG, bq, baddr, NoSideC{});
     // ---- dh_7 = F^T dg1 + w_d g_sigma; dy_7 = dh_7 . relu'(h_7): four passes of two groups; the first also carries dg2's epilogue
-    EpiBwd<4, 0, 0, false, false, 3, 4, 64, 16> eG{accG, bq, PA[0], PA[1], make_rowio(a.dsave + SL.g2, 128, MP, blk, lane), {g2bits[0], g2bits[1]}, 0.f};
+    EpiBwd<4, 0, 0, false, false, 3, 4, 64, 16> eG{accG, bq, PA[0], PA[1], make_rowio(a.dsave + SL.g1, 256, MP, blk, lane, 4), {g2bits[0], g2bits[1]}, 0.f};
     const RowIO io7 = make_rowio(a.dsave + SL.h + (int64_t)7 * 256 * MP, 256, MP, blk, lane);
     f16_pass<2, 2, 0, 8, 0, 0, true, 0, 64>(ws, Pg1[0], Pg1[1], acc0, bq, baddr, eG);
     baddr += 128;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_split_kernel(const BwdSArgs a) {
             zero_acc<4>(t4);
             gemm_split<0, 2 * OBI, 4, 8>(ws, Pg, t4, lane);
         }
-        mask_store_split<4, false>(t4, g2bits, make_rowio(a.dsave + SL.g2, 128, MP, blk, lane), Pn);
+        mask_store_split<4, false>(t4, g2bits, make_rowio(a.dsave + SL.g1, 256, MP, blk, lane, 4), Pn);    // (dg1 | dg2: one 256-row tensor, layout.h)
         zero_acc<4>(t4);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_split_kernel(const BwdSArgs a) {
                 }
             }
         }
-        mask_store_split<4, true>(t4, g1bits, make_rowio(a.dsave + SL.g1, 128, MP, blk, lane), Pn);
+        mask_store_split<4, true>(t4, g1bits, make_rowio(a.dsave + SL.g1, 256, MP, blk, lane), Pn);
         zero_acc<8>(acc);
         gemm_split<0, 8, 8, 8>(ws, Pn, acc, lane);
     }

@@ -155,8 +155,10 @@ __device__ __forceinline__ rsrc_t uniform_rsrc(const float* base, int64_t n_floa
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)nb, 0x00020000);
 }
 
-// base: tensor start; R: its row count; blk: this wave's block (Mp is unused: kept for the call sites' symmetry).
-__device__ __forceinline__ RowIO make_rowio(const float* base, int R, int64_t Mp, int64_t blk, int lane) {
+// base: tensor start; R: its row count; blk: this wave's block (Mp is unused: kept for the call sites' symmetry); ob0: first
+// out-block (32 rows) of the tensor this RowIO writes -- dg1 and dg2 share one 256-row tensor (ob0 = 0 / 4) so that the weight-
+// gradient kernel reads them as ONE A operand against h_7.
+__device__ __forceinline__ RowIO make_rowio(const float* base, int R, int64_t Mp, int64_t blk, int lane, int ob0 = 0) {
     RowIO io;
     const unsigned long long p = reinterpret_cast<unsigned long long>(base);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
@@ -165,7 +167,7 @@ __device__ __forceinline__ RowIO make_rowio(const float* base, int R, int64_t Mp
     // with ADD_TID_ENABLE the DATA_FORMAT bits of word 3 are stride[17:14]: they stay 0
     io.rs = __builtin_amdgcn_make_buffer_rsrc(q, 4, 64, 1 << 23);
     (void)Mp;
-    io.soff = __builtin_amdgcn_readfirstlane((unsigned)(blk * R * 128));
+    io.soff = __builtin_amdgcn_readfirstlane((unsigned)(blk * R * 128 + ob0 * 4096));
     (void)lane;
     return io;
 }

@@ -208,7 +208,9 @@ __global__ void wgrad_reduce_kernel(float* __restrict__ part, const WgOut* __res
             const float* p = part + o.bias_part_off + r;
             for (int k = 0; k < o.n_slices; ++k)
                 for (int q = 0; q < o.bias_sub; ++q) s += p[k * o.bias_slice_stride + (int64_t)q * o.ldb];
-            grad_flat[o.bias_out_off + (o.perm_a ? row_feature(r) : r)] = s * us;
+            const int rr = o.perm_a ? row_feature(r) : r;
+            if (o.bias_split > 0 && rr >= o.bias_split) grad_flat[o.bias_out_off2 + rr - o.bias_split] = s * us;
+            else grad_flat[o.bias_out_off + rr] = s * us;
         }
     }
 }
@@ -222,6 +224,7 @@ struct JobDesc {
     int rowsA, rowsB, cls;
     int64_t out_off; int ld_out, col_off;
     int64_t bias_out_off;       // -1: bias handled by another job with the same A
+    int bias_split = 0; int64_t bias_out_off2 = -1;   // rows >= bias_split: their row sums belong to another layer's bias
 };
 
 int class_for(int rowsA, int rowsB) {
@@ -265,10 +268,17 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs, bool split = false) {
     }
     // the four linears around the activation-free feature layers: G and Q (scratch) + the two hidden bias gradients here,
     // d rgb_feature_linear(s), d ins_feature_linear(s) from them in head_unfuse_kernel
+    // dg1 and dg2 are ONE 256-row tensor in the gradient workspace (layout.h::SaveLayout): [G ; Q] = [dg1 ; dg2] . h_7^T is one
+    // fat 256 x 256 job that streams h_7 once (two 128 x 256 jobs read it twice: 256 of 5657 operand rows per chunk)
+    static_assert(HEAD_F_FLOATS == HW * W, "G and Q are adjacent in the scratch head");
     const size_t i_G = d.size();
-    d.push_back({1, R_g1, HW, 0, 0, R_h + 7 * W, W, 0, HW, W, 0, S_G, W, 0, b_rh});
-    d.push_back({1, R_g2, HW, 0, 0, R_h + 7 * W, W, 0, HW, W, 0, S_Q, W, 0, b_ih});
-    d.push_back({1, R_g1, HW, 0, 0, R_de, DIR_CH, 0, HW, DIR_CH, 0, w_rh, W + DIR_CH, W, -1});                 // cat[rgb_feature, dirs] (:90)
+    {
+        JobDesc gq{1, R_g1, 2 * HW, 0, 0, R_h + 7 * W, W, 0, 2 * HW, W, 0, S_G, W, 0, b_rh};
+        gq.bias_split = HW; gq.bias_out_off2 = b_ih;
+        d.push_back(gq);
+        (void)S_Q;
+    }
+    d.push_back({1, R_g1, 2 * HW, 0, 0, R_de, DIR_CH, 0, HW, DIR_CH, 0, w_rh, W + DIR_CH, W, -1});             // cat[rgb_feature, dirs] (:90): rows 0..127 = dg1
     d.push_back({2, 0, GT, 3, 0, R_h + 7 * W, W, 0, 1, W, 0, w_d, W, 0, b_d});                                  // density_linear
     d.push_back({2, 0, GT, 4, 0, R_g2, HW, 0, C, HW, 0, w_io, HW, 0, b_io});                                   // ins_linear
     d.push_back({2, 0, GT, 0, 0, R_g1, HW, 0, 3, HW, 0, w_ro, HW, 0, b_ro});                                   // rgb_linear
@@ -315,7 +325,8 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs, bool split = false) {
         o.out_off = j.out_off; o.bias_out_off = j.bias_out_off;
         o.n_slices = ns; o.rowsA = j.rowsA; o.rowsB = j.rowsB; o.ldp = nbb * 32; o.ld_out = j.ld_out; o.col_off = j.col_off;
         o.bias_sub = nshare; o.ldb = nba * 32;
-        o.to_scratch = (jk == i_G || jk == i_G + 1) ? 1 : 0;
+        o.to_scratch = jk == i_G ? 1 : 0;
+        o.bias_split = j.bias_split; o.bias_out_off2 = j.bias_out_off2;
         o.perm_a = j.a_src == 1;                                            // dy tensors of the dgrad pass
         o.perm_b = !(j.b_base == R_pe || j.b_base == R_de);                 // saved h / g1 / g2 (not the encodings)
         P.outs.push_back(o);

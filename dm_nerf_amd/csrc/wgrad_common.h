@@ -42,8 +42,9 @@ struct WgOut {
     int64_t out_off, bias_out_off;    // float offsets into the flat gradient vector (reference order); bias -1 = none
     int n_slices, rowsA, rowsB, ldp;  // ldp = NBB*32
     int ld_out, col_off, bias_sub, ldb;        // bias_sub shares per slice, ldb = NBA*32 apart
-    int perm_a, perm_b, to_scratch, pad1;      // operand rows are in the accumulator-layout memory order (layout.h::row_feature);
+    int perm_a, perm_b, to_scratch, bias_split;   // operand rows are in the accumulator-layout memory order (layout.h::row_feature);
                                                // to_scratch: out_off addresses the head of the partials workspace (G / Q of heads.hip)
+    int64_t bias_out_off2;                     // bias_split > 0: the row sums of rows >= bias_split go here (the [dg1 ; dg2] job: two layers' biases)
 };
 
 struct WgArgs {

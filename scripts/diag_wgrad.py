@@ -3,7 +3,8 @@
 Runs one fine-level (4096 x 192 samples) and one coarse-level (4096 x 64) MLP backward with
 dmnerf_wgrad_set_trace on and prints, per job of the plan, the slice count, chunks per slice and
 the measured time per workgroup / per 32-sample chunk.  Used to fit chunk_cost() in csrc/wgrad.hip.
-DMNERF_DIAG_SPLIT=1: the opt-in split-bf16 backward (csrc/wgrad_split.hip) and its plan.
+DMNERF_DIAG_SPLIT=1: the opt-in split-bf16 backward (csrc/wgrad_split.hip) and its plan; DMNERF_DIAG_SPLIT=f16: the split-f16
+backward (csrc/wgrad_f16.hip; the split plan).
 """
 import ctypes
 import os
@@ -36,8 +37,9 @@ def main():
         ro, rd = torch.randn(N, 3, device=dev), torch.randn(N, 3, device=dev)
         z = torch.sort(torch.rand(N, S, device=dev) * 4 + 1, -1)[0]
         Mtot = N * S
-        split = bool(int(os.environ.get("DMNERF_DIAG_SPLIT", "0")))
-        jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev, split=split)
+        sv = os.environ.get("DMNERF_DIAG_SPLIT", "0")
+        split = {"0": None, "1": "bf16x3", "f16": "f16x2"}[sv]
+        jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev, split=bool(split))
         jh = jobs.cpu().numpy().view(JOB)
         assert JOB.itemsize * n_jobs == jobs.numel(), (JOB.itemsize, n_jobs, jobs.numel())
         ticks = torch.zeros(2 * n_jobs, dtype=torch.int64, device=dev)
@@ -70,7 +72,7 @@ def main():
             nch = jh["nchunk"][i:k]
             print(f"  job rows {int(j['rowsA']):3d}x{int(j['rowsB']):3d} cls ({nba},{nbb}) slices {k - i:3d} chunks/slice {int(nch.max()):5d}"
                   f"  wg time mean {d.mean():8.0f} max {d.max():8.0f} us   per chunk {1e3 * (d / nch).mean():7.0f} ns"
-                  f"  (MFMA-ideal {(96 if split else 256) * nba * nbb / 2.4:7.0f} ns)")
+                  f"  (MFMA-ideal {({None: 256, 'bf16x3': 96, 'f16x2': 48}[split]) * nba * nbb / 2.4:7.0f} ns;  HBM at 6.3 TB/s / 256 CUs: {(nba + nbb) * 4096 / 24.6:7.0f} ns)")
             i = k
 
 

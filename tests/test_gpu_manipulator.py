@@ -122,7 +122,7 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
     assert torch.equal(cpu(tz0), g["s2_tar_z0"]) and torch.equal(g["s2_tar_z0"], g["s2_tar_z1"])
     # fine network on the merged depths (448 samples per ray), original and both target ray sets
     mf = _mk(A, g["seeds"][1], ins_num, **O.PEAKY)
-    worst = {}
+    worst, f32gap = {}, {}
     for rays_key, z_key, raw_key in (("ori_rays", "s2_ori_z_merged", "s2_ori_raw"), ("tar_rays0", "s2_tar_z0", "s2_tar_raw0"),
                                      ("tar_rays1", "s2_tar_z1", "s2_tar_raw1")):
         rays = g[rays_key].cuda()
@@ -132,9 +132,17 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
         assert raw.shape == want.shape == (24, 448, 4 + ins_num + 1)
         err = (raw - want).abs() / (1 + want.abs())
         worst[raw_key] = [float(err[..., :3].max()), float(err[..., 3].max()), float(err[..., 4:].max())]
-        # PEAKY scales the density head by 100 and the trunk by 2: the f32-roundoff class of THESE weights (the contract's
-        # 1e-5 (1 + |raw|) is stated for default-init-class weights)
-        assert worst[raw_key][0] <= 1e-4 and worst[raw_key][2] <= 1e-4 and worst[raw_key][1] <= 1e-3, worst
+        # PEAKY scales the density head by 100 and the trunk by 2 (the contract's 1e-5 (1 + |raw|) is stated for default-init-class
+        # weights).  The f32-roundoff class of THESE weights is MEASURED, not assumed: the reference's own f32 result (the golden
+        # `want`) against a float64 evaluation of the same network on the same inputs -- the kernel may be as far from the reference
+        # as the reference is from the real number (x 2: two independent f32 roundings), and never beyond the old fixed bounds
+        sd64 = {k: v.double() for k, v in O.make_weights(int(g["seeds"][1]), ins_num, **O.PEAKY).items()}
+        ref64, _ = O.manipulator_nerf(g[rays_key].double(), sd64, z_vals=g[z_key].double())
+        gap = (want.double() - ref64).abs() / (1 + ref64.abs())
+        own = [float(gap[..., :3].max()), float(gap[..., 3].max()), float(gap[..., 4:].max())]
+        f32gap.setdefault(raw_key, own)
+        for got_e, ref_e, cap in zip(worst[raw_key], own, (1e-4, 1e-3, 1e-4)):
+            assert got_e <= min(cap, max(2.0 * ref_e, 1e-5)), (raw_key, worst[raw_key], own)
     # exchanger #2 (:201) on the reference's own fine raws: exact, labels included
     ori = g["s2_ori_raw"].clone().cuda()
     out_raw, _, ol, tl = A.MA.exchanger(ori, [g["s2_tar_raw0"].cuda(), g["s2_tar_raw1"].cuda()], g["ex1_ori_acc"].cuda(), accs, labels)
@@ -146,7 +154,8 @@ def test_manipulator_stage_by_stage_on_reference_intermediates(A, golden, capsys
     assert torch.equal(cpu(ins).argmax(-1), g["final_ins"].argmax(-1))
     with capsys.disabled():
         print(f"\n[manipulator stages] resampling: {frac_crit:.4f} of the draws threshold-critical, within the conditioning bound on the others "
-              f"{agree:.5f}, within 1e-5 overall {float(tight.float().mean()):.5f}; fine network max |d raw|/(1+|raw|) [rgb, sigma, ins]: " + str(worst))
+              f"{agree:.5f}, within 1e-5 overall {float(tight.float().mean()):.5f}; fine network max |d raw|/(1+|raw|) [rgb, sigma, ins]: " + str(worst)
+              + "; the reference's own f32 result against float64 on the same inputs: " + str(f32gap))
 
 
 def test_manipulator_whole_chain_smoke(A, golden):
