@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--mode", default="")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): the update as multi-tensor kernels")
     ap.add_argument("--summarize", default=None)
     a = ap.parse_args()
     if a.summarize:
@@ -68,7 +69,7 @@ def main():
         gs = GraphedTrainStep((mc, mf), opt, args, 13, rays, z, target, labels)
         one = gs.step
     else:
-        opt = torch.optim.Adam(params, lr=5e-4)
+        opt = torch.optim.Adam(params, lr=5e-4, fused=True) if a.fused_adam else torch.optim.Adam(params, lr=5e-4)
         one = lambda: D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, 13)[0]
     for _ in range(3):
         one()
@@ -77,7 +78,7 @@ def main():
     for _ in range(a.steps):
         one()
     torch.cuda.synchronize()
-    print(f"{n} rays, mode {a.mode or 'f32'}{' (graph)' if a.graph else ''}: {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms per step")
+    print(f"{n} rays, mode {a.mode or 'f32'}{' (graph)' if a.graph else ''}{' (fused Adam)' if a.fused_adam else ''}: {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms per step")
 
 
 if __name__ == "__main__":
