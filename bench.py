@@ -582,13 +582,19 @@ def main():
     mc.blob(); mf.blob()                                        # packed weights resident
     # setup, not a step: load the code objects (a 32-ray render) and create the RCCL communicator (one scalar all-reduce),
     # so that --warmup 0 still times K steady-state steps
+    # (with a scratch HIP-event pair: the runtime sets its timestamp machinery up on the first timed event record of the process
+    # -- 35-55 ms on some boxes, measured -- and that is setup, not a step)
+    ev_scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     with torch.no_grad():
-        R.dm_nerf(torch.stack([ro[:32], rd[:32]]), pe, ve, mc, mf, z[:32].contiguous(), args)
+        R.dm_nerf(torch.stack([ro[:32], rd[:32]]), pe, ve, mc, mf, z[:32].contiguous(), args, _events=ev_scratch)
     if world > 1:
         dist.all_reduce(torch.zeros(1, device=dev))
     torch.cuda.synchronize()
     flush_c_stdio()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for b_, e_ in ev:                                               # create the hipEvent_t objects now (torch creates them at the first record)
+        b_.record(); e_.record()
+    torch.cuda.synchronize()
     gathers = [0]
 
     def gather_frame():
@@ -609,12 +615,14 @@ def main():
 
     with torch.no_grad():
         for i in range(a.warmup):
-            step(i)
+            step(i, ev_scratch)
         barrier()
         gathers[0] = 0
+        host_t = []
         t0 = time.perf_counter()
         for i in range(a.steps):
             out_rgb, out_ins = step(i, ev[i])
+            host_t.append(time.perf_counter())
         if world > 1 and a.steps > 0 and gathers[0] == 0:
             gather_frame()                                      # fewer steps than a band has chunks: the frame's gather is still timed
         barrier()
@@ -667,6 +675,9 @@ def main():
                          "flop_per_launch": flop_per_launch},
             "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
         }
+        if a.steps > 1:                                             # diagnostic: how long the HOST took to enqueue each step (no sync inside the loop)
+            hd = np.diff(np.array([t0] + host_t)) * 1e3
+            res["host_enqueue_ms_per_step"] = {"median": float(np.median(hd)), "max": float(hd.max()), "first": float(hd[0])}
         if world == 1 and not a.no_cpu_baseline:
             c = 0 if a.steps == 0 else (a.steps - 1) % n_chunks
             rays_cpu = torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]]).cpu()
