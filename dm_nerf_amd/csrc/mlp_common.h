@@ -167,6 +167,9 @@ __device__ __forceinline__ RowIO make_rowio(const float* base, int R, int64_t Mp
     // with ADD_TID_ENABLE the DATA_FORMAT bits of word 3 are stride[17:14]: they stay 0
     io.rs = __builtin_amdgcn_make_buffer_rsrc(q, 4, 64, 1 << 23);
     (void)Mp;
+#ifdef DMN_ACT_STORE_HOT      /* diagnostic: every store lands in 8 blocks that stay in L2 -- the instructions without their HBM traffic */
+    blk &= 7;
+#endif
     io.soff = __builtin_amdgcn_readfirstlane((unsigned)(blk * R * 128 + ob0 * 4096));
     (void)lane;
     return io;

@@ -6,6 +6,11 @@
 // differentiates; values are f32-class (2e-7 against float64) but not the bitwise fmaf chain of the default path.
 #include "mlp_f16_impl.h"
 
+#ifdef DMN_F16_TRACE
+static long long* g_f16_train_trace = nullptr;
+extern "C" void dmnerf_f16_train_set_trace(long long* d_trace) { g_f16_train_trace = d_trace; }
+#endif
+
 extern "C" int dmnerf_mlp_fwd_rays_train_f16(const float* d_blob_f16, int ins_num, const float* d_rays_o, const float* d_rays_d,
                                              const float* d_z, int64_t N, int S, float* d_raw, float* d_save, void* stream) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS) return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_train_f16: ins_num %d unsupported", ins_num);
@@ -15,6 +20,9 @@ extern "C" int dmnerf_mlp_fwd_rays_train_f16(const float* d_blob_f16, int ins_nu
     F16Args a{};
     a.blob = d_blob_f16; a.S = make_f16_layout(ins_num);
     a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.z = d_z; a.raw = d_raw; a.save = d_save; a.M = N * S; a.Sr = S;
+#ifdef DMN_F16_TRACE
+    a.trace = g_f16_train_trace;
+#endif
     if (a.M > DMNERF_MAX_TRAIN_SAMPLES)
         return dmn_fail(DMNERF_E_ARG, "mlp_fwd_rays_train_f16: %lld samples per launch exceed %lld; split the batch", (long long)a.M, (long long)DMNERF_MAX_TRAIN_SAMPLES);
     const int64_t nblk = (a.M + 31) / 32;

@@ -34,13 +34,19 @@ lib = _lib.load()
 blob = m.blob_f16()
 n_wg = (N * S + 127) // 128
 trace = None
-if hasattr(lib, "dmnerf_f16_set_trace"):
+TRAIN = bool(int(os.environ.get("EXP_TRAIN", "0")))          # the training forward (SAVE: rows + masks)
+setter = "dmnerf_f16_train_set_trace" if TRAIN else "dmnerf_f16_set_trace"
+if hasattr(lib, setter):
     trace = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
-    lib.dmnerf_f16_set_trace.argtypes = [ctypes.c_void_p]
-    lib.dmnerf_f16_set_trace(ctypes.c_void_p(trace.data_ptr()))
+    getattr(lib, setter).argtypes = [ctypes.c_void_p]
+    getattr(lib, setter)(ctypes.c_void_p(trace.data_ptr()))
+save = torch.empty(lib.dmnerf_train_save_floats(N * S), device=dev) if TRAIN else None
 
 
 def launch():
+    if TRAIN:
+        _lib.check(lib.dmnerf_mlp_fwd_rays_train_f16(_lib.ptr(blob), ins_num, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(z), N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "f16 train")
+        return
     _lib.check(lib.dmnerf_mlp_fwd_rays_f16(_lib.ptr(blob), ins_num, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(z), N, S, _lib.ptr(raw), _lib.stream()), "f16")
 
 
@@ -51,7 +57,7 @@ torch.cuda.synchronize()
 ts = sorted(b.elapsed_time(e) for b, e in ev[2:])
 name = os.path.basename(os.environ.get("DMNERF_DIAG_LIB", "libdmnerf_hip.so"))
 mfma = 24 * (140 + {1: 1, 2: 2, 3: 4, 4: 4}[(ins_num + 32) // 32])
-print(f"{name}: {N} x {S} samples, ins_num {ins_num}: median {ts[len(ts) // 2]:.3f} ms  min {ts[0]:.3f} ms   "
+print(f"{name}{' [training forward]' if TRAIN else ''}: {N} x {S} samples, ins_num {ins_num}: median {ts[len(ts) // 2]:.3f} ms  min {ts[0]:.3f} ms   "
       f"(MFMA issue alone at 2.4 GHz: {n_wg / 256 * mfma * 32 / 2.4e6:.3f} ms)")
 if trace is not None:
     t = trace.cpu().numpy().reshape(n_wg, 8)

@@ -20,17 +20,17 @@ for w in $WHAT; do
       echo "bench rc=$?"; tail -c 3000 $OUT/${TAG}_bench.json ;;
     prof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}/trace -o bench -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_${TAG}_trace.log 2>&1)
-      python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary.txt 2>&1
+      python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary_trace.txt 2>&1
       find $OUT/prof_${TAG} -name "*kernel_trace.csv" -size +2M -delete; find $OUT/prof_${TAG} -name "*.db" -delete
-      head -n 60 $OUT/prof_${TAG}/summary.txt ;;
+      head -n 60 $OUT/prof_${TAG}/summary_trace.txt ;;
     pmc)
       BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train"      # (extras on: the opt-in render legs incl. f16x2)
       (cd /tmp
        timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_${TAG}/pmc_mfma -o bench -- $BENCH > $OUT/prof_${TAG}_pmc_mfma.log 2>&1
        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}/pmc_fetch -o bench -- $BENCH > $OUT/prof_${TAG}_pmc_fetch.log 2>&1
        timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}/pmc_write -o bench -- $BENCH > $OUT/prof_${TAG}_pmc_write.log 2>&1)
-      python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary.txt 2>&1
+      python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary_pmc.txt 2>&1
       find $OUT/prof_${TAG} -name "*.csv" -size +2M -delete; find $OUT/prof_${TAG} -name "*.db" -delete
-      head -n 80 $OUT/prof_${TAG}/summary.txt ;;
+      head -n 80 $OUT/prof_${TAG}/summary_pmc.txt ;;
   esac
 done
