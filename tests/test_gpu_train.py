@@ -435,12 +435,13 @@ def test_split_backward_kernels_vs_oracle_autograd(A, mode, capsys):
             m = model_from(A, sd, ins_num)
             M_ = N * S
             Mp = A.G._row_len(M_)
+            ro_d, rd_d, z_d = rays_o.cuda(), rays_d.cuda(), z.cuda()          # kept alive: the C ABI takes raw pointers
             bits = []
             for fn, blob in ((lib.dmnerf_mlp_fwd_rays_train, m.blob()),
                              (lib.dmnerf_mlp_fwd_rays_train_split, m.blob_split()) if mode == "bf16x3" else (lib.dmnerf_mlp_fwd_rays_train_f16, m.blob_f16())):
                 raw_ = torch.empty(N, S, 4 + ins_num + 1, device="cuda")
                 save_ = torch.empty(lib.dmnerf_train_save_floats(M_), device="cuda")
-                _lib.check(fn(_lib.ptr(blob), ins_num, _lib.ptr(rays_o.cuda()), _lib.ptr(rays_d.cuda()), _lib.ptr(z.cuda()), N, S,
+                _lib.check(fn(_lib.ptr(blob), ins_num, _lib.ptr(ro_d), _lib.ptr(rd_d), _lib.ptr(z_d), N, S,
                               _lib.ptr(raw_), _lib.ptr(save_), _lib.stream()), "train forward")
                 bits.append(save_[(63 + 27 + 8 * 256 + 128 + 128) * Mp:].view(torch.int32).cpu())
             if not torch.equal(bits[0], bits[1]):
