@@ -498,6 +498,19 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
         out[f"T{T}"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "network_samples_per_ray": samples,
                         "tflops": 2.0 * mac * samples * N_RAYS / dt / 1e12, "frac_of_f32_mfma_peak": 2.0 * mac * samples * N_RAYS / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
                         "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all())}
+    if HAVE_F16X2:                                       # opt-in (args.mfma_split = "f16x2"), T = 1; not an MFMA-roof fraction: three products per MAC
+        args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, target_labels=[1], mfma_split="f16x2")
+        torch.manual_seed(0); torch.cuda.manual_seed(0)
+        with torch.no_grad():
+            MA.manipulator(None, None, mc, mf, ori, tars[:1], args)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                rgb, ins, _, _ = MA.manipulator(None, None, mc, mf, ori, tars[:1], args)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        out["T1_split_f16x2"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all()),
+                                 "note": "opt-in split-f16 network kernels (f32-class, not bitwise the default); not part of the T1 / T2 numbers"}
     out["note"] = ("manipulator() on one 4096-ray chunk, 64 + 128 samples, T moved objects (default f32 kernels); network_samples_per_ray = "
                    "(1+T)(64+192) + 2T(192+128T) -- the reference re-evaluates the original rays once per target (:190-193); frac = whole call (incl. resampling, exchanger, composites) against the f32 MFMA roof")
     return out

@@ -91,6 +91,8 @@ def wgrad_plan(ins_num, M, device, max_wgs=None, split=False):
         hj, ho = np.empty(jb.value, dtype=np.uint8), np.empty(ob.value, dtype=np.uint8)
         _lib.check(f_plan(ins_num, M, max_wgs, hj.ctypes.data_as(ctypes.c_void_p), jb.value,
                           ho.ctypes.data_as(ctypes.c_void_p), ob.value), "dmnerf_wgrad_plan")
+        while len(_plan_cache) >= 32:                      # a training run has one or two batch sizes; ragged callers do not pile up plans
+            _plan_cache.pop(next(iter(_plan_cache)))
         _plan_cache[key] = (torch.from_numpy(hj).to(device), nj.value, torch.from_numpy(ho).to(device), no.value, pf.value)
     return _plan_cache[key]
 

@@ -53,13 +53,14 @@ def manipulator_z(N_rays, near, far, N_samples, device=None):
     return z
 
 
-def manipulator_nerf(rays, position_embedder, view_embedder, model, N_samples=None, near=None, far=None, z_vals=None):
-    """``manipulator_nerf`` (networks/manipulator.py:108-134) -> (raw [N,S,4+C], z_vals)."""
+def manipulator_nerf(rays, position_embedder, view_embedder, model, N_samples=None, near=None, far=None, z_vals=None, split=None):
+    """``manipulator_nerf`` (networks/manipulator.py:108-134) -> (raw [N,S,4+C], z_vals).  ``split`` (extension): the opt-in
+    split-operand network kernels, ``weights.split_mode(args)``."""
     rays_o, rays_d = rays
     if z_vals is None:
         z_vals = manipulator_z(rays_d.shape[0], near, far, N_samples, rays_d.device)
     with torch.no_grad():
-        raw = run_network(model, rays_o, rays_d, z_vals)
+        raw = run_network(model, rays_o, rays_d, z_vals, split=split)
     return raw, z_vals
 
 
@@ -77,27 +78,30 @@ def manipulator(position_embedder, view_embedder, model_coarse, model_fine, ori_
 
     RNG: the reference calls ``sample_pdf(..., det=False)`` even at evaluation (:148,:170,:187): ``2 + T`` draws
     of ``torch.rand([N, N_importance])`` in the order original, each target, original again; the same draws are
-    made here on the rays' device, or pass them as ``us`` (extension used by the tests).
+    made here on the rays' device, or pass them as ``us`` (extension used by the tests).  ``args.mfma_split`` (extension, default
+    off) evaluates the 3 + 4 T network launches on the opt-in split-operand kernels, as in ``dm_nerf``.
     """
+    from .. import weights
+    split = weights.split_mode(args)
     N_samples, N_importance, near, far = args.N_samples, args.N_importance, args.near, args.far
     dev = ori_rays.device
     Nr = ori_rays.shape[1]
     us = list(us) if us is not None else None
     draw = lambda: _lib.f32(us.pop(0)) if us is not None else torch.rand([Nr, N_importance], device=dev)
     pe, ve = position_embedder, view_embedder
-    ori_raw, ori_z = manipulator_nerf(ori_rays, pe, ve, model_coarse, N_samples, near, far)
+    ori_raw, ori_z = manipulator_nerf(ori_rays, pe, ve, model_coarse, N_samples, near, far, split=split)
     _, ori_w, _, _ = manipulator_render(ori_raw, ori_z, ori_rays[1])
     ori_z_full = helpers.importance_resample(ori_z, ori_w, N_importance, u=draw())
-    ori_raw_full, _ = manipulator_nerf(ori_rays, pe, ve, model_fine, z_vals=ori_z_full)
+    ori_raw_full, _ = manipulator_nerf(ori_rays, pe, ve, model_fine, z_vals=ori_z_full, split=split)
     _, _, _, ori_ins_accum = manipulator_render(ori_raw_full, ori_z_full, ori_rays[1])
     tar_raws, f_tar_z, f_tar_zs, tar_ins_accums = [], [], [], []
     tar_rgb = tar_ins_accum = None
     for tar_rays in f_tar_rays:
-        tar_raw, tar_z = manipulator_nerf(tar_rays, pe, ve, model_coarse, N_samples, near, far)
+        tar_raw, tar_z = manipulator_nerf(tar_rays, pe, ve, model_coarse, N_samples, near, far, split=split)
         tar_raws.append(tar_raw); f_tar_z.append(tar_z)
         tar_rgb, tar_w, _, _ = manipulator_render(tar_raw, tar_z, tar_rays[1])
         tar_z_full, tar_zs = helpers.importance_resample(tar_z, tar_w, N_importance, u=draw(), return_samples=True)
-        tar_raw_full, _ = manipulator_nerf(tar_rays, pe, ve, model_fine, z_vals=tar_z_full)
+        tar_raw_full, _ = manipulator_nerf(tar_rays, pe, ve, model_fine, z_vals=tar_z_full, split=split)
         _, _, _, tar_ins_accum = manipulator_render(tar_raw_full, tar_z_full, tar_rays[1])
         f_tar_zs.append(tar_zs); tar_ins_accums.append(tar_ins_accum)
     ori_raw, _, _, _ = exchanger(ori_raw, tar_raws, ori_ins_accum, tar_ins_accums, args.target_labels)
@@ -107,9 +111,9 @@ def manipulator(position_embedder, view_embedder, model_coarse, model_fine, ori_
     f_tar_zs = torch.cat(f_tar_zs, dim=-1)
     ori_z = sort_rows(torch.cat([ori_z, ori_zs, f_tar_zs], dim=-1))
     for idx, tar_rays in enumerate(f_tar_rays):
-        ori_raw, ori_z = manipulator_nerf(ori_rays, pe, ve, model_fine, z_vals=ori_z)
+        ori_raw, ori_z = manipulator_nerf(ori_rays, pe, ve, model_fine, z_vals=ori_z, split=split)
         tar_z = sort_rows(torch.cat([f_tar_z[idx], ori_zs, f_tar_zs], dim=-1))
-        tar_raws[idx], _ = manipulator_nerf(tar_rays, pe, ve, model_fine, z_vals=tar_z)
+        tar_raws[idx], _ = manipulator_nerf(tar_rays, pe, ve, model_fine, z_vals=tar_z, split=split)
     ori_raw, _, _, _ = exchanger(ori_raw, tar_raws, ori_ins_accum, tar_ins_accums, args.target_labels)
     final_rgb, _, _, final_ins = manipulator_render(ori_raw, ori_z, ori_rays[1])
     return final_rgb, final_ins, tar_rgb, tar_ins_accum

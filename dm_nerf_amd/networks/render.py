@@ -26,18 +26,24 @@ def render_train(raw, z_vals, rays_d):
     return rgb, w, depth, ins
 
 
-def run_network(model, rays_o, rays_d, z_vals):
+def run_network(model, rays_o, rays_d, z_vals, split=None):
     """pts = o + d z -> embed(pts) | embed(d/|d|) -> ``model`` (networks/render.py:49-61 / :71-83)
-    as one fused kernel: ``[N,3], [N,3], [N,S] -> raw [N,S,4+C]`` (inference only)."""
+    as one fused kernel: ``[N,3], [N,3], [N,S] -> raw [N,S,4+C]`` (inference only).  ``split``: None (the f32 kernels) or
+    ``weights.split_mode(args)`` = "bf16x3" / "f16x2", the opt-in split-operand kernels (f32-class, not bitwise)."""
     if not model._fused_ok():                              # another network shape: layer by layer (dm_nerf_amd/generic.py)
+        if split:
+            raise ValueError("args.mfma_split: the split-operand kernels exist for the 8 x 256 network only")
         from .. import generic
         return generic.run_network(model, rays_o, rays_d, z_vals, train=False)
     rays_o, rays_d, z = _lib.f32(rays_o.reshape(-1, 3)), _lib.f32(rays_d.reshape(-1, 3)), _lib.f32(z_vals)
     _lib.require_gpu(rays_o, rays_d, z)
     N, S = z.shape
     raw = torch.empty(N, S, 4 + model.ins_num + 1, dtype=torch.float32, device=z.device)
-    _lib.check(_lib.load().dmnerf_mlp_fwd_rays(_lib.ptr(model.blob()), model.ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d),
-                                               _lib.ptr(z), N, S, _lib.ptr(raw), _lib.stream()), "dmnerf_mlp_fwd_rays")
+    lib = _lib.load()
+    fn, blob, name = {None: (lib.dmnerf_mlp_fwd_rays, model.blob, "dmnerf_mlp_fwd_rays"),
+                      "bf16x3": (lib.dmnerf_mlp_fwd_rays_split, model.blob_split, "dmnerf_mlp_fwd_rays_split"),
+                      "f16x2": (lib.dmnerf_mlp_fwd_rays_f16, model.blob_f16, "dmnerf_mlp_fwd_rays_f16")}[split or None]
+    _lib.check(fn(_lib.ptr(blob()), model.ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z), N, S, _lib.ptr(raw), _lib.stream()), name)
     return raw
 
 
