@@ -73,6 +73,8 @@ SIGNATURES = {
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan_sizes_split": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan_split": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
+    "dmnerf_wgrad_plan_sizes_f16": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_wgrad_plan_f16": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
     "dmnerf_mlp_bwd_weights_split": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_head_product": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "dmnerf_fuse_heads": (c_int, [c_vp, c_int, c_vp, c_vp]),

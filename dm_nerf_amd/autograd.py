@@ -74,16 +74,20 @@ _plan_cache = {}
 
 def wgrad_plan(ins_num, M, device, max_wgs=None, split=False):
     """Device-resident split-K plan of the weight-gradient kernel for (ins_num, M): (jobs, n_jobs, outs, n_outs, part_floats).
-    ``split``: balanced for the opt-in split-bf16 kernel (csrc/wgrad_split.hip)."""
+    ``split``: False = balanced for the f32 kernel, True / "bf16x3" = for the opt-in split-bf16 kernel (csrc/wgrad_split.hip),
+    "f16x2" = for the split-f16 kernel (csrc/wgrad_f16.hip); any plan is valid for any kernel."""
     import ctypes
 
     import numpy as np
     if max_wgs is None:
         max_wgs = torch.cuda.get_device_properties(device).multi_processor_count     # one workgroup per CU
-    key = (ins_num, M, str(device), max_wgs, bool(split))
+    kind = "f16x2" if split == "f16x2" else ("bf16x3" if split else None)
+    key = (ins_num, M, str(device), max_wgs, kind)
     if key not in _plan_cache:
         lib = _lib.load()
-        f_sizes, f_plan = (lib.dmnerf_wgrad_plan_sizes_split, lib.dmnerf_wgrad_plan_split) if split else (lib.dmnerf_wgrad_plan_sizes, lib.dmnerf_wgrad_plan)
+        f_sizes, f_plan = {None: (lib.dmnerf_wgrad_plan_sizes, lib.dmnerf_wgrad_plan),
+                           "bf16x3": (lib.dmnerf_wgrad_plan_sizes_split, lib.dmnerf_wgrad_plan_split),
+                           "f16x2": (lib.dmnerf_wgrad_plan_sizes_f16, lib.dmnerf_wgrad_plan_f16)}[kind]
         jb, ob, pf = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         nj, no = ctypes.c_int(), ctypes.c_int()
         _lib.check(f_sizes(ins_num, M, max_wgs, ctypes.byref(jb), ctypes.byref(ob), ctypes.byref(pf),
@@ -274,7 +278,7 @@ def _mlp_backward(ctx, g_raw):
         else:
             _lib.check(lib.dmnerf_mlp_bwd_data(_lib.ptr(ctx.blob), _lib.ptr(ctx.blob_t), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data")
-    jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device, split=split)
+    jobs, n_jobs, outs, n_outs, part_floats = wgrad_plan(ins_num, M, g.device, split="f16x2" if f16 else split)
     part = torch.empty(part_floats, dtype=torch.float32, device=g.device)
     flat = None
     arena = arena_slot(model)                                    # data-parallel step: write into the shared all-reduce buffer

@@ -241,7 +241,8 @@ struct Plan {
 };
 
 // Parameter offsets in the flat gradient vector = reference state_dict order (weight, bias per layer).
-Plan make_plan(int ins_num, int64_t M, int max_wgs, bool split = false) {
+// mode: 0 = wgrad.hip (f32 MFMA), 1 = wgrad_split.hip (bf16x3), 2 = wgrad_f16.hip (f16x2): whose chunk times balance the slices
+Plan make_plan(int ins_num, int64_t M, int max_wgs, int mode = 0) {
     const int C = ins_num + 1;
     const int64_t Mp = save_row_len(M);
     const int nchunks = (int)(Mp / KT);
@@ -286,13 +287,18 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs, bool split = false) {
     // r01): the MFMA time 256 * NBA * NBB cycles at ~2.4 GHz plus ~3 % for the fat classes; the skinny
     // classes are bound by the per-chunk hand-over (barrier + DMA issue), ~0.5 us.
     // split (wgrad_split.hip, six bf16 MFMAs per f32 product: 96 NBA NBB MFMA cycles per chunk): measured with
-    // DMNERF_DIAG_SPLIT=1 scripts/diag_wgrad.py (r02q); the skinny classes keep their hand-over / HBM floor.
-    auto chunk_cost = [split](int cls) {
+    // DMNERF_DIAG_SPLIT=1 scripts/diag_wgrad.py (r02q, re-measured r03x with the merged [dg1 ; dg2] job); the skinny classes keep
+    // their hand-over / HBM floor.
+    // f16x2 (wgrad_f16.hip, 48 NBA NBB MFMA cycles per chunk): every class sits on its operand stream; DMNERF_DIAG_SPLIT=f16
+    // scripts/diag_wgrad.py (mean of r03w / r03x, both under this plan: profiles/r03/diag_wgrad_f16_r03w.txt, ..._r03x.txt; the classes ins_num 13 does not use: 174 ns per block).
+    auto chunk_cost = [mode](int cls) {
         static const double ns[N_CLASSES] = {/*8,8*/ 7025, /*4,8*/ 3530, /*8,2*/ 1858, /*4,1*/ 538, /*1,8*/ 984,
                                              /*1,4*/ 540, /*2,4*/ 1000, /*3,4*/ 1400, /*4,4*/ 1800};
-        static const double ns_split[N_CLASSES] = {/*8,8*/ 4436, /*4,8*/ 2568, /*8,2*/ 1920, /*4,1*/ 839, /*1,8*/ 1311,
-                                                   /*1,4*/ 872, /*2,4*/ 1100, /*3,4*/ 1300, /*4,4*/ 1600};
-        return split ? ns_split[cls] : ns[cls];
+        static const double ns_split[N_CLASSES] = {/*8,8*/ 4748, /*4,8*/ 2750, /*8,2*/ 2044, /*4,1*/ 880, /*1,8*/ 1389,
+                                                   /*1,4*/ 967, /*2,4*/ 1180, /*3,4*/ 1390, /*4,4*/ 1710};
+        static const double ns_f16[N_CLASSES] = {/*8,8*/ 2795, /*4,8*/ 2100, /*8,2*/ 1320, /*4,1*/ 622, /*1,8*/ 895,
+                                                 /*1,4*/ 692, /*2,4*/ 1043, /*3,4*/ 1217, /*4,4*/ 1391};
+        return mode == 2 ? ns_f16[cls] : (mode == 1 ? ns_split[cls] : ns[cls]);
     };
     // Slices per job: minimise the longest workgroup (chunks per slice x chunk cost) under sum(slices) <= max_wgs:
     // start from one slice each and keep giving a slice to the job whose workgroups are the longest.
@@ -348,10 +354,10 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs, bool split = false) {
 
 }  // namespace
 
-static int plan_sizes(bool split, int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
+static int plan_sizes(int mode, int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
                       int64_t* part_floats, int* n_jobs, int* n_outs) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS || M < 1 || max_wgs < 32) return dmn_fail(DMNERF_E_ARG, "wgrad_plan: bad argument");
-    const Plan P = make_plan(ins_num, M, max_wgs, split);
+    const Plan P = make_plan(ins_num, M, max_wgs, mode);
     if (n_job_bytes) *n_job_bytes = (int64_t)(P.jobs.size() * sizeof(WgJob));
     if (n_out_bytes) *n_out_bytes = (int64_t)(P.outs.size() * sizeof(WgOut));
     if (part_floats) *part_floats = P.part_floats;
@@ -360,9 +366,9 @@ static int plan_sizes(bool split, int ins_num, int64_t M, int max_wgs, int64_t* 
     return DMNERF_OK;
 }
 
-static int plan_fill(bool split, int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
+static int plan_fill(int mode, int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
     if (ins_num < 1 || ins_num + 1 > DMNERF_MAX_LOGITS || M < 1 || max_wgs < 32 || !h_jobs || !h_outs) return dmn_fail(DMNERF_E_ARG, "wgrad_plan: bad argument");
-    const Plan P = make_plan(ins_num, M, max_wgs, split);
+    const Plan P = make_plan(ins_num, M, max_wgs, mode);
     if (job_bytes != (int64_t)(P.jobs.size() * sizeof(WgJob)) || out_bytes != (int64_t)(P.outs.size() * sizeof(WgOut)))
         return dmn_fail(DMNERF_E_ARG, "wgrad_plan: buffer sizes do not match dmnerf_wgrad_plan_sizes");
     memcpy(h_jobs, P.jobs.data(), (size_t)job_bytes);
@@ -372,18 +378,26 @@ static int plan_fill(bool split, int ins_num, int64_t M, int max_wgs, void* h_jo
 
 extern "C" int dmnerf_wgrad_plan_sizes(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
                                        int64_t* part_floats, int* n_jobs, int* n_outs) {
-    return plan_sizes(false, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
+    return plan_sizes(0, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
 }
 extern "C" int dmnerf_wgrad_plan(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
-    return plan_fill(false, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
+    return plan_fill(0, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
 }
 // the same tables balanced for the chunk times of the split-bf16 kernel (wgrad_split.hip)
 extern "C" int dmnerf_wgrad_plan_sizes_split(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
                                              int64_t* part_floats, int* n_jobs, int* n_outs) {
-    return plan_sizes(true, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
+    return plan_sizes(1, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
 }
 extern "C" int dmnerf_wgrad_plan_split(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
-    return plan_fill(true, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
+    return plan_fill(1, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
+}
+// ... and for those of the split-f16 kernel (wgrad_f16.hip)
+extern "C" int dmnerf_wgrad_plan_sizes_f16(int ins_num, int64_t M, int max_wgs, int64_t* n_job_bytes, int64_t* n_out_bytes,
+                                           int64_t* part_floats, int* n_jobs, int* n_outs) {
+    return plan_sizes(2, ins_num, M, max_wgs, n_job_bytes, n_out_bytes, part_floats, n_jobs, n_outs);
+}
+extern "C" int dmnerf_wgrad_plan_f16(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes, void* h_outs, int64_t out_bytes) {
+    return plan_fill(2, ins_num, M, max_wgs, h_jobs, job_bytes, h_outs, out_bytes);
 }
 
 long long* g_dmn_wgrad_trace = nullptr;      // (wgrad_split.hip shares the diagnostic hook)

@@ -39,7 +39,7 @@ def main():
         Mtot = N * S
         sv = os.environ.get("DMNERF_DIAG_SPLIT", "0")
         split = {"0": None, "1": "bf16x3", "f16": "f16x2"}[sv]
-        jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev, split=bool(split))
+        jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev, split=split or False)
         jh = jobs.cpu().numpy().view(JOB)
         assert JOB.itemsize * n_jobs == jobs.numel(), (JOB.itemsize, n_jobs, jobs.numel())
         ticks = torch.zeros(2 * n_jobs, dtype=torch.int64, device=dev)
