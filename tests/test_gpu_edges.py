@@ -327,3 +327,35 @@ def test_empty_training_batch_gives_zero_gradients(A):
     raw.sum().backward()
     for k, p in m.named_parameters():
         assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k
+
+
+def test_f16x2_range_of_the_two_plane_split(A, capsys):
+    """The f16x2 mode splits every layer INPUT into two f16 planes: 22 significand bits as long as the activation is inside the f16
+    range.  Activations in the thousands (weights 4.5x nn.Linear's scale: trunk to ~10^3, the heads' hidden layers to ~10^4; the
+    reference's trained scenes sit below 100): still the f32-class tolerance against the oracle.  Beyond 65 504 (8x: the trunk alone
+    reaches ~84 000) the planes SATURATE -- v_cvt_pkrtz_f16_f32
+    rounds towards zero, never to infinity -- so the result stays finite but is no longer f32-class, which INTEGRATION.md states; the
+    default kernels keep the f32 range and their tolerance on the same weights."""
+    g = torch.Generator().manual_seed(1)
+    N, S, ins_num = 8, 8, 13
+    ro, rd = torch.randn(N, 3, generator=g) * 0.5, torch.randn(N, 3, generator=g)
+    z = torch.sort(torch.rand(N, S, generator=g) * 5 + 1, -1)[0]
+    pts = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
+    vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+    x = torch.cat([O.embed(pts.reshape(-1, 3), 10), O.embed(vd[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1)
+    rep = {}
+    for gain in (4.5, 8.0):
+        sd = O.make_weights(21, ins_num, gain=gain)
+        want = O.mlp_forward(sd, x).reshape(N, S, -1)
+        m = model_from(A, sd, ins_num)
+        with torch.no_grad():
+            got32 = cpu(A.R.run_network(m, ro.cuda(), rd.cuda(), z.cuda()))
+            got16 = cpu(A.R.run_network(m, ro.cuda(), rd.cuda(), z.cuda(), split="f16x2"))
+        scale = float(want.abs().max())
+        rep[gain] = dict(max_raw=scale, f32=float((got32 - want).abs().max()) / scale, f16x2=float((got16 - want).abs().max()) / scale)
+        assert bool(torch.isfinite(got16).all()) and bool(torch.isfinite(got32).all()), rep
+        assert rep[gain]["f32"] <= 1e-5, rep
+    with capsys.disabled():
+        print("\n[f16x2 range] max |d raw| / max |raw| vs the oracle: " + str(rep))
+    assert rep[4.5]["f16x2"] <= 1e-5, rep                  # inside the f16 range: f32 class
+    assert rep[8.0]["f16x2"] > 1e-4, rep                   # beyond it: saturated planes (finite, documented, not f32 class)
