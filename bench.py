@@ -77,6 +77,17 @@ def parse():
     return p.parse_args()
 
 
+def quiesce():
+    """At the START of a measurement leg, before its warm-up steps: run the cyclic garbage collector now.  A full (generation-2)
+    collection of a process holding a few hundred thousand Python objects pauses the host for 50-80 ms; landing inside a 20-step
+    timed loop it drains the launch queue and reads as +2 .. 4 ms per step (seen on `train_loop` when an unrelated change moved the
+    pause; scripts/diag_train_loop.py: the same loop is within 1 % of the resident-batch step).  A long training run pays such a
+    pause once per many thousand steps.  Not placed between warm-up and timing: the GPU would sit idle for the length of the
+    collection and start the timed steps from a lower clock (measured: +2 .. 5 % on the training kernels)."""
+    import gc
+    gc.collect()
+
+
 def flush_c_stdio():
     """RCCL prints its version banner with printf (NCCL_DEBUG=VERSION on this pool); on a pipe that sits in the C
     buffer until exit and would land BEHIND the JSON line.  Push it out early instead."""
@@ -142,6 +153,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     fine-network pass, timed with HIP events on their stream (autograd.KERNEL_EVENTS): ``frac`` divides the MACs the kernel
     EXECUTES (mac_counts) by the peak of the MFMA type it runs on; ``algorithmic_tflops`` is the reference's FLOP count of
     the stage over the same time -- larger than ``achieved`` where the head re-association removed work."""
+    quiesce()
     from dm_nerf_amd import autograd as G, distributed as D
     ins_num = INS_NUM if ins_num is None else ins_num
     mc.train(); mf.train()
@@ -245,6 +257,7 @@ def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=
     """The same optimisation step as `train_leg` replayed from ONE HIP graph (dm_nerf_amd.graphed.GraphedTrainStep: forward,
     losses, every backward kernel, Adam, weight re-packing in a single launch; bit-equal to the eager step,
     tests/test_gpu_driver.py) on a batch of ``n`` rays: ms per step and the eager figure next to it."""
+    quiesce()
     from dm_nerf_amd.graphed import GraphedTrainStep
     ins_num = INS_NUM if ins_num is None else ins_num
     mc.train(); mf.train()
@@ -298,6 +311,7 @@ def train_loop_leg(mc, mf, dev, steps, mfma_split=False):
     Reports loop ms per iteration next to the step alone on a resident batch: the difference is the host-side overhead the
     prefetcher has to hide (< 3 % is the bar).  `inline_selection_ms` = the same loop with the drop-in
     get_select_full on the critical path (what the reference's loop structure costs here)."""
+    quiesce()
     from dm_nerf_amd import distributed as D
     from dm_nerf_amd.networks import helpers as H
     from dm_nerf_amd.prefetch import TrainBatchPrefetcher
@@ -355,6 +369,7 @@ def frame_leg(mc, mf, K, c2w, dev, mfma_split=False):
     """One complete 640x480 pose through the frame driver (distributed.render_path: raygen of the band, 75 chunks of
     N_test = 4096 rays, preallocated frame buffers, device-side label / confidence of ins_eval) -- what render_test does
     per pose (networks/tester.py:58-85) minus file output and CPU metrics."""
+    quiesce()
     from dm_nerf_amd import distributed as D
     args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, N_test=N_RAYS, N_samples=S_COARSE, near=NEAR, far=FAR,
                                  mfma_split=mfma_split)
@@ -433,6 +448,7 @@ def render_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref=None, fuse_heads=False,
     "f16x2": two f16 planes, three products (f32-class accuracy either way; csrc/mlp_split_impl.h, csrc/mlp_f16_impl.h).
     ins_num: the models' object-code width (BASELINE config 3: Replica office_0 = 59).  Roofline of the fine-network launch from
     HIP events around it: executed MACs x 16-bit products against the peak of the MFMA type used."""
+    quiesce()
     from dm_nerf_amd.networks import render as R
     ins_num = INS_NUM if ins_num is None else ins_num
     fused = bool(fuse_heads or mfma_split)
@@ -471,6 +487,7 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
     64 + 128 + 128 T depths (T = 1: 1152 network samples per ray = 4.5 x a dm_nerf render), three resamplings with random u (sample_pdf(det=False) even at evaluation), two exchanger
     rounds, the final composite.  Rays: the bench camera for the original view; each target view is the same camera
     moved by a rigid transform (what manipulator_demo does with the edited object's pose, :346-371)."""
+    quiesce()
     from dm_nerf_amd.networks import helpers as H, manipulator as MA
     from dm_nerf_amd.synthetic import pose_spherical
     c2w = pose_spherical(30.0, -65.0, 7.0).to(dev)
@@ -626,6 +643,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    quiesce()
     with torch.no_grad():
         for i in range(a.warmup):
             step(i, ev_scratch)
@@ -736,7 +754,7 @@ def main():
                     res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"], "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
                                 "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the split-operand 16-bit MFMA kernels "
                                         f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
-                    tl = train_loop_leg(mc, mf, dev, a.train_steps, mfma_split=mode)
+                    tl = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20), mfma_split=mode)
                     res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
                     res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
         if train_multi is not None:

@@ -68,6 +68,8 @@ SIGNATURES = {
     "dmnerf_exchanger": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_penalizer_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp]),
     "dmnerf_penalizer_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp]),
+    "dmnerf_penalizer_sums": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "dmnerf_penalizer_finish": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan_sizes": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),

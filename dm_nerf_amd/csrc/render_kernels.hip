@@ -814,6 +814,46 @@ extern "C" int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const 
     return dmn_check_launch("penalizer_bwd");
 }
 
+// The scalar tail of emptiness_penalizer (penalizer.py:44-55) on the device: the per-ray partials -> 4 sums (one block, fixed
+// order: deterministic), then loss = S0 / (C max(S1, 1e-8)) + S2 / max(S3, 1e-8) and the two factors the backward multiplies by.
+// Two launches instead of the ~14 scalar tensor operations of the same formulas (sum, clamp, mul, div, add, casts).
+__global__ __launch_bounds__(1024) void penalizer_sums_kernel(const double* __restrict__ part, int64_t N, double* __restrict__ sums4) {
+    __shared__ double red[1024][4];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = threadIdx.x; i < N; i += 1024)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += part[4 * i + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) sums4[threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ void penalizer_finish_kernel(const double* __restrict__ sums4, int C, float* __restrict__ loss1, float* __restrict__ inv2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double nb = sums4[1] > 1e-8 ? sums4[1] : 1e-8, nm = sums4[3] > 1e-8 ? sums4[3] : 1e-8;
+    loss1[0] = (float)(sums4[0] / ((double)C * nb) + sums4[2] / nm);
+    inv2[0] = (float)(1.0 / ((double)C * nb));
+    inv2[1] = (float)(1.0 / nm);
+}
+
+extern "C" int dmnerf_penalizer_sums(const double* d_partials, int64_t N, double* d_sums4, void* stream) {
+    if (N < 0 || !d_sums4 || (N > 0 && !d_partials)) return dmn_fail(DMNERF_E_ARG, "penalizer_sums: bad argument");
+    hipLaunchKernelGGL(penalizer_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_partials, N, d_sums4);
+    return dmn_check_launch("penalizer_sums");
+}
+
+extern "C" int dmnerf_penalizer_finish(const double* d_sums4, int C, float* d_loss1, float* d_inv2, void* stream) {
+    if (!d_sums4 || !d_loss1 || !d_inv2 || C < 1) return dmn_fail(DMNERF_E_ARG, "penalizer_finish: bad argument");
+    hipLaunchKernelGGL(penalizer_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_sums4, C, d_loss1, d_inv2);
+    return dmn_check_launch("penalizer_finish");
+}
+
 extern "C" int dmnerf_raygen_select(int H, int W, const float* h_intr, const float* h_c2w, const int64_t* d_idx, int64_t n,
                                     float* d_rays_o, float* d_rays_d, void* stream) {
     if (H < 1 || W < 1 || n < 0) return dmn_fail(DMNERF_E_ARG, "raygen_select: bad size");

@@ -24,27 +24,28 @@ class _Penalizer(torch.autograd.Function):
         part = torch.empty(N, 4, dtype=torch.float64, device=raw.device)
         _lib.check(lib.dmnerf_penalizer_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(depth), _lib.ptr(rays_d), N, S, C,
                                             float(tolerance), k2w, kh, _lib.ptr(part), _lib.stream()), "dmnerf_penalizer_fwd")
-        s = part.sum(0)                                               # 4 doubles; stays on the device
+        s = torch.empty(4, dtype=torch.float64, device=raw.device)    # the four batch sums; stay on the device
+        _lib.check(lib.dmnerf_penalizer_sums(_lib.ptr(part), N, _lib.ptr(s), _lib.stream()), "dmnerf_penalizer_sums")
         if sharded:                                                   # ray-sharded batch: the four sums are batch-global
             from .. import distributed
             distributed.allreduce_sums(s)
-        nb = torch.clamp(s[1], min=1e-8)
-        nm = torch.clamp(s[3], min=1e-8)
-        loss = (s[0] / (C * nb) + s[2] / nm).to(torch.float32)
-        ctx.save_for_backward(raw, z, depth, rays_d, (1.0 / (C * nb)).to(torch.float32), (1.0 / nm).to(torch.float32))
+        loss = torch.empty(1, dtype=torch.float32, device=raw.device)  # the reference returns a 1-element tensor
+        inv = torch.empty(2, dtype=torch.float32, device=raw.device)   # 1 / (C max(sum m_b, 1e-8)), 1 / max(sum m_m, 1e-8)
+        _lib.check(lib.dmnerf_penalizer_finish(_lib.ptr(s), C, _lib.ptr(loss), _lib.ptr(inv), _lib.stream()), "dmnerf_penalizer_finish")
+        ctx.save_for_backward(raw, z, depth, rays_d, inv)
         ctx.consts = (float(tolerance), k2w, kh, C)
-        return loss.reshape(1)                                         # the reference returns a 1-element tensor
+        return loss
 
     @staticmethod
     def backward(ctx, up):
         lib = _lib.load()
-        raw, z, depth, rays_d, inv_b, inv_m = ctx.saved_tensors
+        raw, z, depth, rays_d, inv = ctx.saved_tensors
         tol, k2w, kh, C = ctx.consts
         N, S, ch = raw.shape
-        scales = torch.stack([inv_b, inv_m]) * up.reshape(()).to(torch.float32)
+        scales = (inv * up.reshape(()).to(torch.float32)).contiguous()
         d_raw = torch.empty_like(raw)
         _lib.check(lib.dmnerf_penalizer_bwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(depth), _lib.ptr(rays_d), N, S, C, tol, k2w, kh,
-                                            _lib.ptr(scales.contiguous()), _lib.ptr(d_raw), _lib.stream()), "dmnerf_penalizer_bwd")
+                                            _lib.ptr(scales), _lib.ptr(d_raw), _lib.stream()), "dmnerf_penalizer_bwd")
         return d_raw, None, None, None, None, None, None
 
 

@@ -356,6 +356,12 @@ int dmnerf_penalizer_fwd(const float* d_raw, const float* d_z, const float* d_de
 int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const float* d_depth, const float* d_rays_d,
                          int64_t N, int S, int C, float tolerance, float two_deta_w_sq, float gauss_norm,
                          const float* d_scales, float* d_grad_raw, void* stream);
+/* The scalar tail of the same function (penalizer.py:44-55) without a chain of scalar tensor operations: _sums reduces the per-ray
+ * partials to d_sums4 = {S0, S1, S2, S3} (doubles; one block, fixed order; a ray-sharded caller all-reduces them here), _finish
+ * writes d_loss1 = (float)(S0 / (C max(S1,1e-8)) + S2 / max(S3,1e-8)) and d_inv2 = {1 / (C max(S1,1e-8)), 1 / max(S3,1e-8)}
+ * (float; d_scales of _bwd = d_inv2 * upstream gradient). */
+int dmnerf_penalizer_sums(const double* d_partials, int64_t N, double* d_sums4, void* stream);
+int dmnerf_penalizer_finish(const double* d_sums4, int C, float* d_loss1, float* d_inv2, void* stream);
 
 /* dm_nerf inference (networks/render.py:31-96, perturb handled by the caller passing t_rand/u):
  * all stages on `stream`, outputs = the 10 tensors of the reference dict (ins_* are [N, C-1]).
