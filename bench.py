@@ -88,6 +88,18 @@ def quiesce():
     gc.collect()
 
 
+def warm_up(one, min_steps=2, seconds=0.4):
+    """Untimed warm-up of a leg: at least ``min_steps`` calls and ``seconds`` of back-to-back GPU work.  The training legs follow
+    CPU baselines that leave the GPU idle for tens of seconds; the first ~100 ms of kernels after an idle period run 2-5 % slower
+    (clock ramp), which two 27 ms steps do not cover."""
+    t0 = time.perf_counter()
+    k = 0
+    while k < min_steps or time.perf_counter() - t0 < seconds:
+        one()
+        torch.cuda.synchronize()
+        k += 1
+
+
 def flush_c_stdio():
     """RCCL prints its version banner with printf (NCCL_DEBUG=VERSION on this pool); on a pipe that sits in the C
     buffer until exit and would land BEHIND the JSON line.  Push it out early instead."""
@@ -179,7 +191,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
-    one(); one()
+    warm_up(one, seconds=0.4 if world == 1 else 0.0)           # (N > 1: a fixed count -- every step contains collectives)
     fence()
     G.KERNEL_EVENTS = []
     t0 = time.perf_counter()
@@ -271,8 +283,7 @@ def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=
     zz = z[:n].contiguous()
     torch.manual_seed(0); torch.cuda.manual_seed(0)
     gs = GraphedTrainStep((mc, mf), opt, args, ins_num, rays, zz, target, labels)
-    gs.step(); gs.step()
-    torch.cuda.synchronize()
+    warm_up(gs.step)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = gs.step()
