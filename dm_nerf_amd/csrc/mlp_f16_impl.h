@@ -393,9 +393,6 @@ __global__ __launch_bounds__(256) void mlp_f16_kernel(const F16Args a) {
         constexpr int LAYER = decltype(lc)::value;
         constexpr bool PE_ON = LAYER == 5;                               // skip concat [h, pts] (dm_nerf.py:87)
         constexpr bool HQP = decltype(hasq_prev)::value;                 // (mlps.0 has no table bias)
-#ifdef DMN_F16_VMT2
-        constexpr int VMT = SAVE ? ((LAYER == 5 || LAYER == 6) ? 16 : DMN_F16_VMT2) : 0;      // experiment: a larger in-flight allowance where 32 stores per window are certain
-#endif
         const SaveCtx svp = save_ctx(SL.h + (int64_t)(LAYER - 1) * 256 * MP, 256, 4, 0);      // the previous layer's outputs
         const SaveCtx svl = save_ctx(SL.h + (int64_t)LAYER * 256 * MP, 256, 4, 0);
         f16_pass<2, 4, 0, 8, 0, 0, true, VMT>(ws, Pin[0], Pin[1], acc0, bq, baddr,
