@@ -28,7 +28,8 @@ struct BwdHArgs {
 // its subnormal range.  The whole backward is LINEAR in dL/draw, so it runs on 2^s dL/draw with s = 6 - ceil(log2 max|dL/draw|)
 // (max 64: three decades of headroom for growth through the layers, 2^-2 .. 64 at full two-plane precision) and the weight-
 // gradient reduction multiplies by 2^-s -- both exact.  One pass over dL/draw; the last block to finish writes the factors.
-__global__ void grad_scale_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out4) {
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out4) {
+    __shared__ unsigned wmax[4];
     unsigned mx = 0u;
     auto take = [&](float x) {
         const unsigned u = __float_as_uint(x) & 0x7fffffffu;
@@ -36,17 +37,26 @@ __global__ void grad_scale_kernel(const float* __restrict__ g, int64_t n, float*
     };
     const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n / 4 : 0;           // 16-byte lanes where the buffer allows them
     const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(g);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {               // four loads in flight per lane
+        const f32x4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { take(v0[e]); take(v1[e]); take(v2[e]); take(v3[e]); }
+    }
+    for (; i < n4; i += stride) {
         const f32x4 v = g4[i];
         take(v[0]); take(v[1]); take(v[2]); take(v[3]);
     }
-    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) take(g[i]);
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) take(g[j]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
-    unsigned* scratch = reinterpret_cast<unsigned*>(out4) + 2;    // [2] = running max (bits), [3] = blocks done; both zero between calls
-    if ((threadIdx.x & 63) == 0) atomicMax(scratch, mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    unsigned* scratch = reinterpret_cast<unsigned*>(out4) + 2;    // [2] = running max (bits), [3] = blocks done; both zero between calls
+    if (threadIdx.x == 0) {                                       // ONE atomic pair per block (a grid of a few hundred: the atomics were
+        const unsigned a01 = wmax[0] > wmax[1] ? wmax[0] : wmax[1], a23 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];   // the kernel's time at 2048 x 4)
+        atomicMax(scratch, a01 > a23 ? a01 : a23);
         __threadfence();
         if (atomicAdd(scratch + 1, 1u) == gridDim.x - 1) {
             const unsigned all = atomicMax(scratch, 0u);
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_f16_kernel(const BwdHArgs a) {
 
 extern "C" int dmnerf_grad_scale(const float* d_graw, int64_t n, float* d_scale4, void* stream) {
     if (!d_graw || !d_scale4 || n < 1) return dmn_fail(DMNERF_E_ARG, "grad_scale: bad argument");
-    const unsigned blocks = (unsigned)((n + 4095) / 4096 < 2048 ? (n + 4095) / 4096 : 2048);
+    const unsigned blocks = (unsigned)((n + 4095) / 4096 < 512 ? (n + 4095) / 4096 : 512);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_graw, n, d_scale4);
     return dmn_check_launch("grad_scale");
 }

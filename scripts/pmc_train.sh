@@ -1,5 +1,5 @@
 set -u
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; TAG=r03q
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; TAG=${TAG:-r03q}
 export TMPDIR=/tmp
 cd /tmp
 for mode in f16x2 ""; do
