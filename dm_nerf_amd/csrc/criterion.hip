@@ -8,7 +8,9 @@
 //   cr_partial_kernel   per 64-ray chunk: sums over the chunk's rays of -log(1-P), P (per channel) and of
 //                       log(1-P) - log(P), P per (label, channel) -- each element is visited once, its label
 //                       picks the LDS row; one thread per channel adds in ray order (deterministic)
-//   cr_solve_kernel     chunk partials -> cost matrices (rows = the labels that occur, ascending: the one-hot
+//   cr_reduce_kernel    the chunk partials of every entry summed in f64 (16 lanes per entry, fixed order), many workgroups:
+//                       with one workgroup this latency-bound sum was 0.8 of the 1.0 ms the loss took at ins_num 93
+//   cr_solve_kernel     sums -> cost matrices (rows = the labels that occur, ascending: the one-hot
 //                       compaction of :21-26), then the rectangular assignment by shortest augmenting paths
 //                       (the algorithm scipy implements, Crouse 2016) on one wavefront with the column scan
 //                       spread over the lanes, then the three loss terms
@@ -32,6 +34,7 @@ constexpr int CR_MAXC = 128;      // channels (= ins_num) supported by the solve
 // Work buffer layout (byte offsets; everything 8-byte aligned).  L = C + 1 label values 0..C.
 struct CrLayout {
     int64_t part_b, part_t, part_a, part_s, part_cnt;     // chunk partials
+    int64_t red;                                          // double [L + 2 C + 2 L C]: counts | A | S | b | t summed over the chunks
     int64_t ce, siou, tp_all;                             // float [C][C]: rows g < V (tp_all: the soft true-positive sums)
     int64_t row4col, lab_of_row, tp_of_col, den_of_col;   // int [C], int [C], float [C], float [C]
     int64_t scal;                                         // int V, int U, int flags (DMNERF_CRIT_*), pad
@@ -50,6 +53,7 @@ __host__ __device__ inline CrLayout cr_layout(int64_t N, int C) {
     w.part_a = take((int64_t)w.nch * C * 4);
     w.part_s = take((int64_t)w.nch * C * 4);
     w.part_cnt = take((int64_t)w.nch * w.L * 4);
+    w.red = take((int64_t)(w.L + 2 * C + 2 * w.L * C) * 8);
     w.ce = take((int64_t)C * C * 4);
     w.siou = take((int64_t)C * C * 4);
     w.tp_all = take((int64_t)C * C * 4);
@@ -108,6 +112,33 @@ __global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const float* __rest
     for (int i = p; i < L; i += blockDim.x) pc[i] = lc[i];
 }
 
+// ---- sums over the chunks: entry e of [counts (L) | A (C) | S (C) | b (L C) | t (L C)], 16 neighbouring lanes per entry (every 16th
+// chunk partial each, loads in flight together), combined in a fixed butterfly order; exact for the counts
+__global__ __launch_bounds__(256) void cr_reduce_kernel(int64_t N, int C, char* __restrict__ work) {
+    const CrLayout w = cr_layout(N, C);
+    const int L = w.L, sub = threadIdx.x & 15;
+    const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int n_ent = L + 2 * C + 2 * L * C;
+    double v = 0.0;
+    if (e < L) {
+        const int* __restrict__ pc = reinterpret_cast<const int*>(work + w.part_cnt);
+        int c = 0;
+        for (int k = sub; k < w.nch; k += 16) c += pc[(int64_t)k * L + e];
+        v = (double)c;
+    } else if (e < n_ent) {
+        const float* __restrict__ src;
+        int64_t stride;
+        int off;
+        if (e < L + C) { src = reinterpret_cast<const float*>(work + w.part_a); stride = C; off = e - L; }
+        else if (e < L + 2 * C) { src = reinterpret_cast<const float*>(work + w.part_s); stride = C; off = e - L - C; }
+        else if (e < L + 2 * C + L * C) { src = reinterpret_cast<const float*>(work + w.part_b); stride = (int64_t)L * C; off = e - L - 2 * C; }
+        else { src = reinterpret_cast<const float*>(work + w.part_t); stride = (int64_t)L * C; off = e - L - 2 * C - L * C; }
+        for (int k = sub; k < w.nch; k += 16) v += (double)src[(int64_t)k * stride + off];
+    }
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    if (sub == 0 && e < n_ent) reinterpret_cast<double*>(work + w.red)[e] = v;
+}
+
 // ---- cost matrices, assignment, loss terms: one workgroup ------------------------------------------------
 __device__ __forceinline__ double wave_min_key(double v, int key, int& key_out) {
     // minimum of v over the wave; ties: smaller key.  Returns the minimum, key_out = its key.
@@ -132,39 +163,16 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
     float* ce = reinterpret_cast<float*>(work + w.ce);
     float* siou = reinterpret_cast<float*>(work + w.siou);
     float* tp_all = reinterpret_cast<float*>(work + w.tp_all);
-    const float* pb = reinterpret_cast<const float*>(work + w.part_b);
-    const float* pt = reinterpret_cast<const float*>(work + w.part_t);
-    const float* pa = reinterpret_cast<const float*>(work + w.part_a);
-    const float* ps = reinterpret_cast<const float*>(work + w.part_s);
-    const int* pc = reinterpret_cast<const int*>(work + w.part_cnt);
+    const double* red = reinterpret_cast<const double*>(work + w.red);      // cr_reduce_kernel: counts | A | S | b | t
+    const double* red_b = red + L + 2 * C;
+    const double* red_t = red_b + L * C;
 
-    // 1. label counts, the labels that occur (ascending) -> rows (evaluator.py:21-26).  Sixteen neighbouring lanes share
-    //    an entry (every 16th chunk partial each, loads in flight together), combined in a fixed butterfly order.
-    auto sum16d = [](double v) {
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        return v;
-    };
-    {
-        const int sub = tid & 15;
-        for (int e0 = 0; e0 < L + 2 * C; e0 += blockDim.x / 16) {
-            const int e = e0 + (tid >> 4);
-            double v = 0.0;
-            if (e < L) {
-                int c = 0;
-                for (int k = sub; k < w.nch; k += 16) c += pc[(int64_t)k * L + e];
-                v = (double)c;                                            // exact
-            } else if (e < L + C) {
-                for (int k = sub; k < w.nch; k += 16) v += (double)pa[(int64_t)k * C + (e - L)];
-            } else if (e < L + 2 * C) {
-                for (int k = sub; k < w.nch; k += 16) v += (double)ps[(int64_t)k * C + (e - L - C)];
-            }
-            v = sum16d(v);
-            if (sub == 0) {
-                if (e < L) s_cnt[e] = (int)v;
-                else if (e < L + C) s_A[e - L] = v;
-                else if (e < L + 2 * C) s_S[e - L - C] = v;
-            }
-        }
+    // 1. label counts, the labels that occur (ascending) -> rows (evaluator.py:21-26)
+    for (int e = tid; e < L + 2 * C; e += blockDim.x) {
+        const double v = red[e];
+        if (e < L) s_cnt[e] = (int)v;
+        else if (e < L + C) s_A[e - L] = v;
+        else s_S[e - L - C] = v;
     }
     __syncthreads();
     if (tid == 0) {
@@ -183,19 +191,13 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
     for (int l = tid; l < L; l += blockDim.x)
         if (s_rank[l] >= 0) lab_of_row[s_rank[l]] = l;
 
-    // 2. cost matrices (evaluator.py:57-66), f32 entries; same 16-lane sharing
-    for (int e0 = 0; e0 < L * C; e0 += blockDim.x / 16) {
-        const int e = e0 + (tid >> 4), sub = tid & 15;
-        const bool in = e < L * C;
-        const int l = in ? e / C : 0, p = in ? e - l * C : 0;
-        const int g = in ? s_rank[l] : -1;
-        double b = 0.0, t = 0.0;
-        if (g >= 0)
-            for (int k = sub; k < w.nch; k += 16) { b += (double)pb[((int64_t)k * L + l) * C + p]; t += (double)pt[((int64_t)k * L + l) * C + p]; }
-        b = sum16d(b); t = sum16d(t);
-        if (g >= 0 && sub == 0) {
-            ce[g * C + p] = (float)((s_A[p] + b) / (double)N);
-            const float TP = (float)t;
+    // 2. cost matrices (evaluator.py:57-66), f32 entries
+    for (int e = tid; e < L * C; e += blockDim.x) {
+        const int l = e / C, p = e - l * C;
+        const int g = s_rank[l];
+        if (g >= 0) {
+            ce[g * C + p] = (float)((s_A[p] + red_b[e]) / (double)N);
+            const float TP = (float)red_t[e];
             tp_all[g * C + p] = TP;
             const float FP = (float)s_S[p] - TP;
             const float FN = (float)s_cnt[l] - TP;
@@ -355,6 +357,10 @@ extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_la
         return dmn_fail_hip(e, "ins_criterion: hipMemsetAsync");
     hipLaunchKernelGGL(cr_partial_kernel, dim3((unsigned)w.nch), dim3(CR_MAXC), lds, (hipStream_t)stream, d_pred, (const int*)d_labels, N, ins_num, (char*)d_work);
     int rc = dmn_check_launch("ins_criterion: partial sums");
+    if (rc) return rc;
+    const int n_ent = w.L + 2 * ins_num + 2 * w.L * ins_num;
+    hipLaunchKernelGGL(cr_reduce_kernel, dim3((unsigned)((n_ent + 15) / 16)), dim3(256), 0, (hipStream_t)stream, N, ins_num, (char*)d_work);
+    rc = dmn_check_launch("ins_criterion: chunk sums");
     if (rc) return rc;
     hipLaunchKernelGGL(cr_solve_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, ins_num, (char*)d_work, d_out4);
     return dmn_check_launch("ins_criterion: solve");
