@@ -235,16 +235,12 @@ class MLPRaysFunction(torch.autograd.Function):
         return (None, None, None, None, None) + _mlp_backward(ctx, g_raw)
 
 
-_scale_buffers = {}
-
-
 def _grad_scale_buffer(device):
-    """Per device: the 4 floats of dmnerf_grad_scale ({2^s, 2^-s, scratch, scratch}; zeroed once, the kernel keeps the scratch zero).
-    One buffer serves every backward on the device: the launches that write and read it are ordered on the stream."""
-    key = str(device)
-    if key not in _scale_buffers:
-        _scale_buffers[key] = torch.zeros(4, dtype=torch.float32, device=device)
-    return _scale_buffers[key]
+    """The 4 floats of dmnerf_grad_scale ({2^s, 2^-s, scratch, scratch}), one buffer PER BACKWARD, zeroed here by a fill on the
+    launch stream (a memset node under graph capture).  Nothing is shared between backwards: two models trained on two streams do
+    not race on the scale pair or on the atomic scratch words, and a kernel that died mid-run cannot leave a non-zero scratch word
+    behind for the next step (the kernel's own reset of the scratch is no longer relied upon)."""
+    return torch.zeros(4, dtype=torch.float32, device=device)
 
 
 def _mlp_backward(ctx, g_raw):

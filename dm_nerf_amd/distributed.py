@@ -110,8 +110,17 @@ def allreduce_grads(models, average=False, arena=None):
     # it rendered) followed by one flag per parameter -- after the sum a flag of zero means NO rank had a gradient for that
     # tensor, and it stays None as in a single process (an optimizer skips it; zero-filling would let Adam's moments or weight
     # decay move a parameter nobody differentiated)
-    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in params] + [has])
+    # The message is formed in the widest floating type among the parameters (f32 for the shipped models; f64 parameters -- the
+    # CPU / gloo path, oracle-style double models -- are summed in f64 as a single process would); the flags are small integers,
+    # exact in any of them.  (Reading the flags back is a host synchronisation: this path is the CPU / injected-renderer one;
+    # the HIP path reduces the arena above, in place and graph-capturably.)
+    wide = params[0].dtype
+    for p in params[1:]:
+        wide = torch.promote_types(wide, p.dtype)
+    if not wide.is_floating_point:
+        wide = torch.float32
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=wide, device=params[0].device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(wide) for p in params] + [has])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     n_grad = flat.numel() - len(params)
     any_rank = flat[n_grad:].tolist()
@@ -184,7 +193,8 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
       with ``args.perturb > 0`` the two jitter tensors are drawn FULL-size from the (identically seeded) device
       generator, in the reference's order (render.py:46, helpers.py:135), and sliced, so the jitter of ray i does not
       depend on the world size;
-    * the per-ray outputs the batch-global losses need are all-gathered (``gather_batch``: 2 x (rgb + ins), ≈0.2 MB):
+    * the per-ray outputs the batch-global losses need are all-gathered in ONE packed ``gather_batch`` (rgb and ins of both
+      levels side by side, ≈0.2 MB):
       img2mse's mean and the Hungarian cost matrices / soft-IoU sums of ins_criterion (evaluator.py:19-74) are then
       evaluated identically on every rank, and autograd hands each rank the gradient rows of its own slice;
       ``args.N_ins`` (ScanNet: only the LAST N_ins rays carry labels, render.py:88-90) is applied to the gathered tensor;
@@ -226,10 +236,19 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
                  None if t_rand is None else t_rand[sl].contiguous(),
                  None if u is None else (u if u.dim() == 1 else u[sl].contiguous()))      # a 1-D u is the grid shared by all rays
     penalize = bool(getattr(args, "penalize", False))    # train_dmsr.py:51: the emptiness term is optional (--penalize)
+    # ONE exchange for everything the batch-global losses need: rgb_fine | rgb_coarse | ins_fine | ins_coarse packed side by side
+    # into [n_local, 6 + 2 * ins_num] and all-gathered once (160 B per ray at ins_num 13; at the 384-ray shard of an 8-rank step
+    # four latency-bound collectives would cost more than the 61 KB they carry).  Packing and un-packing move values, not
+    # arithmetic: the gathered columns are the same floats, and autograd routes each rank the rows of its own slice.
+    levels = ("fine", "coarse")
+    widths = [out['rgb_' + l].shape[-1] for l in levels] + [out['ins_' + l].shape[-1] for l in levels]
+    if world > 1:
+        packed = gather_batch(torch.cat([out['rgb_' + l] for l in levels] + [out['ins_' + l] for l in levels], -1), sizes)
+        rgb_f, rgb_c, ins_f, ins_c = torch.split(packed, widths, -1)
+    else:
+        rgb_f, rgb_c, ins_f, ins_c = (out['rgb_fine'], out['rgb_coarse'], out['ins_fine'], out['ins_coarse'])
     loss = 0.
-    for lvl in ("fine", "coarse"):
-        rgb = gather_batch(out['rgb_' + lvl], sizes)
-        ins = gather_batch(out['ins_' + lvl], sizes)
+    for lvl, rgb, ins in (("fine", rgb_f, ins_f), ("coarse", rgb_c, ins_c)):
         if n_ins is not None:
             ins = ins[-n_ins:]
         loss = loss + mse(rgb, target) + criterion(ins, labels)
@@ -276,7 +295,7 @@ class FrameRenderer:
     ``render_frame`` is ``step`` over all chunks + ``gather``; bench.py drives the same object chunk by chunk."""
 
     def __init__(self, H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64,
-                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None):
+                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None, ins_num=None):
         self.rank, self.world = world_info()
         self.H, self.W, self.models, self.args, self.chunk = int(H), int(W), models, args, int(chunk)
         self.labels_only = bool(labels_only)
@@ -298,7 +317,19 @@ class FrameRenderer:
         self.dev = self.rays_o.device
         self.n_chunks = -(-self.n_local // self.chunk)
         self.z_full = self.z_fn(min(self.chunk, max(self.n_local, 1)), self.dev) if self.n_local else None
-        self.band = None                                           # allocated by the first chunk (its dtype / ins width)
+        # The packed band is sized HERE (object-code width from the model, f32 like every kernel output), not by the first rendered
+        # chunk: a rank whose band has no rays (H < world size) never renders one, and must still enter the frame's all-gather with
+        # a buffer of the common size -- raising on that rank alone would leave the others waiting in the collective.
+        self.band = None
+        if ins_num is None and models is not None:
+            ins_num = getattr(models[-1], "ins_num", None)
+        if ins_num is not None:
+            self._alloc_band(int(ins_num), torch.float32)
+
+    def _alloc_band(self, n_ins, dtype):
+        self.n_ins = n_ins
+        cols = 6 if self.labels_only else 3 + n_ins + 1
+        self.band = torch.empty(max(max(self.sizes), 1), cols, dtype=dtype, device=self.dev)
 
     def step(self, i, events=None):
         """Render chunk ``i`` (0 .. n_chunks - 1; the last one may be ragged, tester.py:65-67) into the band."""
@@ -309,10 +340,11 @@ class FrameRenderer:
             c_rgb, c_ins, c_depth = self.render_chunk(self.rays_o[s:e], self.rays_d[s:e], z, self.models, self.args, events=events)
         else:
             c_rgb, c_ins, c_depth = self.render_chunk(self.rays_o[s:e], self.rays_d[s:e], z, self.models, self.args)
-        if self.band is None:
-            self.n_ins = c_ins.shape[-1]
-            cols = 6 if self.labels_only else 3 + self.n_ins + 1
-            self.band = torch.empty(max(self.sizes), cols, dtype=c_rgb.dtype, device=self.dev)
+        if self.band is None or self.band.dtype != c_rgb.dtype or self.n_ins != c_ins.shape[-1]:
+            if self.band is not None and self.world > 1:           # every rank must gather the same shape: fail before the collective
+                raise RuntimeError(f"FrameRenderer: the chunk renderer returned ins width {c_ins.shape[-1]} / {c_rgb.dtype}, the band "
+                                   f"was sized for {self.n_ins} / {self.band.dtype} (pass ins_num=, or a model with .ins_num)")
+            self._alloc_band(c_ins.shape[-1], c_rgb.dtype)
         t = self.band[s:e]
         t[:, :3] = c_rgb
         if self.labels_only:
@@ -327,8 +359,9 @@ class FrameRenderer:
     def gather(self):
         """ONE all-gather of the packed band -> the frame's tensors on every rank."""
         H, W = self.H, self.W
-        if self.band is None:                                      # a frame with no rays on this rank cannot size the band
-            raise RuntimeError("FrameRenderer.gather() before any chunk was rendered")
+        if self.band is None:                                      # no model width, no ins_num=, and no chunk rendered yet
+            raise RuntimeError("FrameRenderer.gather(): the band was never sized -- render a chunk first or pass ins_num= "
+                               "(required when a rank's band can be empty)")
         if self.world == 1:
             full = self.band
         else:
@@ -342,7 +375,7 @@ class FrameRenderer:
 
 
 def render_frame(H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64,
-                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None):
+                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None, ins_num=None):
     """Full-frame render, rows sharded over ranks, ONE all-gather per frame (``FrameRenderer``).
 
     Mirrors the per-pose body of ``render_test`` (networks/tester.py:58-85): same chunking
@@ -353,7 +386,7 @@ def render_frame(H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64
     before the gather, and ``(rgb, label, conf, depth)`` is returned: 24 instead of 16 + 4*ins_num bytes per pixel cross the links.
     """
     fr = FrameRenderer(H, W, K, c2w, models, near, far, args, chunk=chunk, n_samples=n_samples, raygen=raygen,
-                       render_chunk=render_chunk, z_fn=z_fn, labels_only=labels_only, label_conf=label_conf)
+                       render_chunk=render_chunk, z_fn=z_fn, labels_only=labels_only, label_conf=label_conf, ins_num=ins_num)
     for i in range(fr.n_chunks):
         fr.step(i)
     return fr.gather()

@@ -85,6 +85,12 @@ class GraphedTrainStep:
             if src is not None:
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # The replay updated the parameters on the device without touching their Python-side ``_version``, which the models'
+        # kernel-layout caches are keyed on (networks/dm_nerf.py ``blob``): forget them, so that an eager render between replays
+        # (the periodic test render of train_dmsr.py:88-100) re-packs from the CURRENT parameters instead of reusing the copy
+        # an earlier evaluation packed.  (The graph itself is unaffected: it re-packs into its own buffers on every replay.)
+        for m in self.models:
+            m.invalidate_blobs()
         return self.loss
 
     def set_lr(self, lr):

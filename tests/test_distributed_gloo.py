@@ -49,7 +49,7 @@ def _frame(h=H, labels_only=False):
     K, c2w, sd_c, sd_f = _scene()
     kw = dict(labels_only=True, label_conf=lambda x: (x.argmax(-1), x.max(-1).values)) if labels_only else {}
     return D.render_frame(h, W, K, c2w, (sd_c, sd_f), 4.0, 15.0, None, chunk=CHUNK, n_samples=16,
-                          raygen=_raygen, render_chunk=_render_chunk, z_fn=_z_fn, **kw)
+                          raygen=_raygen, render_chunk=_render_chunk, z_fn=_z_fn, ins_num=INS, **kw)
 
 
 def _worker(rank, world, port, q):
@@ -232,13 +232,28 @@ def _train_two_steps(penalize=True):
 
     torch.manual_seed(7)                                     # the jitter stream: identical on every rank
     losses = []
+    calls = {"gather": 0, "reduce": 0}
+    real_gather, real_reduce = dist.all_gather, dist.all_reduce
+    if dist.is_initialized():
+        dist.all_gather = lambda *a, **k: (calls.__setitem__("gather", calls["gather"] + 1), real_gather(*a, **k))[1]
+        dist.all_reduce = lambda *a, **k: (calls.__setitem__("reduce", calls["reduce"] + 1), real_reduce(*a, **k))[1]
+    try:
+        losses = _two_steps(rays, z, target, labels, mc, mf, args, opt, render, penalizer)
+    finally:
+        dist.all_gather, dist.all_reduce = real_gather, real_reduce
+    flat = torch.cat([p.detach().reshape(-1) for p in mc.parameters() + mf.parameters()])
+    return losses, flat.numpy(), _two_steps.nbytes, calls
+
+
+def _two_steps(rays, z, target, labels, mc, mf, args, opt, render, penalizer):
+    losses = []
     for _ in range(2):
         loss, nbytes = D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, INS, render=render,
                                             mse=lambda a, b: ((a - b) ** 2).mean(),
                                             criterion=lambda p, gt: O.ins_criterion(p, gt, INS)[0].sum(), penalizer=penalizer)
         losses.append(float(loss))
-    flat = torch.cat([p.detach().reshape(-1) for p in mc.parameters() + mf.parameters()])
-    return losses, flat.numpy(), nbytes
+    _two_steps.nbytes = nbytes
+    return losses
 
 
 def _train_worker(rank, world, port, q, penalize=True):
@@ -257,7 +272,7 @@ def test_two_rank_sharded_training_equals_single_process(penalize):
     """Two gradient steps with jitter, a partially labelled batch (N_ins) and uneven slices: both ranks end with the
     parameters a single process reaches on the whole batch (differences: f32 summation order of the all-reduce).
     With and without the optional emptiness term (``args.penalize``, train_dmsr.py:51-58)."""
-    want_losses, want, nb0 = _train_two_steps(penalize)
+    want_losses, want, nb0, _ = _train_two_steps(penalize)
     assert nb0 == 0
     _, _, sd_c, sd_f = _scene()
     start = torch.cat([v.reshape(-1) for v in list(sd_c.values()) + list(sd_f.values())]).numpy()
@@ -272,9 +287,66 @@ def test_two_rank_sharded_training_equals_single_process(penalize):
         p.join(60)
         assert p.exitcode == 0
     n_param = want.size
-    for rank, losses, flat, nbytes in res:
+    for rank, losses, flat, nbytes, calls in res:
         assert nbytes == 4 * n_param                        # ONE flat bucket with both models' gradients
+        if not penalize:                                    # (the injected penalizer of this test gathers on its own)
+            # per step: ONE packed all-gather (rgb | ins of both levels) and ONE gradient all-reduce
+            assert calls == {"gather": 2, "reduce": 2}, calls
         assert np.allclose(losses, want_losses, rtol=1e-5), (losses, want_losses)
         assert np.abs(flat - want).max() <= 1e-6, np.abs(flat - want).max()
         assert np.abs(flat - start).max() >= 1e-3           # ... of steps that did move the weights
     assert np.array_equal(res[0][2], res[1][2])            # the replicas stay bit-identical
+
+
+# ---- the 8-GPU node's world size (and a non-divisor) on CPU ---------------------------------------------------------
+def _wide_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = {h: [t.numpy() for t in _frame(h)] for h in (H, 5)}       # 10 rows: uneven bands; 5 rows: some ranks own NO row
+        lab = [t.numpy() for t in _frame(5, labels_only=True)]
+        losses, flat, nbytes, calls = _train_two_steps(False)
+        q.put((rank, frames, lab, losses, flat, nbytes, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [8, 7])
+def test_wide_worlds_frame_and_training_equal_single_process(world):
+    """World size 8 (the node the scaling bench runs on) and 7 (divides nothing): row bands of 2/1 rows, a 5-row frame on which
+    ranks 5.. own no ray at all and still take part in the frame's one all-gather (that once raised on the empty rank
+    and hung the others), ray slices of 4/3 rays with the labelled tail (N_ins) spread over the last ranks.  Every rank ends with
+    the same frame bit for bit (the single-process one to the oracle's chunk-position ulp) and the single-process parameters to summation order."""
+    single = {h: [t.numpy() for t in _frame(h)] for h in (H, 5)}
+    lab1 = [t.numpy() for t in _frame(5, labels_only=True)]
+    want_losses, want, _, _ = _train_two_steps(False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, frames, lab, losses, flat, nbytes, calls in res:
+        for h in (H, 5):
+            # (the renderer injected here is the CPU oracle, whose vectorised sigmoid / exp are not bit-invariant to where a ray
+            # falls in a chunk: one ulp on a few elements when the chunk sizes differ from the single-process ones.  The sharding
+            # itself moves bytes: every rank holds the same frame, bit for bit.)
+            assert all(np.allclose(a, b, rtol=0, atol=2.5e-7) for a, b in zip(frames[h], single[h])), (rank, h)
+            assert all(np.array_equal(a, b) for a, b in zip(frames[h], res[0][1][h])), (rank, h)
+        assert np.array_equal(lab[1], lab1[1]) and lab[1].dtype == np.int64
+        assert all(np.allclose(a, b, rtol=0, atol=2.5e-7) for a, b in zip(lab, lab1))
+        assert calls == {"gather": 2, "reduce": 2}, calls
+        assert np.allclose(losses, want_losses, rtol=1e-5), (losses, want_losses)
+        assert np.abs(flat - want).max() <= 2e-6, np.abs(flat - want).max()
+        assert np.array_equal(flat, res[0][4])                              # replicas bit-identical
+    for r in range(world):                                                  # the index helpers at these sizes
+        assert D.ray_slice(TN, r, world)[1] in (TN // world, TN // world + 1)
+    idx = D._compact_index([D.row_band(5, r, world)[1] * W for r in range(world)], W, "cpu")
+    assert idx.numel() == 5 * W and torch.equal(idx, torch.arange(5 * W))   # (ranks 0..4 own one row each, contiguous at the front)
