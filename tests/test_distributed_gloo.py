@@ -221,8 +221,11 @@ def _train_two_steps(penalize=True):
                                  tolerance=0.05 if penalize else None, deta_w=0.05 if penalize else None)
     sizes = [D.ray_slice(TN, r, D.world_info()[1])[1] for r in range(D.world_info()[1])]
 
+    seen = []
+
     def render(r, zz, a, tr, uu):
         assert a.N_ins is None                               # the label slice belongs to the gathered batch
+        seen.append((tr.clone(), uu.clone()))                # the jitter rows this rank was handed
         return O.dm_nerf(r, mc.sd, mf.sd, zz, perturb=1., N_importance=TIMP, is_train=True, N_ins=None, t_rand=tr, u=uu)
 
     def penalizer(out, lvl, rays_d):                         # exact batch-global semantics through gather_batch
@@ -242,7 +245,8 @@ def _train_two_steps(penalize=True):
     finally:
         dist.all_gather, dist.all_reduce = real_gather, real_reduce
     flat = torch.cat([p.detach().reshape(-1) for p in mc.parameters() + mf.parameters()])
-    return losses, flat.numpy(), _two_steps.nbytes, calls
+    draws = [torch.cat([a, b], 1).numpy() for a, b in seen]  # per step: [n_local, S + N_importance]
+    return losses, flat.numpy(), _two_steps.nbytes, calls, draws
 
 
 def _two_steps(rays, z, target, labels, mc, mf, args, opt, render, penalizer):
@@ -272,7 +276,7 @@ def test_two_rank_sharded_training_equals_single_process(penalize):
     """Two gradient steps with jitter, a partially labelled batch (N_ins) and uneven slices: both ranks end with the
     parameters a single process reaches on the whole batch (differences: f32 summation order of the all-reduce).
     With and without the optional emptiness term (``args.penalize``, train_dmsr.py:51-58)."""
-    want_losses, want, nb0, _ = _train_two_steps(penalize)
+    want_losses, want, nb0, _, draws1 = _train_two_steps(penalize)
     assert nb0 == 0
     _, _, sd_c, sd_f = _scene()
     start = torch.cat([v.reshape(-1) for v in list(sd_c.values()) + list(sd_f.values())]).numpy()
@@ -287,7 +291,12 @@ def test_two_rank_sharded_training_equals_single_process(penalize):
         p.join(60)
         assert p.exitcode == 0
     n_param = want.size
-    for rank, losses, flat, nbytes, calls in res:
+    # ray i's jitter does not depend on the world size: the ranks' rows, in rank order, ARE the single-process draws (full-size
+    # draws from the identically seeded generator, then sliced; render.py:46 / helpers.py:135 order)
+    by_rank = sorted(res, key=lambda r: r[0])
+    for step in range(2):
+        assert np.array_equal(np.concatenate([r[5][step] for r in by_rank], 0), draws1[step])
+    for rank, losses, flat, nbytes, calls, _ in res:
         assert nbytes == 4 * n_param                        # ONE flat bucket with both models' gradients
         if not penalize:                                    # (the injected penalizer of this test gathers on its own)
             # per step: ONE packed all-gather (rgb | ins of both levels) and ONE gradient all-reduce
@@ -306,8 +315,8 @@ def _wide_worker(rank, world, port, q):
     try:
         frames = {h: [t.numpy() for t in _frame(h)] for h in (H, 5)}       # 10 rows: uneven bands; 5 rows: some ranks own NO row
         lab = [t.numpy() for t in _frame(5, labels_only=True)]
-        losses, flat, nbytes, calls = _train_two_steps(False)
-        q.put((rank, frames, lab, losses, flat, nbytes, calls))
+        losses, flat, nbytes, calls, draws = _train_two_steps(False)
+        q.put((rank, frames, lab, losses, flat, nbytes, calls, draws))
     finally:
         dist.destroy_process_group()
 
@@ -321,7 +330,7 @@ def test_wide_worlds_frame_and_training_equal_single_process(world):
     the same frame bit for bit (the single-process one to the oracle's chunk-position ulp) and the single-process parameters to summation order."""
     single = {h: [t.numpy() for t in _frame(h)] for h in (H, 5)}
     lab1 = [t.numpy() for t in _frame(5, labels_only=True)]
-    want_losses, want, _, _ = _train_two_steps(False)
+    want_losses, want, _, _, draws1 = _train_two_steps(False)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -333,7 +342,10 @@ def test_wide_worlds_frame_and_training_equal_single_process(world):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world))
-    for rank, frames, lab, losses, flat, nbytes, calls in res:
+    by_rank = sorted(res, key=lambda r: r[0])
+    for step in range(2):                                                   # jitter of ray i independent of the world size
+        assert np.array_equal(np.concatenate([r[7][step] for r in by_rank], 0), draws1[step])
+    for rank, frames, lab, losses, flat, nbytes, calls, _ in res:
         for h in (H, 5):
             # (the renderer injected here is the CPU oracle, whose vectorised sigmoid / exp are not bit-invariant to where a ray
             # falls in a chunk: one ulp on a few elements when the chunk sizes differ from the single-process ones.  The sharding
