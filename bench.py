@@ -618,7 +618,11 @@ def main():
     args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None)
     fr = D.FrameRenderer(H_IMG, W_IMG, K, c2w.to(dev), (mc, mf), NEAR, FAR, args, chunk=n_step, n_samples=S_COARSE)
     ro, rd = fr.rays_o, fr.rays_d
-    n_chunks = ro.shape[0] // n_step                           # whole chunks of the band (a ragged tail chunk is not a bench step)
+    # the steps cycle through ALL chunks of the band, as render_frame does: at N > 1 the band (307 200 / N rays) is not a multiple
+    # of 4096 and ends in a ragged chunk (tester.py:65-67) -- it is rendered like the others, so that every gathered frame is
+    # complete, and `value` counts the rays each step really rendered (N = 1: 75 chunks of 4096, no ragged one)
+    n_chunks = fr.n_chunks
+    chunk_rays = [min(n_step, fr.n_local - c * n_step) for c in range(n_chunks)]
     z = fr.z_full
     mc.blob(); mf.blob()                                        # packed weights resident
     # setup, not a step: load the code objects (a 32-ray render) and create the RCCL communicator (one scalar all-reduce),
@@ -669,10 +673,15 @@ def main():
             gather_frame()                                      # fewer steps than a band has chunks: the frame's gather is still timed
         barrier()
         dt = time.perf_counter() - t0
+    rays_rank = sum(chunk_rays[i % n_chunks] for i in range(a.steps))      # rays THIS rank rendered in the timed region
+    rays_total = rays_rank
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        cnt = torch.tensor([rays_rank], device=dev, dtype=torch.float64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        rays_total = int(cnt.item())
 
     train_multi = None
     if world > 1 and not a.no_train:
@@ -699,9 +708,10 @@ def main():
                 assert torch.equal(out['rgb_fine'], out_rgb), "frame driver and dm_nerf disagree on the same chunk"
         # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
         k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else float("nan")
-        flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * n_step
+        # (average over the timed launches of rank 0; with a ragged chunk among them, the average launch is that much smaller)
+        flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * (rays_rank / max(a.steps, 1))
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
-        rays_per_s = world * n_step * a.steps / dt
+        rays_per_s = rays_total / dt
         traffic, traffic_src = pmc_traffic() if (INS_NUM == 13 and n_step == N_RAYS) else (None, None)
         res = {
             "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
@@ -709,7 +719,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,") + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
                                    f"{n_step}-ray chunk per step per GPU, det sampling, ins_num={INS_NUM}, random-init weights",
-                       "rays_per_step_per_gpu": n_step,
+                       "rays_per_step_per_gpu": n_step, "rays_in_timed_region": rays_total,
+                       "chunks_per_band": n_chunks, "ragged_chunk_rays": (chunk_rays[-1] if chunk_rays and chunk_rays[-1] != n_step else 0),
                        "parallelism": f"ray-sharded x{world}" + (f" + one RCCL all-gather of the rank's band per frame ({gathers[0]} in the timed region)" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -770,6 +781,13 @@ def main():
                     res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
         if train_multi is not None:
             res["train"] = train_multi
+        t = res.get("train")
+        if isinstance(t, dict) and "error" not in t:            # top-level scalars: the training claim in the driver's parsed record
+            res["train_ms_per_step"] = t["ms_per_step"]
+            res["train_rays_per_s"] = t["rays_per_s"]
+            res["train_batch_rays"] = t["batch_rays"]
+            res["train_roofline_frac_worst"] = None if not t.get("roofline") else t["roofline"]["frac"]
+            res["train_step_frac_of_mfma_peak"] = t["frac_of_mfma_peak"]["executed"]
     if world > 1:
         dist.barrier()                                          # nobody is still printing
     flush_c_stdio()

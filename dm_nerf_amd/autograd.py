@@ -23,6 +23,7 @@ HW = 128
 # forward, data gradient, weight gradient -- are bracketed by HIP events on the stream they are launched on and
 # ``(kernel, samples M, begin, end)`` is appended per launch.  None (the default): nothing is recorded.
 KERNEL_EVENTS = None
+PLAN_MAX_WGS = None
 
 
 class _timed:
@@ -80,7 +81,10 @@ def wgrad_plan(ins_num, M, device, max_wgs=None, split=False):
 
     import numpy as np
     if max_wgs is None:
-        max_wgs = torch.cuda.get_device_properties(device).multi_processor_count     # one workgroup per CU
+        # (PLAN_MAX_WGS: diagnostic override -- another workgroup budget gives another split of the sample axis, i.e. the SAME
+        # gradients summed in another order; tests/test_gpu_convergence.py uses it to measure how far two correct f32 trainings
+        # drift apart)
+        max_wgs = PLAN_MAX_WGS or torch.cuda.get_device_properties(device).multi_processor_count     # one workgroup per CU
     kind = "f16x2" if split == "f16x2" else ("bf16x3" if split else None)
     key = (ins_num, M, str(device), max_wgs, kind)
     if key not in _plan_cache:

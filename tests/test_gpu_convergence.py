@@ -7,9 +7,16 @@ intersection), so there is a right answer without a dataset:
   N_train = 3072 random pixels, img2mse + Hungarian-matched ins_criterion + emptiness penalizer on both levels, Adam with the
   reference's decay, perturb = 1) for 3000 steps: held-out PSNR, permutation-invariant label purity (untrained: 0.39), the
   number of object channels in use, and every loss term falling.
+  Then the TRAINED networks are rendered by the CPU oracle too: on real learned surfaces the two renderers give the same image
+  (PSNR vs ground truth within 0.05 dB -- north_star's bound --, <= 1e-3 of the pixels change label, PSNR(HIP, oracle) >= 80 dB).
 * ``test_training_trajectory_follows_the_oracle`` -- the first 300 steps at 512 rays on exactly the batches and jitter the CPU
   oracle was run on in the build container (tests/golden/make_train_traj.py -> train_traj.npz): per-term losses step by step,
-  and the held-out PSNR / purity after them, for the default kernels and both opt-in split modes.
+  and the held-out PSNR / purity after them, for the default kernels and both opt-in split modes.  A training trajectory is
+  chaotic, so the PSNR bound is not a guess: the same training is repeated on the HIP path with only the SUMMATION ORDER of the
+  weight-gradient split changed (autograd.PLAN_MAX_WGS), and the allowed gap to the oracle is 1.5 x the spread of those runs
+  (never below 0.05 dB).
+* ``test_trained_psnr_matches_the_oracle_at_the_plateau`` -- the same run continued to 2000 steps, where the PSNR has stopped
+  climbing: mean held-out PSNR at steps 1000 / 1500 / 2000 against the oracle's, bounded the same way.
 """
 import os
 import sys
@@ -43,10 +50,25 @@ def _evaluate(mc, mf, test_rays, ze, im, lab, mode):
         out = R.dm_nerf(test_rays, None, None, mc, mf, ze, eargs)
     mc.train(); mf.train()
     pred = out['ins_fine'].cpu().argmax(-1)
+    _evaluate.last = out
     return S.psnr(out['rgb_fine'].cpu(), im.reshape(-1, 3)), S.purity(pred, lab.reshape(-1)), int(len(torch.unique(pred)))
 
 
-@pytest.mark.timeout(600)
+def _oracle_render(mc, mf, test_rays, ze, chunk=4800):
+    """The held-out view through oracle/ref_cpu.dm_nerf on the networks' CURRENT weights (host cores; 19 200 rays ~ 1 min)."""
+    from oracle import ref_cpu as O
+    sd_c = {k: v.detach().cpu() for k, v in mc.state_dict().items()}
+    sd_f = {k: v.detach().cpu() for k, v in mf.state_dict().items()}
+    rays, z = test_rays.cpu(), ze.cpu()
+    rgb, ins = [], []
+    with torch.no_grad():
+        for s in range(0, rays.shape[1], chunk):
+            o = O.dm_nerf(rays[:, s:s + chunk].contiguous(), sd_c, sd_f, z[s:s + chunk].contiguous(), perturb=0.)
+            rgb.append(o['rgb_fine']); ins.append(o['ins_fine'])
+    return torch.cat(rgb), torch.cat(ins)
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode", [None, "f16x2"])
 def test_object_branch_learns_on_the_analytic_scene(mode, capsys):
     """3000 steps x 3072 rays of the shipped loop on the analytic scene (12 training views of 120 x 160 + one held out).
@@ -95,24 +117,31 @@ def test_object_branch_learns_on_the_analytic_scene(mode, capsys):
     assert psnr1 >= 28.0, psnr1
     assert pur1 >= 0.97 and used == S.N_OBJECTS + 1, (pur1, used)
     assert (last < 0.25 * first).all(), (first, last)                 # every term fell by more than 4x
+    # The trained regime, rendered by BOTH paths (tester.py:86-88 is where the reference measures PSNR): real learned surfaces --
+    # peaked weights, saturated sigmoids, confident labels -- instead of scaled random weights.
+    hip_rgb, hip_ins = _evaluate.last['rgb_fine'].cpu(), _evaluate.last['ins_fine'].cpu()
+    or_rgb, or_ins = _oracle_render(mc, mf, test_rays, ze)
+    gt = ims[-1].reshape(-1, 3)
+    psnr_or = S.psnr(or_rgb, gt)
+    flips = float((hip_ins.argmax(-1) != or_ins.argmax(-1)).float().mean())
+    agree = S.psnr(hip_rgb, or_rgb)
+    with capsys.disabled():
+        print(f"[trained regime, {mode or 'default'}] held-out PSNR vs ground truth: HIP {psnr1:.4f} dB, oracle {psnr_or:.4f} dB "
+              f"(|d| = {abs(psnr1 - psnr_or):.5f}); label flips {flips:.2e} of {hip_ins.shape[0]} pixels; PSNR(HIP, oracle) {agree:.1f} dB; "
+              f"max |d rgb| {float((hip_rgb - or_rgb).abs().max()):.2e}")
+    assert abs(psnr1 - psnr_or) <= 0.05, (psnr1, psnr_or)             # north_star: PSNR within 0.05 dB of the reference
+    assert flips <= 1e-3, flips
+    assert agree >= 80.0, agree
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode", [None, "bf16x3", "f16x2"])
-def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
-    """300 steps x 512 rays on the batches and jitter of the oracle's run (same seeds -> same numpy / CPU-generator draws).
-    A training trajectory amplifies rounding differences (ReLU boundaries, Adam's sign-like first steps), so the comparison is
-    step by step where it is tight and in windows afterwards.  Measured (r03, printed below): total loss within 1.7e-4 of the
-    oracle's over the first 20 steps for all three modes, 4e-4 .. 5e-3 over the first 100 (the largest single step of a window is
-    spiky: the same mode moved from 1.7e-3 to 5.0e-3 when only the summation order of its weight-gradient plan changed), 1.2 .. 1.6 %
-    on 20-step windows over all 300; after them the held-out PSNR is 20.87 / 21.16 / 21.13 dB (default / bf16x3 / f16x2) against the
-    oracle's 21.21 while still climbing ~0.03 dB per step -- the three GPU modes differ from the oracle no more than from each
-    other.  The bounds are ~2.5-3x those figures."""
+def _run_trajectory(mode, steps, eval_at, max_wgs=None):
+    """``steps`` steps x 512 rays on the batches and jitter of the oracle's run (same seeds -> same numpy / CPU-generator draws),
+    held-out PSNR / purity at step 0 and at ``eval_at``.  ``max_wgs``: workgroup budget of the weight-gradient split-K plan
+    (None = the default, one per CU) -- another budget sums the same products in another order, nothing else changes."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_train_traj as T
+    from dm_nerf_amd import autograd as G
     from dm_nerf_amd.networks import dm_nerf as M, evaluator as E, helpers as Hh, penalizer as P, render as R
-    g = golden("train_traj")
-    assert [int(v) for v in g["config"]] == [T.INS_NUM, T.H, T.W, T.VIEWS, T.STEPS, T.BATCH]
     dev = torch.device("cuda:0")
     poses, ims, labs, K, test_rays = _setup(T.H, T.W, T.VIEWS, dev)
     rays_v = []
@@ -128,36 +157,101 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=None, tolerance=T.TOL, deta_w=T.DW, mfma_split=mode or False)
     z = Hh.z_val_sample(T.BATCH, S.NEAR, S.FAR, 64, device=dev)
     ze = Hh.z_val_sample(T.H * T.W, S.NEAR, S.FAR, 64, device=dev)
-    psnr0, pur0, _ = _evaluate(mc, mf, test_rays, ze, ims[-1], labs[-1], mode)
+    evals = {0: _evaluate(mc, mf, test_rays, ze, ims[-1], labs[-1], mode)[:2]}
     rows = []
-    for it, (v, idx, t_rand, u) in enumerate(T.draws(), 1):
-        idx = idx.to(dev)
-        rays = rays_v[v][:, idx]
-        tc, ti = d_ims[v].reshape(-1, 3)[idx], d_labs[v].reshape(-1)[idx]
-        out = R.dm_nerf(rays.contiguous(), None, None, mc, mf, z, args, t_rand=t_rand.to(dev), u=u.to(dev))
-        t = [E.img2mse(out['rgb_fine'], tc), E.img2mse(out['rgb_coarse'], tc),
-             E.ins_criterion(out['ins_fine'], ti, T.INS_NUM)[0], E.ins_criterion(out['ins_coarse'], ti, T.INS_NUM)[0],
-             P.ins_penalizer(out['raw_fine'], out['z_vals_fine'], out['depth_fine'], rays[1], args).sum(),
-             P.ins_penalizer(out['raw_coarse'], out['z_vals_coarse'], out['depth_coarse'], rays[1], args).sum()]
-        loss = sum(t)
-        opt.zero_grad(); loss.backward(); opt.step()
-        for grp in opt.param_groups:
-            grp['lr'] = 5e-4 * (0.1 ** (it / 500000.0))
-        rows.append(torch.stack([loss.detach()] + [x.detach() for x in t]))
-    got = torch.stack(rows).double().cpu().numpy()
-    want = g["losses"].numpy() if torch.is_tensor(g["losses"]) else np.asarray(g["losses"])
-    psnr1, pur1, _ = _evaluate(mc, mf, test_rays, ze, ims[-1], labs[-1], mode)
+    G.PLAN_MAX_WGS = max_wgs
+    try:
+        for it, (v, idx, t_rand, u) in enumerate(T.draws(steps), 1):
+            idx = idx.to(dev)
+            rays = rays_v[v][:, idx]
+            tc, ti = d_ims[v].reshape(-1, 3)[idx], d_labs[v].reshape(-1)[idx]
+            out = R.dm_nerf(rays.contiguous(), None, None, mc, mf, z, args, t_rand=t_rand.to(dev), u=u.to(dev))
+            t = [E.img2mse(out['rgb_fine'], tc), E.img2mse(out['rgb_coarse'], tc),
+                 E.ins_criterion(out['ins_fine'], ti, T.INS_NUM)[0], E.ins_criterion(out['ins_coarse'], ti, T.INS_NUM)[0],
+                 P.ins_penalizer(out['raw_fine'], out['z_vals_fine'], out['depth_fine'], rays[1], args).sum(),
+                 P.ins_penalizer(out['raw_coarse'], out['z_vals_coarse'], out['depth_coarse'], rays[1], args).sum()]
+            loss = sum(t)
+            opt.zero_grad(); loss.backward(); opt.step()
+            for grp in opt.param_groups:
+                grp['lr'] = 5e-4 * (0.1 ** (it / 500000.0))
+            rows.append(torch.stack([loss.detach()] + [x.detach() for x in t]))
+            if it in eval_at:
+                evals[it] = _evaluate(mc, mf, test_rays, ze, ims[-1], labs[-1], mode)[:2]
+    finally:
+        G.PLAN_MAX_WGS = None
+    return torch.stack(rows).double().cpu().numpy(), evals
+
+
+PLAN_BUDGETS = (None, 224, 192, 160, 128)       # weight-gradient plans: the default (256 = one workgroup per CU) and four other splits
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", [None, "bf16x3", "f16x2"])
+def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
+    """300 steps x 512 rays on the batches and jitter of the oracle's run.  A training trajectory amplifies rounding differences
+    (ReLU boundaries, Adam's sign-like first steps), so the losses are compared step by step where that is tight and in windows
+    afterwards, and the PSNR after the 300 steps -- still climbing ~0.03 dB per step there -- against the CHAOS FLOOR measured in
+    the same test: the identical training with the weight-gradient partial sums taken in four other orders (PLAN_BUDGETS).  The
+    HIP path may differ from the oracle by 1.5 x the spread of those HIP-vs-HIP runs (at least 0.05 dB), no more: it is then
+    indistinguishable from a re-ordering of its own sums.  Loss bounds (r03 measurements: 1.7e-4 over the first 20 steps, 4e-4 ..
+    5e-3 over the first 100, 1.2 .. 1.6 % on 20-step windows) are ~2.5-3x those figures."""
+    g = golden("train_traj")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_train_traj as T
+    assert [int(v) for v in g["config"]] == [T.INS_NUM, T.H, T.W, T.VIEWS, T.STEPS, T.BATCH]
+    runs = {b: _run_trajectory(mode, T.STEPS, (T.STEPS,), max_wgs=b) for b in PLAN_BUDGETS}
+    got, evals = runs[None]
+    want = (g["losses"].numpy() if torch.is_tensor(g["losses"]) else np.asarray(g["losses"]))[:T.STEPS]
+    (psnr0, pur0), (psnr1, pur1) = evals[0], evals[T.STEPS]
     rel = np.abs(got[:, 0] - want[:, 0]) / np.abs(want[:, 0])
     win = lambda a: a[:, 0].reshape(-1, 20).mean(1)
     relw = np.abs(win(got) - win(want)) / np.abs(win(want))
     gp, gpu_ = [float(x) for x in g["psnr"]], [float(x) for x in g["purity"]]
+    psnrs = {b: r[1][T.STEPS][0] for b, r in runs.items()}
+    spread = max(psnrs.values()) - min(psnrs.values())
+    bound = max(0.05, 1.5 * spread)
+    gap = abs(psnr1 - gp[1])
     with capsys.disabled():
         print(f"\n[trajectory vs oracle, {mode or 'default'}] total loss: max rel gap first 20 steps {rel[:20].max():.2e}, first 100 {rel[:100].max():.2e}, "
-              f"all 300 {rel.max():.2e}; 20-step windows {relw.max():.2e};  PSNR {psnr1:.3f} dB (oracle {gp[1]:.3f}, start {gp[0]:.3f}), "
-              f"purity {pur1:.4f} (oracle {gpu_[1]:.4f})")
+              f"all 300 {rel.max():.2e}; 20-step windows {relw.max():.2e};  purity {pur1:.4f} (oracle {gpu_[1]:.4f})")
+        print(f"  gap vs spread after {T.STEPS} steps | oracle {gp[1]:.3f} dB | HIP by wgrad plan budget: "
+              + ", ".join(f"{b or 'default'}: {v:.3f}" for b, v in psnrs.items())
+              + f" | HIP-vs-HIP spread {spread:.3f} dB | HIP(default)-vs-oracle gap {gap:.3f} dB | bound max(0.05, 1.5 x spread) = {bound:.3f} dB")
     assert abs(psnr0 - gp[0]) <= 0.01 and abs(pur0 - gpu_[0]) <= 0.005        # same start
     assert rel[:20].max() <= 5e-4, rel[:20].max()                       # step by step while rounding has not been amplified yet
     assert rel[:100].max() <= 1.5e-2, rel[:100].max()
     assert relw.max() <= 0.04, relw.max()                               # 20-step windows over the whole run
-    assert abs(psnr1 - gp[1]) <= 0.8 and abs(pur1 - gpu_[1]) <= 0.02, (psnr1, gp, pur1, gpu_)
+    assert gap <= bound, (psnr1, gp[1], spread)                         # no further from the oracle than from a re-ordering of itself
+    assert abs(pur1 - gpu_[1]) <= 0.02, (pur1, gpu_)
     assert psnr1 >= gp[0] + 8.0                                         # ... and it learned: + 9.5 dB in 300 steps
+
+
+@pytest.mark.timeout(900)
+def test_trained_psnr_matches_the_oracle_at_the_plateau(golden, capsys):
+    """The same run continued to 2000 steps (the oracle's: ~55 min of CPU in the build container, make_train_traj.py): by 1000
+    steps the held-out PSNR has stopped climbing, so single checkpoints no longer carry the slope of the curve.  Mean PSNR over
+    steps 1000 / 1500 / 2000, default kernels against the oracle, bounded by the chaos floor measured alongside (three HIP runs
+    that differ in the summation order of the weight gradients only): |gap| <= max(0.05 dB, 1.5 x HIP-vs-HIP spread)."""
+    g = golden("train_traj")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_train_traj as T
+    steps_at = [int(x) for x in g["eval_steps"]]
+    assert steps_at == [0] + list(T.EVAL_AT) and steps_at[-1] == T.LONG_STEPS
+    oracle = {s: float(p) for s, p in zip(steps_at, g["eval_psnr"])}
+    late = [s for s in T.EVAL_AT if s >= 1000]
+    runs = {b: _run_trajectory(None, T.LONG_STEPS, T.EVAL_AT, max_wgs=b)[1] for b in (None, 192, 128)}
+    mean = lambda ev: float(np.mean([ev[s] if not isinstance(ev[s], tuple) else ev[s][0] for s in late]))
+    means = {b: mean(ev) for b, ev in runs.items()}
+    want = mean(oracle)
+    spread = max(means.values()) - min(means.values())
+    bound = max(0.05, 1.5 * spread)
+    gap = abs(means[None] - want)
+    with capsys.disabled():
+        print(f"\n[plateau] held-out PSNR (dB) at steps {list(T.EVAL_AT)}: oracle " + ", ".join(f"{oracle[s]:.3f}" for s in T.EVAL_AT))
+        for b, ev in runs.items():
+            print(f"  HIP, wgrad plan budget {b or 'default'}: " + ", ".join(f"{ev[s][0]:.3f}" for s in T.EVAL_AT) + f" | mean of {late}: {means[b]:.3f}")
+        print(f"  gap vs spread | oracle mean {want:.3f} | HIP-vs-HIP spread {spread:.3f} dB | HIP(default)-vs-oracle gap {gap:.3f} dB | "
+              f"bound max(0.05, 1.5 x spread) = {bound:.3f} dB; purity at {T.LONG_STEPS}: HIP {runs[None][T.LONG_STEPS][1]:.4f}, "
+              f"oracle {float(g['eval_purity'][-1]):.4f}")
+    assert gap <= bound, (means, want)
+    assert abs(runs[None][T.LONG_STEPS][1] - float(g["eval_purity"][-1])) <= 0.02

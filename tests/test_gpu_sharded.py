@@ -88,13 +88,7 @@ def test_two_rank_sharded_training_step_equals_single_process():
     assert np.array_equal(res[0][2], res[1][2])
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_multi_rank_code_path_prints_a_valid_line(scaling):
-    """The driver's SCALE run launches ``bench.py --gpus N`` under torch.distributed.run on an 8-GPU node this build never
-    sees: exercise that exact code path here with two ranks sharing the box's one GPU over gloo
-    (DMNERF_BENCH_ONE_DEVICE / DMNERF_BENCH_BACKEND) and validate the JSON line -- per-frame band gather, sharded training
-    step with the in-place gradient arena, max-over-ranks timing, both scaling modes."""
+def _run_bench(world, steps, scaling, train_steps=1, timeout=800):
     import json
     import subprocess
     import sys
@@ -103,21 +97,54 @@ def test_bench_multi_rank_code_path_prints_a_valid_line(scaling):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, DMNERF_BENCH_ONE_DEVICE="1", DMNERF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--train-steps", "1", "--scaling", scaling]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    # the driver's command line (task statement), with the two environment switches that put every rank on the box's one GPU
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "1",
+           "--train-steps", str(train_steps), "--scaling", scaling]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = [l for l in p.stdout.strip().split("\n") if l.startswith("{")][-1]
-    r = json.loads(line)
-    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 1 and r["unit"] == "rays/s" and r["scaling"] == scaling
-    per_rank = 4096 if scaling == "weak" else 2048
+    return json.loads([l for l in p.stdout.strip().split("\n") if l.startswith("{")][-1])
+
+
+def _check_line(r, world, steps, scaling, rays_expected, gathers):
+    assert r["n_gpus"] == world and r["steps"] == steps and r["warmup"] == 1 and r["unit"] == "rays/s" and r["scaling"] == scaling
+    per_rank = 4096 if scaling == "weak" else 4096 // world
     assert r["config"]["rays_per_step_per_gpu"] == per_rank
-    assert abs(r["value"] - 2 * per_rank * 4 / (r["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * r["value"]
-    assert "all-gather of the rank's band per frame" in r["config"]["parallelism"]
+    assert r["config"]["rays_in_timed_region"] == rays_expected
+    assert abs(r["value"] - rays_expected / (r["ms_per_step"] * steps * 1e-3)) <= 1e-6 * r["value"]
+    assert f"all-gather of the rank's band per frame ({gathers} in the timed region)" in r["config"]["parallelism"]
     assert r["roofline"]["bound"] == "mfma" and 0.0 < r["roofline"]["frac"] <= 1.0
     assert "cpu_baseline" not in r                                  # rank 0 at N = 1 only
     t = r["train"]
     assert "error" not in t, t
-    assert t["batch_rays"] == (8192 if scaling == "weak" else 4096) and t["rays_per_s"] > 0 and np.isfinite(t["final_loss"])
-    assert t["roofline"]["samples_per_launch"] == t["batch_rays"] // 2 * 192
+    assert t["batch_rays"] == (4096 * world if scaling == "weak" else 4096) and t["rays_per_s"] > 0 and np.isfinite(t["final_loss"])
+    assert t["roofline"]["samples_per_launch"] == t["batch_rays"] // world * 192
+    assert r["train_ms_per_step"] == t["ms_per_step"] and r["train_rays_per_s"] == t["rays_per_s"]     # top-level scalars
+    assert 0.0 < r["train_roofline_frac_worst"] <= 1.0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_code_path_prints_a_valid_line(scaling):
+    """The driver's SCALE run launches ``bench.py --gpus N`` under torch.distributed.run on an 8-GPU node this build never
+    sees: exercise that exact code path here with two ranks sharing the box's one GPU over gloo
+    (DMNERF_BENCH_ONE_DEVICE / DMNERF_BENCH_BACKEND) and validate the JSON line -- per-frame band gather, sharded training
+    step with the in-place gradient arena, max-over-ranks timing, both scaling modes."""
+    r = _run_bench(2, 4, scaling)
+    per_rank = 4096 if scaling == "weak" else 2048
+    _check_line(r, 2, 4, scaling, 2 * per_rank * 4, 1)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_eight_rank_dry_run_covers_a_whole_band(scaling):
+    """The 8-GPU run before it exists: EIGHT ranks on the one GPU over gloo, the driver's command line, and enough steps for one
+    whole band per rank -- weak: 60 rows = 38 400 rays = nine 4096-ray chunks and the ragged 1536-ray one (tester.py:65-67), then
+    the frame's single all-gather; strong: 75 chunks of 512 rays.  Every ray of the 640 x 480 frame is rendered exactly once in
+    the timed region (``rays_in_timed_region`` = 307 200), by 8 ranks, with one gather -- and the sharded training step runs at
+    world 8 (weak: a 32 768-ray batch, 4096 per rank; strong: the 4096-ray batch in 512-ray slices)."""
+    steps = 10 if scaling == "weak" else 75
+    r = _run_bench(8, steps, scaling, timeout=1400)
+    _check_line(r, 8, steps, scaling, 480 * 640, 1)
+    assert r["config"]["chunks_per_band"] == steps
+    assert r["config"]["ragged_chunk_rays"] == (1536 if scaling == "weak" else 0)
