@@ -70,6 +70,9 @@ SIGNATURES = {
     "dmnerf_penalizer_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp]),
     "dmnerf_penalizer_sums": (c_int, [c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_penalizer_finish": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_penalizer_sums2": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dmnerf_loss_tail_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_loss_tail_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan_sizes": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
@@ -109,6 +112,8 @@ SIGNATURES = {
     "dmnerf_ins_criterion_flags_offset": (c_i64, [c_i64, c_int]),
     "dmnerf_ins_criterion_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_ins_criterion_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_ins_criterion_fwd2": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dmnerf_ins_criterion_bwd2": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

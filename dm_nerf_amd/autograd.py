@@ -247,8 +247,79 @@ def _grad_scale_buffer(device):
     return torch.zeros(4, dtype=torch.float32, device=device)
 
 
+class _Overlap:
+    """State of ``overlapped_backward``: the side stream of each device, and the backward currently in flight on it."""
+    active = False
+    streams = {}
+    pending = None          # (done event, [tensors the side-stream kernels read that the main stream's allocator must not reuse yet])
+
+
+class overlapped_backward:
+    """``with overlapped_backward(): loss.backward()`` -- the two levels' network backwards run CONCURRENTLY (extension; the
+    reference's backward is one stream, train_dmsr.py:63).
+
+    The coarse and the fine network are separate autograd graphs below the loss (``z_samples.detach()``, render.py:68), so
+    their data-gradient and weight-gradient launches do not depend on each other.  Inside this context the first network
+    backward of the pass (autograd runs the fine network's first) is issued on a side stream that waits for the main one, the
+    next runs on the main stream next to it, and the main stream then waits for the side one (also when the context exits).
+    At the per-rank shard of an 8-way split (384 rays) the fine launch is 576 workgroups = 2.25 rounds of the 256 CUs and the
+    coarse one 192 = 0.75: together exactly three rounds instead of 3 + 1 (bench.py ``train_shard_proxy``).
+
+    Only for a pass whose parameter gradients start as ``None`` (``zero_grad(set_to_none=True)``: autograd then INSTALLS the
+    kernels' output as ``p.grad`` without reading it); anything that would read a gradient on the main stream before the join --
+    accumulation into existing ``.grad`` tensors -- makes ``_mlp_backward`` fall back to the main stream for that model.  Gradient
+    hooks on the parameters are the caller's responsibility (none in this package).  ``distributed.sharded_train_step`` uses it;
+    plain ``loss.backward()`` of the drop-in functions stays on one stream."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _Overlap.active
+        _Overlap.active = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _join_side()
+        _Overlap.active = self.prev
+        return False
+
+
+def _join_side():
+    """The main (current) stream waits for the side-stream backward in flight, if any; its inputs may be reused after that."""
+    if _Overlap.pending is not None:
+        done, keep = _Overlap.pending
+        torch.cuda.current_stream().wait_event(done)
+        _Overlap.pending = None
+        del keep
+
+
 def _mlp_backward(ctx, g_raw):
-    """dgrad + wgrad of one saved forward (rays or pre-embedded rows): the parameter gradients as views of one flat vector."""
+    """dgrad + wgrad of one saved forward (rays or pre-embedded rows): the parameter gradients as views of one flat vector.
+    Inside ``overlapped_backward`` the first call of a pass runs on the side stream (see there)."""
+    if (_Overlap.active and _Overlap.pending is None and ctx.M > 0 and g_raw.is_cuda
+            and all(p.grad is None for p in ctx.model.parameters())):
+        dev = g_raw.device
+        side = _Overlap.streams.get(dev.index)
+        if side is None:
+            side = _Overlap.streams[dev.index] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        # everything the side-stream kernels READ that was allocated on the main stream stays referenced until the join: freed
+        # earlier, the main stream's allocator could hand the block to a kernel that runs while they are still reading
+        keep = [g_raw, ctx.save, ctx.flat, getattr(ctx, "blob", None), getattr(ctx, "blob_t", None), getattr(ctx, "blob_ts", None)]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            grads = _mlp_backward_on_stream(ctx, g_raw)
+            done = torch.cuda.Event()
+            done.record(side)
+        _Overlap.pending = (done, keep)
+        return grads
+    grads = _mlp_backward_on_stream(ctx, g_raw)
+    _join_side()
+    return grads
+
+
+def _mlp_backward_on_stream(ctx, g_raw):
     lib = _lib.load()
     model, M = ctx.model, ctx.M
     ins_num = model.ins_num

@@ -34,6 +34,7 @@ constexpr int CR_MAXC = 128;      // channels (= ins_num) supported by the solve
 // Work buffer layout (byte offsets; everything 8-byte aligned).  L = C + 1 label values 0..C.
 struct CrLayout {
     int64_t part_b, part_t, part_a, part_s, part_cnt;     // chunk partials
+    int64_t part_flag;                                    // int [nch]: DMNERF_CRIT_* conditions seen by the chunk (plain stores: nothing to zero)
     int64_t red;                                          // double [L + 2 C + 2 L C]: counts | A | S | b | t summed over the chunks
     int64_t ce, siou, tp_all;                             // float [C][C]: rows g < V (tp_all: the soft true-positive sums)
     int64_t row4col, lab_of_row, tp_of_col, den_of_col;   // int [C], int [C], float [C], float [C]
@@ -53,6 +54,7 @@ __host__ __device__ inline CrLayout cr_layout(int64_t N, int C) {
     w.part_a = take((int64_t)w.nch * C * 4);
     w.part_s = take((int64_t)w.nch * C * 4);
     w.part_cnt = take((int64_t)w.nch * w.L * 4);
+    w.part_flag = take((int64_t)w.nch * 4);
     w.red = take((int64_t)(w.L + 2 * C + 2 * w.L * C) * 8);
     w.ce = take((int64_t)C * C * 4);
     w.siou = take((int64_t)C * C * 4);
@@ -66,10 +68,21 @@ __host__ __device__ inline CrLayout cr_layout(int64_t N, int C) {
     return w;
 }
 
+// One or two problems per launch (blockIdx.y): the two levels of a training step -- pred_fine / pred_coarse against the SAME
+// labels, N and C -- go through every kernel together (dmnerf_ins_criterion_fwd2 / _bwd2: 3 + 1 launches per step instead of 8 + 2).
+struct CrPair {
+    const float* pred[2];
+    char* work[2];
+    float* out4[2];
+    const float* gout4[2];
+    float* grad[2];
+};
+
 // ---- per-chunk partial sums ---------------------------------------------------------------------------
-__global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const float* __restrict__ pred, const int* __restrict__ labels,
-                                                             int64_t N, int C, char* __restrict__ work) {
+__global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const CrPair pr, const int* __restrict__ labels, int64_t N, int C) {
     extern __shared__ float lds[];                       // [L][C] b-sums, [L][C] P-sums, [L] counts
+    const float* __restrict__ pred = pr.pred[blockIdx.y];
+    char* __restrict__ work = pr.work[blockIdx.y];
     const CrLayout w = cr_layout(N, C);
     const int L = w.L, p = threadIdx.x;
     float* lb = lds;
@@ -79,6 +92,7 @@ __global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const float* __rest
     __syncthreads();
     const int64_t n0 = (int64_t)blockIdx.x * CR_CHUNK;
     float acc_a = 0.f, acc_s = 0.f;
+    int bad = 0;
     for (int r = 0; r < CR_CHUNK; ++r) {
         const int64_t n = n0 + r;
         if (n >= N) break;
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const float* __rest
         }
         if (p == 0 && lab_ok) lc[l] += 1;
         // a label outside [0, ins_num]: the reference's one_hot / column indexing (:21-25) would raise; here the ray
-        // takes part in no row, and the condition is reported in the flags word (zeroed by the host before this launch)
-        if (p == 0 && !lab_ok) atomicOr(reinterpret_cast<int*>(work + w.scal) + 2, DMNERF_CRIT_LABEL_RANGE);
+        // takes part in no row, and the condition is reported in the flags word (through this chunk's flag, which cr_solve_kernel ORs)
+        if (!lab_ok) bad = DMNERF_CRIT_LABEL_RANGE;
     }
     __syncthreads();
     float* pb = reinterpret_cast<float*>(work + w.part_b) + (int64_t)blockIdx.x * L * C;
@@ -110,11 +124,13 @@ __global__ __launch_bounds__(CR_MAXC) void cr_partial_kernel(const float* __rest
     }
     int* pc = reinterpret_cast<int*>(work + w.part_cnt) + (int64_t)blockIdx.x * L;
     for (int i = p; i < L; i += blockDim.x) pc[i] = lc[i];
+    if (p == 0) reinterpret_cast<int*>(work + w.part_flag)[blockIdx.x] = bad;
 }
 
 // ---- sums over the chunks: entry e of [counts (L) | A (C) | S (C) | b (L C) | t (L C)], 16 neighbouring lanes per entry (every 16th
 // chunk partial each, loads in flight together), combined in a fixed butterfly order; exact for the counts
-__global__ __launch_bounds__(256) void cr_reduce_kernel(int64_t N, int C, char* __restrict__ work) {
+__global__ __launch_bounds__(256) void cr_reduce_kernel(int64_t N, int C, const CrPair pr) {
+    char* __restrict__ work = pr.work[blockIdx.y];
     const CrLayout w = cr_layout(N, C);
     const int L = w.L, sub = threadIdx.x & 15;
     const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -152,7 +168,9 @@ __device__ __forceinline__ double wave_min_key(double v, int key, int& key_out) 
     return v;
 }
 
-__global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* __restrict__ work, float* __restrict__ out4) {
+__global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, const CrPair pr) {
+    char* __restrict__ work = pr.work[blockIdx.x];
+    float* __restrict__ out4 = pr.out4[blockIdx.x];
     const CrLayout w = cr_layout(N, C);
     const int L = w.L, tid = threadIdx.x;
     __shared__ int s_cnt[CR_MAXC + 1], s_rank[CR_MAXC + 1], s_V;
@@ -160,6 +178,15 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
     __shared__ double s_u[CR_MAXC], s_v[CR_MAXC], s_spc[CR_MAXC];
     __shared__ int s_path[CR_MAXC], s_col4row[CR_MAXC], s_row4col[CR_MAXC];
     __shared__ unsigned char s_SR[CR_MAXC], s_SC[CR_MAXC];
+    __shared__ int s_flags;
+    if (tid == 0) s_flags = 0;
+    __syncthreads();
+    {   // the chunks' condition flags -> one word (this kernel writes V, U and the flags word afresh on every call)
+        const int* pf = reinterpret_cast<const int*>(work + w.part_flag);
+        int f = 0;
+        for (int k = tid; k < w.nch; k += blockDim.x) f |= pf[k];
+        if (f) atomicOr(&s_flags, f);
+    }
     float* ce = reinterpret_cast<float*>(work + w.ce);
     float* siou = reinterpret_cast<float*>(work + w.siou);
     float* tp_all = reinterpret_cast<float*>(work + w.tp_all);
@@ -182,7 +209,7 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
             if (s_cnt[l] > 0 && v >= C) ++extra;          // more distinct labels than channels: the reference raises on
             s_rank[l] = (s_cnt[l] > 0 && v < C) ? v++ : -1;   // the one-hot column mismatch (:24); here the first C are kept
         }
-        if (extra) atomicOr(reinterpret_cast<int*>(work + w.scal) + 2, DMNERF_CRIT_TOO_MANY_LABELS);
+        if (extra) atomicOr(&s_flags, DMNERF_CRIT_TOO_MANY_LABELS);
         s_V = v;
     }
     __syncthreads();
@@ -290,13 +317,16 @@ __global__ __launch_bounds__(256) void cr_solve_kernel(int64_t N, int C, char* _
         out4[0] = valid_ce + invalid_ce + valid_siou;
         out4[1] = valid_ce; out4[2] = invalid_ce; out4[3] = valid_siou;
         int* sc = reinterpret_cast<int*>(work + w.scal);
-        sc[0] = V; sc[1] = U;
+        sc[0] = V; sc[1] = U; sc[2] = s_flags; sc[3] = 0;
     }
 }
 
 // ---- backward: elementwise -------------------------------------------------------------------------------
-__global__ void cr_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ labels, int64_t N, int C,
-                              const char* __restrict__ work, const float* __restrict__ gout4, float* __restrict__ grad) {
+__global__ void cr_bwd_kernel(const CrPair pr, const int* __restrict__ labels, int64_t N, int C) {
+    const float* __restrict__ pred = pr.pred[blockIdx.y];
+    const char* __restrict__ work = pr.work[blockIdx.y];
+    const float* __restrict__ gout4 = pr.gout4[blockIdx.y];
+    float* __restrict__ grad = pr.grad[blockIdx.y];
     const CrLayout w = cr_layout(N, C);
     const int* row4col = reinterpret_cast<const int*>(work + w.row4col);
     const int* lab_of_row = reinterpret_cast<const int*>(work + w.lab_of_row);
@@ -340,10 +370,11 @@ extern "C" int64_t dmnerf_ins_criterion_flags_offset(int64_t N, int ins_num) {
     return cr_layout(N, ins_num).scal + 8;
 }
 
-extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, void* d_work,
-                                        int64_t work_bytes, float* d_out4, void* stream) {
+static int cr_forward(const CrPair& pr, int levels, const int32_t* d_labels, int64_t N, int ins_num, int64_t work_bytes, void* stream) {
     if (N < 1 || ins_num < 1 || ins_num > CR_MAXC) return dmn_fail(DMNERF_E_ARG, "ins_criterion: bad N=%lld ins_num=%d (max %d)", (long long)N, ins_num, CR_MAXC);
-    if (!d_pred || !d_labels || !d_work || !d_out4) return dmn_fail(DMNERF_E_ARG, "ins_criterion: null pointer");
+    for (int l = 0; l < levels; ++l)
+        if (!pr.pred[l] || !pr.work[l] || !pr.out4[l]) return dmn_fail(DMNERF_E_ARG, "ins_criterion: null pointer");
+    if (!d_labels) return dmn_fail(DMNERF_E_ARG, "ins_criterion: null pointer");
     const CrLayout w = cr_layout(N, ins_num);
     if (work_bytes < w.total) return dmn_fail(DMNERF_E_ARG, "ins_criterion: work buffer too small (%lld < %lld bytes)", (long long)work_bytes, (long long)w.total);
     const size_t lds = (size_t)(2 * w.L * ins_num + w.L) * sizeof(float);
@@ -352,27 +383,57 @@ extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_la
                                                                 2 * (CR_MAXC + 1) * CR_MAXC * 4 + (CR_MAXC + 1) * 4); });
         e != hipSuccess)
         return dmn_fail_hip(e, "ins_criterion: hipFuncSetAttribute");
-    // V, U and the flags word start at zero (a memset node: still no allocation, no sync, graph-capturable)
-    if (hipError_t e = hipMemsetAsync((char*)d_work + w.scal, 0, 16, (hipStream_t)stream); e != hipSuccess)
-        return dmn_fail_hip(e, "ins_criterion: hipMemsetAsync");
-    hipLaunchKernelGGL(cr_partial_kernel, dim3((unsigned)w.nch), dim3(CR_MAXC), lds, (hipStream_t)stream, d_pred, (const int*)d_labels, N, ins_num, (char*)d_work);
+    // (no memset: V, U and the flags word are written afresh by cr_solve_kernel; the chunks report through plain stores)
+    hipLaunchKernelGGL(cr_partial_kernel, dim3((unsigned)w.nch, (unsigned)levels), dim3(CR_MAXC), lds, (hipStream_t)stream, pr, (const int*)d_labels, N, ins_num);
     int rc = dmn_check_launch("ins_criterion: partial sums");
     if (rc) return rc;
     const int n_ent = w.L + 2 * ins_num + 2 * w.L * ins_num;
-    hipLaunchKernelGGL(cr_reduce_kernel, dim3((unsigned)((n_ent + 15) / 16)), dim3(256), 0, (hipStream_t)stream, N, ins_num, (char*)d_work);
+    hipLaunchKernelGGL(cr_reduce_kernel, dim3((unsigned)((n_ent + 15) / 16), (unsigned)levels), dim3(256), 0, (hipStream_t)stream, N, ins_num, pr);
     rc = dmn_check_launch("ins_criterion: chunk sums");
     if (rc) return rc;
-    hipLaunchKernelGGL(cr_solve_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, ins_num, (char*)d_work, d_out4);
+    hipLaunchKernelGGL(cr_solve_kernel, dim3((unsigned)levels), dim3(256), 0, (hipStream_t)stream, N, ins_num, pr);
     return dmn_check_launch("ins_criterion: solve");
+}
+
+static int cr_backward(const CrPair& pr, int levels, const int32_t* d_labels, int64_t N, int ins_num, void* stream) {
+    if (N < 1 || ins_num < 1 || ins_num > CR_MAXC) return dmn_fail(DMNERF_E_ARG, "ins_criterion_bwd: bad N=%lld ins_num=%d", (long long)N, ins_num);
+    for (int l = 0; l < levels; ++l)
+        if (!pr.pred[l] || !pr.work[l] || !pr.gout4[l] || !pr.grad[l]) return dmn_fail(DMNERF_E_ARG, "ins_criterion_bwd: null pointer");
+    if (!d_labels) return dmn_fail(DMNERF_E_ARG, "ins_criterion_bwd: null pointer");
+    const int64_t total = N * ins_num;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cr_bwd_kernel, dim3(blocks, (unsigned)levels), dim3(256), 0, (hipStream_t)stream, pr, (const int*)d_labels, N, ins_num);
+    return dmn_check_launch("ins_criterion_bwd");
+}
+
+extern "C" int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, void* d_work,
+                                        int64_t work_bytes, float* d_out4, void* stream) {
+    CrPair pr{};
+    pr.pred[0] = d_pred; pr.work[0] = (char*)d_work; pr.out4[0] = d_out4;
+    return cr_forward(pr, 1, d_labels, N, ins_num, work_bytes, stream);
 }
 
 extern "C" int dmnerf_ins_criterion_bwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, const void* d_work,
                                         const float* d_gout4, float* d_grad_pred, void* stream) {
-    if (N < 1 || ins_num < 1 || ins_num > CR_MAXC) return dmn_fail(DMNERF_E_ARG, "ins_criterion_bwd: bad N=%lld ins_num=%d", (long long)N, ins_num);
-    if (!d_pred || !d_labels || !d_work || !d_gout4 || !d_grad_pred) return dmn_fail(DMNERF_E_ARG, "ins_criterion_bwd: null pointer");
-    const int64_t total = N * ins_num;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(cr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_pred, (const int*)d_labels, N, ins_num, (const char*)d_work,
-                       d_gout4, d_grad_pred);
-    return dmn_check_launch("ins_criterion_bwd");
+    CrPair pr{};
+    pr.pred[0] = d_pred; pr.work[0] = (char*)const_cast<void*>(d_work); pr.gout4[0] = d_gout4; pr.grad[0] = d_grad_pred;
+    return cr_backward(pr, 1, d_labels, N, ins_num, stream);
+}
+
+extern "C" int dmnerf_ins_criterion_fwd2(const float* d_pred_a, const float* d_pred_b, const int32_t* d_labels, int64_t N, int ins_num,
+                                         void* d_work_a, void* d_work_b, int64_t work_bytes, float* d_out4_a, float* d_out4_b, void* stream) {
+    CrPair pr{};
+    pr.pred[0] = d_pred_a; pr.pred[1] = d_pred_b; pr.work[0] = (char*)d_work_a; pr.work[1] = (char*)d_work_b;
+    pr.out4[0] = d_out4_a; pr.out4[1] = d_out4_b;
+    return cr_forward(pr, 2, d_labels, N, ins_num, work_bytes, stream);
+}
+
+extern "C" int dmnerf_ins_criterion_bwd2(const float* d_pred_a, const float* d_pred_b, const int32_t* d_labels, int64_t N, int ins_num,
+                                         const void* d_work_a, const void* d_work_b, const float* d_gout4_a, const float* d_gout4_b,
+                                         float* d_grad_a, float* d_grad_b, void* stream) {
+    CrPair pr{};
+    pr.pred[0] = d_pred_a; pr.pred[1] = d_pred_b;
+    pr.work[0] = (char*)const_cast<void*>(d_work_a); pr.work[1] = (char*)const_cast<void*>(d_work_b);
+    pr.gout4[0] = d_gout4_a; pr.gout4[1] = d_gout4_b; pr.grad[0] = d_grad_a; pr.grad[1] = d_grad_b;
+    return cr_backward(pr, 2, d_labels, N, ins_num, stream);
 }

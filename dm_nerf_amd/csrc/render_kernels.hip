@@ -817,7 +817,11 @@ extern "C" int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const 
 // The scalar tail of emptiness_penalizer (penalizer.py:44-55) on the device: the per-ray partials -> 4 sums (one block, fixed
 // order: deterministic), then loss = S0 / (C max(S1, 1e-8)) + S2 / max(S3, 1e-8) and the two factors the backward multiplies by.
 // Two launches instead of the ~14 scalar tensor operations of the same formulas (sum, clamp, mul, div, add, casts).
-__global__ __launch_bounds__(1024) void penalizer_sums_kernel(const double* __restrict__ part, int64_t N, double* __restrict__ sums4) {
+struct PenSumsArgs { const double* part[2]; int64_t N[2]; double* sums4[2]; };     // one block per problem (two levels per launch)
+__global__ __launch_bounds__(1024) void penalizer_sums_kernel(const PenSumsArgs a) {
+    const double* __restrict__ part = a.part[blockIdx.x];
+    const int64_t N = a.N[blockIdx.x];
+    double* __restrict__ sums4 = a.sums4[blockIdx.x];
     __shared__ double red[1024][4];
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t i = threadIdx.x; i < N; i += 1024)
@@ -844,8 +848,21 @@ __global__ void penalizer_finish_kernel(const double* __restrict__ sums4, int C,
 
 extern "C" int dmnerf_penalizer_sums(const double* d_partials, int64_t N, double* d_sums4, void* stream) {
     if (N < 0 || !d_sums4 || (N > 0 && !d_partials)) return dmn_fail(DMNERF_E_ARG, "penalizer_sums: bad argument");
-    hipLaunchKernelGGL(penalizer_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_partials, N, d_sums4);
+    PenSumsArgs a{};
+    a.part[0] = d_partials; a.N[0] = N; a.sums4[0] = d_sums4;
+    hipLaunchKernelGGL(penalizer_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return dmn_check_launch("penalizer_sums");
+}
+
+extern "C" int dmnerf_penalizer_sums2(const double* d_partials_a, int64_t N_a, const double* d_partials_b, int64_t N_b, double* d_sums8,
+                                      void* stream) {
+    if (N_a < 0 || N_b < 0 || !d_sums8 || (N_a > 0 && !d_partials_a) || (N_b > 0 && !d_partials_b))
+        return dmn_fail(DMNERF_E_ARG, "penalizer_sums2: bad argument");
+    PenSumsArgs a{};
+    a.part[0] = d_partials_a; a.N[0] = N_a; a.sums4[0] = d_sums8;
+    a.part[1] = d_partials_b; a.N[1] = N_b; a.sums4[1] = d_sums8 + 4;
+    hipLaunchKernelGGL(penalizer_sums_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, a);
+    return dmn_check_launch("penalizer_sums2");
 }
 
 extern "C" int dmnerf_penalizer_finish(const double* d_sums4, int C, float* d_loss1, float* d_inv2, void* stream) {

@@ -183,6 +183,25 @@ def allreduce_sums(t):
     return t
 
 
+def overlap_enabled(n_local, n_coarse, n_fine, device):
+    """Whether the step runs the two levels' network backwards on two streams (autograd.overlapped_backward).
+
+    Worth it exactly when it removes a partial round: the data-gradient kernel runs one 128-sample workgroup per CU at a time, so
+    the fine launch takes ceil(wg_fine / CUs) rounds and the coarse one ceil(wg_coarse / CUs) after it; side by side they take
+    ceil((wg_fine + wg_coarse) / CUs).  At the 384-ray shard of an 8-way split: 576 + 192 workgroups on 256 CUs, 3 + 1 rounds
+    against 3 (measured, profiles/r04: 3.88 -> 3.72 ms per step); at 512 / 3072 / 4096 rays both launches are whole rounds and two
+    streams only add contention (+1 .. 2 %, same measurement), so they stay on one.  ``DMNERF_OVERLAP_BWD`` = 0 / 1 forces it."""
+    env = os.environ.get("DMNERF_OVERLAP_BWD")
+    if env is not None:
+        return env != "0"
+    if device.type != "cuda":
+        return False
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    wg_f, wg_c = -(-n_local * n_fine // 128), -(-n_local * n_coarse // 128)
+    rounds = lambda w: -(-w // cus)
+    return rounds(wg_f) + rounds(wg_c) > rounds(wg_f + wg_c)
+
+
 def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, ins_num,
                        render=None, mse=None, criterion=None, penalizer=None, t_rand=None, u=None):
     """One optimisation step of train_dmsr.py:26-64 with the ray batch sharded over the ranks, producing the SAME
@@ -210,6 +229,7 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     from .networks import evaluator as E, penalizer as P, render as R
     rank, world = world_info()
     arena = None
+    render_is_hip = render is None
     if render is None and world > 1:                     # HIP path: backward writes both models' gradients into one buffer
         from . import autograd
         arena = autograd.grad_arena(models)
@@ -228,10 +248,6 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     n_ins = getattr(args, "N_ins", None)
     largs.N_ins = None                                   # the label slice is taken on the gathered batch
     render = render or (lambda r, z, a, tr, uu: R.dm_nerf(r, None, None, models[0], models[1], z, a, t_rand=tr, u=uu))
-    mse = mse or E.img2mse
-    criterion = criterion or (lambda pred, gt: E.ins_criterion(pred, gt, ins_num)[0])
-    penalizer = penalizer or (lambda out, lvl, rays_d: P.ins_penalizer(out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl],
-                                                                       rays_d, largs, sharded=True))
     out = render(rays[:, sl].contiguous(), z_vals[sl].contiguous(), largs,
                  None if t_rand is None else t_rand[sl].contiguous(),
                  None if u is None else (u if u.dim() == 1 else u[sl].contiguous()))      # a 1-D u is the grid shared by all rays
@@ -247,17 +263,35 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
         rgb_f, rgb_c, ins_f, ins_c = torch.split(packed, widths, -1)
     else:
         rgb_f, rgb_c, ins_f, ins_c = (out['rgb_fine'], out['rgb_coarse'], out['ins_fine'], out['ins_coarse'])
-    loss = 0.
-    for lvl, rgb, ins in (("fine", rgb_f, ins_f), ("coarse", rgb_c, ins_c)):
+    if render_is_hip and mse is None and criterion is None and penalizer is None and os.environ.get("DMNERF_FUSED_TAIL", "1") != "0":
+        # the HIP path's own loss tail: the same sum as the loop below as ONE autograd node (dm_nerf_amd/losses.py) -- the
+        # object-code loss of both levels per launch, the scalar arithmetic in two kernels instead of some forty
+        from . import losses
         if n_ins is not None:
-            ins = ins[-n_ins:]
-        loss = loss + mse(rgb, target) + criterion(ins, labels)
-        if penalize:
-            loss = loss + penalizer(out, lvl, rays[1, sl]).sum()
+            ins_f, ins_c = ins_f[-n_ins:], ins_c[-n_ins:]
+        loss, _ = losses.train_losses(out, rays[1, sl], target, labels, ins_num, largs, rgb_ins=(rgb_f, rgb_c, ins_f, ins_c),
+                                      sharded=world > 1)
+    else:
+        mse = mse or E.img2mse
+        criterion = criterion or (lambda pred, gt: E.ins_criterion(pred, gt, ins_num)[0])
+        penalizer = penalizer or (lambda o, lvl, rays_d: P.ins_penalizer(o['raw_' + lvl], o['z_vals_' + lvl], o['depth_' + lvl],
+                                                                         rays_d, largs, sharded=True))
+        loss = 0.
+        for lvl, rgb, ins in (("fine", rgb_f, ins_f), ("coarse", rgb_c, ins_c)):
+            if n_ins is not None:
+                ins = ins[-n_ins:]
+            loss = loss + mse(rgb, target) + criterion(ins, labels)
+            if penalize:
+                loss = loss + penalizer(out, lvl, rays[1, sl]).sum()
     optimizer.zero_grad(set_to_none=True)
     if arena is not None:
         arena.begin_step()
-    loss.backward()
+    if render_is_hip:
+        from . import autograd
+        with autograd.overlapped_backward(overlap_enabled(cnt, z_vals.shape[1], z_vals.shape[1] + n_imp, rays.device)):   # coarse and fine network backwards side by side (two streams)
+            loss.backward()
+    else:
+        loss.backward()
     nbytes = allreduce_grads(models, arena=arena)
     optimizer.step()
     return loss.detach(), nbytes

@@ -321,6 +321,27 @@ int dmnerf_ins_criterion_fwd(const float* d_pred, const int32_t* d_labels, int64
                              int64_t work_bytes, float* d_out4, void* stream);
 int dmnerf_ins_criterion_bwd(const float* d_pred, const int32_t* d_labels, int64_t N, int ins_num, const void* d_work,
                              const float* d_gout4, float* d_grad_pred, void* stream);
+/* The same two calls for TWO predictions against the same labels -- the fine and the coarse level of a training step
+ * (train_dmsr.py:38-47) -- in one launch per kernel; each with its own work buffer (work_bytes each) and outputs. */
+int dmnerf_ins_criterion_fwd2(const float* d_pred_a, const float* d_pred_b, const int32_t* d_labels, int64_t N, int ins_num,
+                              void* d_work_a, void* d_work_b, int64_t work_bytes, float* d_out4_a, float* d_out4_b, void* stream);
+int dmnerf_ins_criterion_bwd2(const float* d_pred_a, const float* d_pred_b, const int32_t* d_labels, int64_t N, int ins_num,
+                              const void* d_work_a, const void* d_work_b, const float* d_gout4_a, const float* d_gout4_b,
+                              float* d_grad_a, float* d_grad_b, void* stream);
+
+/* ---- the scalar tail of the training step (train_dmsr.py:33-61; extension: the reference forms it from tensor operations) ----
+ * loss = sum over the levels a (fine), b (coarse) of img2mse(rgb, target) (evaluator.py:11) + ins_criterion (out4[0] of the
+ * calls above; nullable) + emptiness penalizer (penalizer.py:43-55 from the four batch sums of dmnerf_penalizer_sums / _sums2;
+ * nullable), added in f32 in the training loop's order.  _fwd: d_terms8 = {mse_a, crit_a, pen_a, mse_b, crit_b, pen_b, total, 0},
+ * d_pen_inv4 = the penalizer's two normalisers per level.  _bwd, for the upstream scalar d_g_total: d loss / d rgb of both
+ * levels ((g / 3N) * (2 (rgb - target)), the products autograd forms), d_gout8 = {g, 0, 0, 0} x 2 for dmnerf_ins_criterion_bwd2
+ * and d_pen_scales4 = d_pen_inv4 * g for dmnerf_penalizer_bwd.  One launch each. */
+int dmnerf_loss_tail_fwd(const float* d_rgb_a, const float* d_rgb_b, const float* d_target, int64_t N,
+                         const float* d_crit_out4_a, const float* d_crit_out4_b, const double* d_pen_sums4_a,
+                         const double* d_pen_sums4_b, int C, float* d_terms8, float* d_pen_inv4, void* stream);
+int dmnerf_loss_tail_bwd(const float* d_rgb_a, const float* d_rgb_b, const float* d_target, int64_t N,
+                         const float* d_g_total, const float* d_pen_inv4, float* d_grad_rgb_a, float* d_grad_rgb_b,
+                         float* d_gout8, float* d_pen_scales4, void* stream);
 
 /* ---- manipulator.py (scene editing at render time) -----------------------------------
  * manipulator_render (networks/manipulator.py:86-105): render_train whose object map keeps all C channels
@@ -361,6 +382,9 @@ int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const float* d_de
  * writes d_loss1 = (float)(S0 / (C max(S1,1e-8)) + S2 / max(S3,1e-8)) and d_inv2 = {1 / (C max(S1,1e-8)), 1 / max(S3,1e-8)}
  * (float; d_scales of _bwd = d_inv2 * upstream gradient). */
 int dmnerf_penalizer_sums(const double* d_partials, int64_t N, double* d_sums4, void* stream);
+/* ... of two levels in one launch: d_sums8 = the four sums of a, then of b. */
+int dmnerf_penalizer_sums2(const double* d_partials_a, int64_t N_a, const double* d_partials_b, int64_t N_b, double* d_sums8,
+                           void* stream);
 int dmnerf_penalizer_finish(const double* d_sums4, int C, float* d_loss1, float* d_inv2, void* stream);
 
 /* dm_nerf inference (networks/render.py:31-96, perturb handled by the caller passing t_rand/u):
