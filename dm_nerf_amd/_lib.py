@@ -70,6 +70,7 @@ SIGNATURES = {
     "dmnerf_penalizer_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp]),
     "dmnerf_penalizer_sums": (c_int, [c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_penalizer_finish": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
+    "dmnerf_f16x2_range_flags": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_penalizer_sums2": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_loss_tail_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_loss_tail_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -26,6 +26,73 @@ KERNEL_EVENTS = None
 PLAN_MAX_WGS = None
 
 
+# ---- run-time honesty of the opt-in f16x2 mode --------------------------------------------------------------------------------
+# The split-f16 kernels saturate at 65 504 instead of overflowing (csrc/split_f16.h) and nothing at run time says so.  With
+# ``DMNERF_CHECK_F16=1`` (or ``autograd.CHECK_F16 = True``, or ``args.check_f16``) every f16x2 training forward / backward is
+# followed by one pass over the workspace it wrote (dmnerf_f16x2_range_flags: exactly the operands the kernels converted) that
+# ORs into a sticky per-device flags word; ``check_f16x2()`` reads it back (one sync) and warns.  Off by default: no launch, no
+# cost.  The inference path (networks/render.py) probes through the training forward when the check is on.
+CHECK_F16 = None
+F16_ACT_SATURATED, F16_GRAD_SATURATED = 1, 2          # DMNERF_F16_* (include/dmnerf_hip.h)
+_f16_flags = {}
+
+
+def f16_check_enabled(args=None):
+    if args is not None and getattr(args, "check_f16", None) is not None:
+        return bool(args.check_f16)
+    if CHECK_F16 is not None:
+        return bool(CHECK_F16)
+    import os
+    return os.environ.get("DMNERF_CHECK_F16", "0") == "1"
+
+
+def _f16_flags_word(device):
+    key = str(device)
+    if key not in _f16_flags:
+        _f16_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _f16_flags[key]
+
+
+def _f16_range_scan(workspace, M, gradients):
+    _lib.check(_lib.load().dmnerf_f16x2_range_flags(_lib.ptr(workspace), M, 1 if gradients else 0, _lib.ptr(_f16_flags_word(workspace.device)),
+                                                    _lib.stream()), "dmnerf_f16x2_range_flags")
+
+
+def check_f16x2(device=None, reset=True, warn=True):
+    """Read the sticky f16x2 saturation flags of ``device`` (one host synchronisation) -> int (0: nothing saturated;
+    ``F16_ACT_SATURATED``: an activation reached |x| >= 65 504 and was clamped by the conversion; ``F16_GRAD_SATURATED``: a scaled
+    gradient did).  ``warn``: issue a ``RuntimeWarning`` naming what happened; ``reset``: clear the word."""
+    import warnings
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    word = _f16_flags.get(str(device))
+    if word is None:
+        return 0
+    flags = int(word.item())
+    if reset and flags:
+        word.zero_()
+    if warn and flags & F16_ACT_SATURATED:
+        warnings.warn("dm_nerf_amd f16x2: an activation reached |x| >= 65504 and was clamped by the f16 conversion -- results of "
+                      "args.mfma_split = 'f16x2' are not f32-class for this network / input; use the default f32 kernels or 'bf16x3'",
+                      RuntimeWarning, stacklevel=2)
+    if warn and flags & F16_GRAD_SATURATED:
+        warnings.warn("dm_nerf_amd f16x2: a scaled gradient reached |x| >= 65504 in the data-gradient pass (dynamic range of "
+                      "dL/draw above ~2^11) and was clamped; use the default f32 kernels or 'bf16x3' for this step", RuntimeWarning, stacklevel=2)
+    return flags
+
+
+def f16x2_probe(model, rays_o, rays_d, z):
+    """Inference with the check on: the same launch through the training forward (which SAVES what it converts) into a scratch
+    workspace, scanned for saturation.  Doubles the cost of the call -- a diagnostic."""
+    lib = _lib.load()
+    N, S = z.shape
+    M = N * S
+    raw = torch.empty(N, S, 4 + model.ins_num + 1, dtype=torch.float32, device=z.device)
+    save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
+    _lib.check(lib.dmnerf_mlp_fwd_rays_train_f16(_lib.ptr(model.blob_f16()), model.ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
+                                                 N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train_f16")
+    _f16_range_scan(save, M, False)
+
+
 class _timed:
     def __init__(self, tag, M):
         self.tag, self.M = tag, M
@@ -222,6 +289,8 @@ class MLPRaysFunction(torch.autograd.Function):
         with _timed("mlp_fwd_train", M):
             _lib.check(fn(_lib.ptr(fwd_blob), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
                           N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
+        if mode == "f16" and f16_check_enabled():
+            _f16_range_scan(save, M, False)
         ctx.model, ctx.M, ctx.save = model, M, save
         ctx.blob, ctx.flat = blob, model.flat()                                   # the weights this forward used
         ctx.blob_t = ctx.blob_ts = None
@@ -343,6 +412,8 @@ def _mlp_backward_on_stream(ctx, g_raw):
             _lib.check(lib.dmnerf_grad_scale(_lib.ptr(g), g.numel(), _lib.ptr(scale), _lib.stream()), "dmnerf_grad_scale")
             _lib.check(lib.dmnerf_mlp_bwd_data_f16(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                    _lib.ptr(dsave), _lib.ptr(gt), _lib.ptr(scale), _lib.stream()), "dmnerf_mlp_bwd_data_f16")
+            if f16_check_enabled():
+                _f16_range_scan(dsave, M, True)
         elif split:
             _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                      _lib.ptr(dsave), _lib.ptr(gt), _lib.stream()), "dmnerf_mlp_bwd_data_split")

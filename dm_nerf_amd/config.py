@@ -13,4 +13,12 @@ def create_nerf(args):
     D, W = getattr(args, "netdepth", 8), getattr(args, "netwidth", 256)
     model_coarse = DM_NeRF(D, W, input_ch_pos, input_ch_view, [4], args.ins_num).to(device)
     model_fine = DM_NeRF(D, W, input_ch_pos, input_ch_view, [4], args.ins_num).to(device)
+    if not model_fine._fused_ok():
+        # another network shape runs, but not on the kernels the measured numbers come from: say so once, with the measured factor
+        import warnings
+        warnings.warn(f"dm_nerf_amd.create_nerf: netdepth={D} netwidth={W} multires={getattr(args, 'multires', 10)}/"
+                      f"{getattr(args, 'multires_views', 4)} is not the shape the fused kernels are specialised for (8 x 256, skips [4], "
+                      "multires 10 / 4: every shipped config); it runs layer by layer on the generic GEMM path (dm_nerf_amd/generic.py) at "
+                      "about 0.3x of the f32-MFMA roof (0.27 - 0.37 measured, scripts/generic_time.py) instead of 0.93",
+                      RuntimeWarning, stacklevel=2)
     return position_embedder, view_embedder, model_coarse, model_fine, args

@@ -161,6 +161,12 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
             e.record()               # torch creates the hipEvent_t lazily; the library re-records it in place
         a.ev_fine_mlp_begin, a.ev_fine_mlp_end = _events[0].cuda_event, _events[1].cuda_event
     _lib.check(_lib.load().dmnerf_render_rays_fwd(ctypes.byref(a), _lib.stream()), "dmnerf_render_rays_fwd")
+    if split == "f16x2":
+        from .. import autograd
+        if autograd.f16_check_enabled(args):             # opt-in diagnostic (DMNERF_CHECK_F16=1 / args.check_f16): did a conversion saturate?
+            autograd.f16x2_probe(model_coarse, rays_o, rays_d, out['z_vals_coarse'])
+            autograd.f16x2_probe(model_fine, rays_o, rays_d, out['z_vals_fine'])
+            autograd.check_f16x2(dev)
     if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
         out['ins_fine'] = out['ins_fine'][-args.N_ins:]          # render.py:88-90
         out['ins_coarse'] = out['ins_coarse'][-args.N_ins:]

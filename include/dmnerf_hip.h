@@ -295,6 +295,14 @@ int dmnerf_wgrad_plan_sizes_f16(int ins_num, int64_t M, int max_wgs, int64_t* n_
                                 int64_t* n_out_bytes, int64_t* part_floats, int* n_jobs, int* n_outs);
 int dmnerf_wgrad_plan_f16(int ins_num, int64_t M, int max_wgs, void* h_jobs, int64_t job_bytes,
                           void* h_outs, int64_t out_bytes);
+/* Run-time honesty of the f16x2 mode (opt-in diagnostic: DMNERF_CHECK_F16=1 / args.check_f16 in the Python mirror).  The
+ * conversions saturate silently at 65 504; every converted operand is also a row of the f32 workspace the training forward saves
+ * (gradients = 0) or the data-gradient kernel writes (gradients = 1, values carry the factor 2^s of dmnerf_grad_scale), so one
+ * pass over the workspace of M samples finds them: ORs DMNERF_F16_ACT_SATURATED / DMNERF_F16_GRAD_SATURATED into the int32 at
+ * d_flags (sticky: the caller zeroes it when it has read it) if any |x| >= 65 504 or non-finite.  No sync. */
+#define DMNERF_F16_ACT_SATURATED 1
+#define DMNERF_F16_GRAD_SATURATED 2
+int dmnerf_f16x2_range_flags(const float* d_workspace, int64_t M, int gradients, int32_t* d_flags, void* stream);
 int dmnerf_mlp_bwd_weights_f16(const float* d_save, const float* d_dsave, const float* d_graw_t, int64_t M,
                                const void* d_jobs, int n_jobs, const void* d_outs, int n_outs,
                                const float* d_params_flat, int ins_num, float* d_part, float* d_grad_flat,

@@ -359,3 +359,50 @@ def test_f16x2_range_of_the_two_plane_split(A, capsys):
         print("\n[f16x2 range] max |d raw| / max |raw| vs the oracle: " + str(rep))
     assert rep[4.5]["f16x2"] <= 1e-5, rep                  # inside the f16 range: f32 class
     assert rep[8.0]["f16x2"] > 1e-4, rep                   # beyond it: saturated planes (finite, documented, not f32 class)
+
+
+def test_f16x2_saturation_is_reported_when_the_check_is_on(A, monkeypatch):
+    """Run-time honesty of the opt-in mode: with DMNERF_CHECK_F16=1 (or args.check_f16) a render whose activations leave the f16
+    range WARNS (sticky device flags word, read at the check), the same render inside the range does not, and a training step
+    reports through ``autograd.check_f16x2()``.  With the check off nothing is launched and nothing is said (the default)."""
+    import types
+    import warnings
+    from dm_nerf_amd import autograd as G
+    from dm_nerf_amd.networks import render as R
+    ins_num, N = 13, 48
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(20.0, -65.0, 7.0))
+    rays = torch.stack([ro.reshape(-1, 3)[5000:5000 + N], rd.reshape(-1, 3)[5000:5000 + N]]).cuda()
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous().cuda()
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, mfma_split="f16x2", check_f16=True)
+    for gain, expect in ((1.7, False), (8.0, True)):
+        mc, mf = model_from(A, O.make_weights(21, ins_num, gain=gain), ins_num), model_from(A, O.make_weights(22, ins_num, gain=gain), ins_num)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                out = R.dm_nerf(rays, None, None, mc, mf, z, args)
+        said = [x for x in w if issubclass(x.category, RuntimeWarning) and "65504" in str(x.message)]
+        assert bool(said) == expect, (gain, [str(x.message) for x in w])
+        assert bool(torch.isfinite(out['rgb_fine']).all())
+        assert G.check_f16x2(warn=False) == 0                                  # the read cleared the word
+    # check off (the default): silent, and no flag is ever set
+    args.check_f16 = None
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            R.dm_nerf(rays, None, None, mc, mf, z, args)
+    assert not [x for x in w if "65504" in str(x.message)] and G.check_f16x2(warn=False) == 0
+    # training: the forward's saved activations (and the backward's scaled gradients) are scanned on the stream; the caller reads
+    monkeypatch.setattr(G, "CHECK_F16", True)
+    mc.train(); mf.train()
+    targs = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, mfma_split="f16x2")
+    o = R.dm_nerf(rays, None, None, mc, mf, z, targs)
+    (o['rgb_fine'].sum() + o['rgb_coarse'].sum()).backward()
+    with pytest.warns(RuntimeWarning, match="65504"):
+        flags = G.check_f16x2()
+    assert flags & G.F16_ACT_SATURATED
+    assert G.check_f16x2(warn=False) == 0
+    small_c, small_f = model_from(A, O.make_weights(21, ins_num, gain=1.7), ins_num).train(), model_from(A, O.make_weights(22, ins_num, gain=1.7), ins_num).train()
+    o = R.dm_nerf(rays, None, None, small_c, small_f, z, targs)
+    (o['rgb_fine'].sum() + o['rgb_coarse'].sum()).backward()
+    assert G.check_f16x2(warn=False) == 0                                      # inside the range (ragged M too): no false alarm

@@ -102,7 +102,8 @@ def test_dm_nerf_dict_other_shapes(A, cfg):
     ins_num = cfg["ins_num"]
     args = types.SimpleNamespace(multires=cfg["multires"], multires_views=cfg["multires_views"], i_embed=0, netdepth=cfg["D"],
                                  netwidth=cfg["W"], ins_num=ins_num, device=torch.device("cuda:0"))
-    pe, ve, mc, mf, _ = A.Cfg.create_nerf(args)
+    with pytest.warns(RuntimeWarning, match="generic GEMM path"):          # honest about what it costs: said once, with the factor
+        pe, ve, mc, mf, _ = A.Cfg.create_nerf(args)
     inp, inv = pe.out_dim, ve.out_dim
     kw = dict(W=cfg["W"], gain=1.7, sigma_bias=0.3, D=cfg["D"], input_ch_pts=inp, input_ch_views=inv)
     sd_c, sd_f = O.make_weights(31, ins_num, **kw), O.make_weights(32, ins_num, **kw)
@@ -139,3 +140,11 @@ def test_dm_nerf_dict_other_shapes(A, cfg):
             gw = sd_[k].grad.double()
             rel_l2 = float((p.grad.cpu().double() - gw).norm() / (gw.norm() + 1e-30))
             assert rel_l2 <= 2e-3, (k, rel_l2)
+
+
+def test_create_nerf_is_silent_for_the_shipped_shape(A):
+    import warnings
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256, ins_num=13, device=torch.device("cuda:0"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        A.Cfg.create_nerf(args)
