@@ -21,6 +21,7 @@
 //     and round, the rounds dealt out over the waves that hold the same A blocks.
 // Exact f32 (fmaf-chain MFMA), no vendor BLAS.  Roofline: ~equal parts MFMA (2 x MAC x M FLOP) and
 // HBM (each dy / x row is read once per job: ~23 KB per sample and model).
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -41,7 +42,10 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
     constexpr int NGAP = 4 * NPAIR;                // MFMAs per round
     constexpr int D = RG::D, BUF = RG::BUF;
     static_assert((D - 1) * NL <= 63, "vmcnt range");
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));               // opaque per item: the lane geometry below is recomputed for each item of a workgroup
+                                               // (hoisted out of the item loop, nine shape classes' worth of it would spill)
+    const int lane = tid & 63, half = lane >> 5, li = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = lds_addr(lds);
 
@@ -159,19 +163,24 @@ __device__ __forceinline__ void run_job(const WgArgs& a, const WgJob& jb, float*
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WgJob jb = a.jobs[blockIdx.x];
+    WgJob jb = a.jobs[blockIdx.x];
     if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = (long long)wall_clock64();
-    switch (jb.cls) {                                  // workgroup-uniform
-        case C_8_8: run_job<8, 8>(a, jb, lds); break;
-        case C_4_8: run_job<4, 8>(a, jb, lds); break;
-        case C_8_2: run_job<8, 2>(a, jb, lds); break;
-        case C_4_1: run_job<4, 1>(a, jb, lds); break;
-        case C_1_8: run_job<1, 8>(a, jb, lds); break;
-        case C_1_4: run_job<1, 4>(a, jb, lds); break;
-        case C_2_4: run_job<2, 4>(a, jb, lds); break;
-        case C_3_4: run_job<3, 4>(a, jb, lds); break;
-        case C_4_4: run_job<4, 4>(a, jb, lds); break;
-        default: break;
+    for (int item = jb.next - 1, more = jb.follow;; --more) {      // (block = leader item; its followers start at jb.next)
+        switch (jb.cls) {                              // workgroup-uniform
+            case C_8_8: run_job<8, 8>(a, jb, lds); break;
+            case C_4_8: run_job<4, 8>(a, jb, lds); break;
+            case C_8_2: run_job<8, 2>(a, jb, lds); break;
+            case C_4_1: run_job<4, 1>(a, jb, lds); break;
+            case C_1_8: run_job<1, 8>(a, jb, lds); break;
+            case C_1_4: run_job<1, 4>(a, jb, lds); break;
+            case C_2_4: run_job<2, 4>(a, jb, lds); break;
+            case C_3_4: run_job<3, 4>(a, jb, lds); break;
+            case C_4_4: run_job<4, 4>(a, jb, lds); break;
+            default: break;
+        }
+        if (more <= 0) break;
+        __syncthreads();                               // every wave is done with the LDS ring: the next item refills it
+        jb = a.jobs[++item];
     }
     if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = (long long)wall_clock64();
 }
@@ -238,6 +247,7 @@ struct Plan {
     std::vector<WgJob> jobs;
     std::vector<WgOut> outs;
     int64_t part_floats = 0;
+    int n_wgs = 0;              // leaders = blocks of the launch; jobs.size() - n_wgs follower items behind them
 };
 
 // Parameter offsets in the flat gradient vector = reference state_dict order (weight, bias per layer).
@@ -292,30 +302,65 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs, int mode = 0) {
     // f16x2 (wgrad_f16.hip, 48 NBA NBB MFMA cycles per chunk): every class sits on its operand stream; DMNERF_DIAG_SPLIT=f16
     // scripts/diag_wgrad.py (mean of r03w / r03x, both under this plan: profiles/r03/diag_wgrad_f16_r03w.txt, ..._r03x.txt; the classes ins_num 13 does not use: 174 ns per block).
     auto chunk_cost = [mode](int cls) {
-        static const double ns[N_CLASSES] = {/*8,8*/ 7025, /*4,8*/ 3530, /*8,2*/ 1858, /*4,1*/ 538, /*1,8*/ 984,
-                                             /*1,4*/ 540, /*2,4*/ 1000, /*3,4*/ 1400, /*4,4*/ 1800};
+        // (f32: re-fitted in r04 under the time-packed plan, every CU busy to the end of the launch -- scripts/diag_wgrad.py least
+        // squares over the 256 workgroups: the 256 x 256 class 7307 ns at the clock the full chip sustains, the skinny classes
+        // ~10 % above their r01 figures; only the RATIOS matter to the packing)
+        static const double ns[N_CLASSES] = {/*8,8*/ 7307, /*4,8*/ 3680, /*8,2*/ 1950, /*4,1*/ 600, /*1,8*/ 1060,
+                                             /*1,4*/ 600, /*2,4*/ 1100, /*3,4*/ 1500, /*4,4*/ 1900};
         static const double ns_split[N_CLASSES] = {/*8,8*/ 4748, /*4,8*/ 2750, /*8,2*/ 2044, /*4,1*/ 880, /*1,8*/ 1389,
                                                    /*1,4*/ 967, /*2,4*/ 1180, /*3,4*/ 1390, /*4,4*/ 1710};
         static const double ns_f16[N_CLASSES] = {/*8,8*/ 2795, /*4,8*/ 2100, /*8,2*/ 1320, /*4,1*/ 622, /*1,8*/ 895,
                                                  /*1,4*/ 692, /*2,4*/ 1043, /*3,4*/ 1217, /*4,4*/ 1391};
         return mode == 2 ? ns_f16[cls] : (mode == 1 ? ns_split[cls] : ns[cls]);
     };
-    // Slices per job: minimise the longest workgroup (chunks per slice x chunk cost) under sum(slices) <= max_wgs:
-    // start from one slice each and keep giving a slice to the job whose workgroups are the longest.
+    // Work items: every workgroup is filled to the same TIME T (wrap-around rule): walk the jobs in order, give the current
+    // workgroup chunks of the current job until its budget is used, open the next workgroup, and when a job ends inside a
+    // workgroup's budget let that workgroup go on with the first chunks of the next job.  The earlier plan gave every job an
+    // integer number of equal slices, one per workgroup, so the workgroups of a job whose time share is 2.2 workgroups ran 3 (each
+    // idle for a quarter of the launch) or 2 (the critical path): span 6.50 ms against 6.24 ms of divisible work (profiles/r03).
+    // T is the smallest budget whose packing needs at most max_wgs workgroups (bisection); an item pays `item_ns` for its ring
+    // fill and its partial-tile store on top of its chunks, and is never shorter than MINCH chunks unless the job is.
     for (auto& j : d) j.cls = class_for(j.rowsA, j.rowsB);
-    std::vector<int> n_slices(d.size(), 1);
-    {
-        auto wg_time = [&](size_t k) { return chunk_cost(d[k].cls) * (double)((nchunks + n_slices[k] - 1) / n_slices[k]); };
-        int used = (int)d.size();
-        while (used < max_wgs) {
-            size_t worst = 0;
-            for (size_t k = 1; k < d.size(); ++k)
-                if (wg_time(k) > wg_time(worst)) worst = k;
-            if (n_slices[worst] >= nchunks) break;
-            ++n_slices[worst];
-            ++used;
+    struct Item { int job, chunk0, nchunk, lead; };        // lead: 1 = first item of its workgroup
+    auto item_ns = [&](int cls) { return 1500.0 + 8.0 * (double)(CLS_NBA[cls] * 32 * CLS_NBB[cls] * 32) * 4.0 / 256.0; };   // ~1.5 us + the tile store
+    constexpr int MINCH = 8;
+    auto pack = [&](double T, std::vector<Item>* out) {
+        int wgs = 0;
+        double used = 0.0;            // time already in the current workgroup
+        bool open = false;
+        for (size_t jk = 0; jk < d.size(); ++jk) {
+            const double c = chunk_cost(d[jk].cls), oh = item_ns(d[jk].cls);
+            int c0 = 0, rem = nchunks;
+            while (rem > 0) {
+                if (!open) { ++wgs; used = 0.0; open = true; }
+                int n = (int)std::floor((T - used - oh) / c);
+                const int least = rem < MINCH ? rem : MINCH;
+                if (n < least) {
+                    if (used == 0.0) return 1 << 30;              // a fresh workgroup cannot hold the smallest item: T too small
+                    open = false;                                 // not worth starting here: leave the rest of this budget idle
+                    continue;
+                }
+                if (n > rem) n = rem;
+                if (rem - n > 0 && rem - n < MINCH) n = rem - MINCH >= MINCH ? rem - MINCH : rem;      // no crumb for the next workgroup
+                if (out) out->push_back({(int)jk, c0, n, used == 0.0 ? 1 : 0});
+                used += oh + c * (double)n;
+                c0 += n; rem -= n;
+                if (T - used < 0.002 * T) open = false;
+            }
         }
+        return wgs;
+    };
+    double total_ns = 0.0;
+    for (auto& j : d) total_ns += item_ns(j.cls) + chunk_cost(j.cls) * (double)nchunks;
+    double lo = total_ns / (double)max_wgs, hi = total_ns * 1.01 + 1.0;   // hi: one workgroup takes everything (always feasible)
+    for (int it = 0; it < 60 && hi - lo > 1e-4 * hi; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (pack(mid, nullptr) <= max_wgs) hi = mid; else lo = mid;
     }
+    std::vector<Item> items;
+    pack(hi, &items);
+    std::vector<int> n_slices(d.size(), 0);
+    for (const Item& it : items) ++n_slices[it.job];
 
     Plan P;
     P.part_floats = 2 * HEAD_F_FLOATS;                                       // G | Q first, the per-slice partials behind them
@@ -337,17 +382,38 @@ Plan make_plan(int ins_num, int64_t M, int max_wgs, int mode = 0) {
         o.perm_b = !(j.b_base == R_pe || j.b_base == R_de);                 // saved h / g1 / g2 (not the encodings)
         P.outs.push_back(o);
         for (int s = 0; s < ns; ++s) {
+            const Item& it = items[P.jobs.size()];                          // (items are job-major, like this loop)
             WgJob g{};
             g.a_src = j.a_src; g.b_src = j.b_src;
             g.a_off = j.a_base * Mp; g.b_off = j.b_base * Mp;
             g.a_R = j.a_R; g.b_R = j.b_R; g.a_row0 = j.a_row0; g.b_row0 = j.b_row0;
             g.part_off = P.part_floats; g.bias_off = j.bias_out_off >= 0 ? P.part_floats + tile : -1;
             g.rowsA = j.rowsA; g.rowsB = j.rowsB; g.cls = j.cls;
-            g.chunk0 = (int)((int64_t)nchunks * s / ns);
-            g.nchunk = (int)((int64_t)nchunks * (s + 1) / ns) - g.chunk0;
+            g.chunk0 = it.chunk0;
+            g.nchunk = it.nchunk;
+            g.follow = it.lead ? 0 : -1;
             P.jobs.push_back(g);
             P.part_floats += tile + brow;
         }
+    }
+    // The table: the leaders in workgroup order (= the grid), then the followers; a leader's followers are the items between it
+    // and the next leader of the job-major sequence (the tail of one job, the head of the next), kept consecutive.
+    {
+        std::vector<WgJob> lead, foll;
+        std::vector<int> first_foll;
+        for (size_t i = 0; i < P.jobs.size(); ++i) {
+            if (P.jobs[i].follow == 0) { lead.push_back(P.jobs[i]); first_foll.push_back(-1); }
+            else {
+                if (first_foll.back() < 0) first_foll.back() = (int)foll.size();
+                ++lead.back().follow;
+                foll.push_back(P.jobs[i]);
+            }
+        }
+        for (size_t i = 0; i < lead.size(); ++i) lead[i].next = first_foll[i] < 0 ? -1 : (int)lead.size() + first_foll[i];
+        for (auto& f : foll) f.next = -1;
+        P.n_wgs = (int)lead.size();
+        P.jobs = lead;
+        P.jobs.insert(P.jobs.end(), foll.begin(), foll.end());
     }
     return P;
 }
@@ -361,7 +427,7 @@ static int plan_sizes(int mode, int ins_num, int64_t M, int max_wgs, int64_t* n_
     if (n_job_bytes) *n_job_bytes = (int64_t)(P.jobs.size() * sizeof(WgJob));
     if (n_out_bytes) *n_out_bytes = (int64_t)(P.outs.size() * sizeof(WgOut));
     if (part_floats) *part_floats = P.part_floats;
-    if (n_jobs) *n_jobs = (int)P.jobs.size();
+    if (n_jobs) *n_jobs = P.n_wgs;                    // the GRID: one block per workgroup; the table (n_job_bytes) also holds their follower items
     if (n_outs) *n_outs = (int)P.outs.size();
     return DMNERF_OK;
 }

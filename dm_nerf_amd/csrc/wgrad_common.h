@@ -20,7 +20,11 @@ constexpr int KT = 32;                      // samples per chunk
 constexpr int WG_LDS_BYTES = 147456;        // ring budget (of the CU's 160 KiB)
 constexpr int MAX_DEPTH = 6;                // ring slots (the chunk loop is unrolled by the depth)
 
-// One workgroup's work (device table, offsets only => reusable across steps).
+// One work item = one (job, sample slice) with its own partial tile (device table, offsets only => reusable across steps).
+// A WORKGROUP runs one item or a few: the plan fills every workgroup to the same TIME, so the workgroup that finishes a job's
+// last slice early continues with the first slice of the next job.  The table holds one LEADER item per workgroup first (the
+// grid: one block per leader -- never more blocks than CUs: blocks go to the XCDs round-robin, and a 257th would wait a whole
+// launch behind the 32 resident ones of its XCD), then the follower items; a leader names its `follow` followers from `next` on.
 struct WgJob {
     int64_t a_off, b_off;     // float offsets of the A / B TENSORS inside their source buffers
     int a_R, b_R;             // total rows of those tensors (block stride = R*32 floats)
@@ -31,6 +35,8 @@ struct WgJob {
     int rowsA, rowsB;         // valid rows (the rest of the 32-row blocks is zero)
     int cls;                  // shape class (NBA, NBB)
     int chunk0, nchunk;       // 32-sample chunks [chunk0, chunk0 + nchunk)
+    int follow;               // leader: number of further items the same workgroup runs; follower: -1
+    int next;                 // leader with followers: index of the first of them (they are consecutive); else -1
     int pad;
 };
 static_assert(sizeof(WgJob) % 8 == 0, "WgJob layout");

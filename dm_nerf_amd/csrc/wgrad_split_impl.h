@@ -80,7 +80,10 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
     static_assert(IS == 1 || IS == 4, "items per step");
     static_assert((D - 1) * NL <= 63, "vmcnt range");
     static_assert(NG >= NRA + NRB && 2 * NG >= NL && (IS == 1 || WB < 2 * NG), "slots for the reads / the refill");
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));               // opaque per item: the lane geometry below is recomputed for each item of a workgroup
+                                               // (hoisted out of the item loop, nine shape classes' worth of it would spill)
+    const int lane = tid & 63, half = lane >> 5, li = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = lds_addr(lds);
 
@@ -288,19 +291,24 @@ __device__ __forceinline__ void run_job_split(const WgArgs& a, const WgJob& jb, 
 template <class Mode>
 __device__ __forceinline__ void wgrad_split_body(const WgArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const WgJob jb = a.jobs[blockIdx.x];
+    WgJob jb = a.jobs[blockIdx.x];
     if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = (long long)wall_clock64();
-    switch (jb.cls) {                                  // workgroup-uniform
-        case C_8_8: run_job_split<Mode, 8, 8>(a, jb, lds); break;
-        case C_4_8: run_job_split<Mode, 4, 8>(a, jb, lds); break;
-        case C_8_2: run_job_split<Mode, 8, 2>(a, jb, lds); break;
-        case C_4_1: run_job_split<Mode, 4, 1>(a, jb, lds); break;
-        case C_1_8: run_job_split<Mode, 1, 8>(a, jb, lds); break;
-        case C_1_4: run_job_split<Mode, 1, 4>(a, jb, lds); break;
-        case C_2_4: run_job_split<Mode, 2, 4>(a, jb, lds); break;
-        case C_3_4: run_job_split<Mode, 3, 4>(a, jb, lds); break;
-        case C_4_4: run_job_split<Mode, 4, 4>(a, jb, lds); break;
-        default: break;
+    for (int item = jb.next - 1, more = jb.follow;; --more) {      // (block = leader item; its followers start at jb.next)
+        switch (jb.cls) {                              // workgroup-uniform
+            case C_8_8: run_job_split<Mode, 8, 8>(a, jb, lds); break;
+            case C_4_8: run_job_split<Mode, 4, 8>(a, jb, lds); break;
+            case C_8_2: run_job_split<Mode, 8, 2>(a, jb, lds); break;
+            case C_4_1: run_job_split<Mode, 4, 1>(a, jb, lds); break;
+            case C_1_8: run_job_split<Mode, 1, 8>(a, jb, lds); break;
+            case C_1_4: run_job_split<Mode, 1, 4>(a, jb, lds); break;
+            case C_2_4: run_job_split<Mode, 2, 4>(a, jb, lds); break;
+            case C_3_4: run_job_split<Mode, 3, 4>(a, jb, lds); break;
+            case C_4_4: run_job_split<Mode, 4, 4>(a, jb, lds); break;
+            default: break;
+        }
+        if (more <= 0) break;
+        __syncthreads();                               // every wave is done with the LDS ring: the next item refills it
+        jb = a.jobs[++item];
     }
     if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = (long long)wall_clock64();
 }

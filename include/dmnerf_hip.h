@@ -185,8 +185,10 @@ int dmnerf_mlp_bwd_data(const float* d_blob, const float* d_blob_t, int ins_num,
                         const float* d_graw, int64_t M, float* d_dsave, float* d_graw_t, void* stream);
 
 /* Weight / bias gradients dW = dy . x^T over the batch (split-K f32 MFMA, deterministic 2-stage sum).
- * The plan (which workgroup does which job slice) depends only on (ins_num, M, max_wgs): build it once
- * on the host, upload the two tables, reuse every step.  d_graw_t = dL/draw in the same block-major
+ * The plan (which workgroup does which job slices) depends only on (ins_num, M, max_wgs): build it once
+ * on the host, upload the two tables, reuse every step.  n_jobs = the number of WORKGROUPS (<= max_wgs; the grid of the launch,
+ * all filled to the same modelled time); the job table (n_job_bytes) holds one leader item per workgroup followed by the further
+ * items some of them continue with (a job's last slice and the next job's first), each item with its own partial tile.  d_graw_t = dL/draw in the same block-major
  * form, R = 4+C rows, zero in the padding columns.  d_grad_flat: dmnerf_param_count(ins_num) floats in the
  * flat parameter order above.  d_part: workspace of `part_floats` floats.
  * The gradients of rgb_feature_linear, ins_feature_linear and of the two hidden layers that consume them are formed from

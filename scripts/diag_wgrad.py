@@ -22,7 +22,7 @@ from dm_nerf_amd.networks import dm_nerf as M
 
 JOB = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("a_R", "<i4"), ("b_R", "<i4"), ("a_row0", "<i4"), ("b_row0", "<i4"),
                 ("part_off", "<i8"), ("bias_off", "<i8"), ("a_src", "<i4"), ("b_src", "<i4"), ("rowsA", "<i4"), ("rowsB", "<i4"),
-                ("cls", "<i4"), ("chunk0", "<i4"), ("nchunk", "<i4"), ("pad", "<i4")])
+                ("cls", "<i4"), ("chunk0", "<i4"), ("nchunk", "<i4"), ("follow", "<i4"), ("next", "<i4"), ("pad", "<i4")])
 CLS = [(8, 8), (4, 8), (8, 2), (4, 1), (1, 8), (1, 4), (2, 4), (3, 4), (4, 4)]
 
 
@@ -40,8 +40,8 @@ def main():
         sv = os.environ.get("DMNERF_DIAG_SPLIT", "0")
         split = {"0": None, "1": "bf16x3", "f16": "f16x2"}[sv]
         jobs, n_jobs, outs, n_outs, _ = G.wgrad_plan(ins_num, Mtot, dev, split=split or False)
-        jh = jobs.cpu().numpy().view(JOB)
-        assert JOB.itemsize * n_jobs == jobs.numel(), (JOB.itemsize, n_jobs, jobs.numel())
+        jh = jobs.cpu().numpy().view(JOB)            # [n_jobs leaders (one per workgroup)] + [their follower items]
+        assert bool((jh["follow"][:n_jobs] >= 0).all()) and bool((jh["follow"][n_jobs:] == -1).all())
         ticks = torch.zeros(2 * n_jobs, dtype=torch.int64, device=dev)
         for it in range(3):
             for p in m.parameters():
@@ -58,22 +58,29 @@ def main():
         dur = (t[:, 1] - t[:, 0]) * 0.01          # us (100 MHz)
         start = (t[:, 0] - t0) * 0.01
         end = (t[:, 1] - t0) * 0.01
-        print(f"== M = {Mtot} : {n_jobs} workgroups, kernel span {end.max():.0f} us, latest start {start.max():.0f} us")
-        # group consecutive workgroups of the same job (same part stride pattern: same a_off/b_off/rows)
-        key = [(int(j["a_off"]), int(j["b_off"]), int(j["a_row0"]), int(j["b_row0"]), int(j["a_src"])) for j in jh]
-        i = 0
-        while i < n_jobs:
-            k = i
-            while k < n_jobs and key[k] == key[i]:
-                k += 1
-            j = jh[i]
-            nba, nbb = CLS[int(j["cls"])]
-            d = dur[i:k]
-            nch = jh["nchunk"][i:k]
-            print(f"  job rows {int(j['rowsA']):3d}x{int(j['rowsB']):3d} cls ({nba},{nbb}) slices {k - i:3d} chunks/slice {int(nch.max()):5d}"
-                  f"  wg time mean {d.mean():8.0f} max {d.max():8.0f} us   per chunk {1e3 * (d / nch).mean():7.0f} ns"
-                  f"  (MFMA-ideal {({None: 256, 'bf16x3': 96, 'f16x2': 48}[split]) * nba * nbb / 2.4:7.0f} ns;  HBM at 6.3 TB/s / 256 CUs: {(nba + nbb) * 4096 / 24.6:7.0f} ns)")
-            i = k
+        print(f"== M = {Mtot} : {n_jobs} workgroups ({len(jh)} items), kernel span {end.max():.0f} us, latest start {start.max():.0f} us, "
+              f"workgroup time mean {dur.mean():.0f} min {dur.min():.0f} max {dur.max():.0f} us")
+        # per workgroup: its items; least-squares fit  dur = sum over items (c_cls * nchunk) + o_cls per item
+        items = [[i] + list(range(int(jh["next"][i]), int(jh["next"][i]) + int(jh["follow"][i]))) for i in range(n_jobs)]
+        used = sorted(set(int(c) for c in jh["cls"]))
+        A = np.zeros((n_jobs, 2 * len(used)))
+        for w, its in enumerate(items):
+            for k in its:
+                c = used.index(int(jh["cls"][k]))
+                A[w, c] += float(jh["nchunk"][k])
+                A[w, len(used) + c] += 1.0
+        sol, *_ = np.linalg.lstsq(A, dur * 1e3, rcond=None)
+        res = A @ sol - dur * 1e3
+        print("  fitted ns per 32-sample chunk / ns per item (ring fill + tile store), by shape class:")
+        for c, cls in enumerate(used):
+            nba, nbb = CLS[cls]
+            n_it = int(A[:, len(used) + c].sum())
+            print(f"    ({nba},{nbb}): {sol[c]:8.0f} ns per chunk, {sol[len(used) + c]:9.0f} ns per item   [{n_it} items;  MFMA-ideal "
+                  f"{({None: 256, 'bf16x3': 96, 'f16x2': 48}[split]) * nba * nbb / 2.4:6.0f} ns;  HBM at 6.3 TB/s / 256 CUs: {(nba + nbb) * 4096 / 24.6:6.0f} ns]")
+        print(f"  fit residual rms {np.sqrt((res ** 2).mean()) / 1e3:.1f} us, max {np.abs(res).max() / 1e3:.1f} us")
+        worst = np.argsort(-dur)[:8]
+        for w in worst:
+            print(f"    slowest wg {w:3d}: {dur[w]:7.0f} us  items " + ", ".join(f"{CLS[int(jh['cls'][k])]}x{int(jh['nchunk'][k])}" for k in items[w]))
 
 
 if __name__ == "__main__":
