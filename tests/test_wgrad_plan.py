@@ -97,8 +97,8 @@ def test_plans_tile_every_job_exactly_once(ins_num, M, max_wgs):
 
 
 CHUNK_NS = {"f32": (7307, 3680, 1950, 600, 1060, 600, 1100, 1500, 1900),          # csrc/wgrad.hip::make_plan: measured ns per 32-sample
-            "bf16x3": (4748, 2750, 2044, 880, 1389, 967, 1180, 1390, 1710),       # chunk of each shape class, per kernel
-            "f16x2": (2795, 2100, 1320, 622, 895, 692, 1043, 1217, 1391)}
+            "bf16x3": (4600, 2700, 2030, 895, 1330, 975, 1180, 1390, 1710),       # chunk of each shape class, per kernel
+            "f16x2": (2811, 2100, 1341, 660, 950, 738, 1043, 1217, 1391)}
 
 
 def _wg_times(mode, jobs, n_wgs):
@@ -114,8 +114,8 @@ def test_workgroups_are_filled_to_the_same_time(M):
         jobs, outs, _, n_wgs = plan(mode, 13, M, 256)
         t = _wg_times(mode, jobs, n_wgs)
         assert 250 <= len(t) <= 256
-        # (chunk times only: the plan also charges ~10 us per item for the ring fill and the tile store, 2 % of a 0.57 ms launch)
-        assert t.max() <= (1.01 if M >= 500000 else 1.03) * t.mean(), (mode, t.max() / t.mean())
+        # (chunk times only: the plan also charges ~10 us per item for the ring fill and the tile store, 2 - 4 % of a 0.26 - 0.57 ms launch)
+        assert t.max() <= (1.01 if M >= 500000 else 1.05) * t.mean(), (mode, t.max() / t.mean())
         assert int(jobs["follow"].max()) <= 2
 
 
