@@ -65,22 +65,6 @@ def fused_flat(flat, ins_num):
     return out
 
 
-def fuse_heads(state):
-    """The same folding on a state_dict with torch ops -- the readable statement of what ``dmnerf_fuse_heads`` computes;
-    used by the CPU tests only (the product path calls ``fused_flat``): a copy of ``state`` whose ``rgb_feature_linears.0`` /
-    ``ins_feature_linears.0`` hold ``W_hidden[:, :256] @ W_feature`` (float64, rounded once) and the matching biases."""
-    st = {k: v.detach() for k, v in state.items()}
-    for feat, hid in (("rgb_feature_linear", "rgb_feature_linears.0"), ("ins_feature_linear", "ins_feature_linears.0")):
-        Wf, bf = st[feat + ".weight"].double(), st[feat + ".bias"].double()
-        Wh, bh = st[hid + ".weight"].double(), st[hid + ".bias"].double()
-        n_in = Wf.shape[0]                                         # 256 feature columns (then the 27 dir columns, rgb only)
-        Wn = Wh.clone()
-        Wn[:, :n_in] = Wh[:, :n_in] @ Wf
-        st[hid + ".weight"] = Wn.float()
-        st[hid + ".bias"] = (Wh[:, :n_in] @ bf + bh).float()
-    return st
-
-
 def flat_params(state):
     """Concatenate parameters in reference order.  ``state``: mapping key -> tensor (all on one GPU)."""
     return torch.cat([state[k].detach().reshape(-1).float() for k in PARAM_KEYS])

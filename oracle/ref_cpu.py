@@ -511,3 +511,21 @@ def scannet_scene(H=480, W=640, ins_num=7):
     ins = lab.reshape(-1).copy(); ins[crop.reshape(-1) == 0] = ins_num
     ins_index = np.where(ins != ins_num)[0]
     return rgb, lab, crop, ins_index
+
+
+def fuse_heads(state):
+    """What the library's ``dmnerf_fuse_heads`` (csrc/heads.hip; inference-only ``args.fuse_heads`` and the split modes) must
+    compute, stated with torch ops on a state_dict -- the CHECKER of that kernel, not a path of the product (which calls
+    ``weights.fused_flat``): the activation-free ``rgb_feature_linear`` / ``ins_feature_linear`` (dm_nerf.py:89,96) folded into
+    the hidden layers that consume them.  Returns a copy of ``state`` whose ``rgb_feature_linears.0`` /
+    ``ins_feature_linears.0`` hold ``W_hidden[:, :256] @ W_feature`` (float64, rounded once) and the matching biases."""
+    st = {k: v.detach() for k, v in state.items()}
+    for feat, hid in (("rgb_feature_linear", "rgb_feature_linears.0"), ("ins_feature_linear", "ins_feature_linears.0")):
+        Wf, bf = st[feat + ".weight"].double(), st[feat + ".bias"].double()
+        Wh, bh = st[hid + ".weight"].double(), st[hid + ".bias"].double()
+        n_in = Wf.shape[0]                                         # 256 feature columns (then the 27 dir columns, rgb only)
+        Wn = Wh.clone()
+        Wn[:, :n_in] = Wh[:, :n_in] @ Wf
+        st[hid + ".weight"] = Wn.float()
+        st[hid + ".bias"] = (Wh[:, :n_in] @ bf + bh).float()
+    return st

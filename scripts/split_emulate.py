@@ -151,7 +151,7 @@ def main():
     for cname, kw, near, far in cases:
         pts, vd = inputs(a.rows, near, far)
         sd = O.make_weights(**kw)
-        sdf = {k: v for k, v in __import__("dm_nerf_amd.weights", fromlist=["fuse_heads"]).fuse_heads(sd).items()}
+        sdf = {k: v for k, v in __import__("oracle.ref_cpu", fromlist=["fuse_heads"]).fuse_heads(sd).items()}
         xp, xv = O.embed(pts, 10), O.embed(vd, 4)
         ref = network({k: v.double() for k, v in sdf.items()}, xp.double(), xv.double(), Scheme("f64"))
         print(f"== {cname}: {xp.shape[0]} samples, |raw64| max {float(ref.abs().max()):.1f}")

@@ -235,7 +235,7 @@ def test_device_head_fusion_equals_the_float64_formula(A):
         sd = {k: v.cuda() for k, v in O.make_weights(seed, ins_num, gain=1.7).items()}
         flat = Wt.flat_params(sd)
         got = Wt.fused_flat(flat, ins_num)
-        want = Wt.flat_params(Wt.fuse_heads(sd))
+        want = Wt.flat_params(O.fuse_heads(sd))
         assert got.shape == want.shape
         changed = (got != flat)
         assert int(changed.sum()) <= 2 * (128 * 256 + 128)                   # only the two hidden layers' fused blocks

@@ -200,7 +200,7 @@ def test_fuse_heads_is_the_same_function():
     g = torch.Generator().manual_seed(9)
     x = torch.cat([O.embed(torch.randn(64, 3, generator=g), 10), O.embed(torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1), 4)], -1)
     want = O.mlp_forward(sd, x)
-    sf = W.fuse_heads(sd)
+    sf = O.fuse_heads(sd)
     # evaluate the fused network: hidden layers take h directly
     xp, xv = x[:, :63], x[:, 63:]
     h = xp

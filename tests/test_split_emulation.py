@@ -22,7 +22,7 @@ from oracle import ref_cpu as O                             # noqa: E402
                                                ("PEAKY ins13", dict(seed=5, ins_num=13, **O.PEAKY), 4.0, 15.0)])
 def test_three_products_of_two_f16_planes_are_f32_class(name, kw, near, far):
     pts, vd = E.inputs(512, near, far)
-    sdf = dict(weights.fuse_heads(O.make_weights(**kw)))
+    sdf = dict(O.fuse_heads(O.make_weights(**kw)))
     xp, xv = O.embed(pts, 10), O.embed(vd, 4)
     ref = E.network({k: v.double() for k, v in sdf.items()}, xp.double(), xv.double(), E.Scheme("f64"))
     err = {}
