@@ -73,7 +73,9 @@ SIGNATURES = {
     "dmnerf_f16x2_range_flags": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "dmnerf_penalizer_sums2": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dmnerf_loss_tail_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
-    "dmnerf_loss_tail_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_loss_tail_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_composite_pen_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmnerf_composite_pen_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_float, c_float, c_float, c_vp, c_vp]),
     "dmnerf_wgrad_plan_sizes": (c_int, [c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmnerf_wgrad_plan": (c_int, [c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_i64]),
     "dmnerf_mlp_bwd_weights": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),

@@ -499,6 +499,81 @@ class CompositeFunction(torch.autograd.Function):
         return d_raw, None, None
 
 
+class CompositePenFunction(torch.autograd.Function):
+    """render_train (networks/render.py:6-28) AND the emptiness penalizer's per-ray partial sums (networks/penalizer.py:5-42, with
+    this level's own depth map as its detached depth argument -- what ins_penalizer is called with, train_dmsr.py:52-57) from ONE
+    pass over the ray (extension).  Extra output ``part [N,4]`` (float64): what ``dmnerf_penalizer_fwd`` returns.
+    Backward: the compositing gradient plus, when a gradient arrives for ``part`` (the penalizer's normalised loss was used), the
+    penalizer's gradient w.r.t. ``raw[..., 4:]`` added in the same kernel.  The gradient of ``part`` is the same 4-vector for
+    every ray (the loss divides batch sums); the consumers in this package hand it over as an expanded ``[4]`` tensor."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rays_d, consts):
+        lib = _lib.load()
+        N, S, ch = raw.shape
+        C = ch - 4
+        f = dict(dtype=torch.float32, device=raw.device)
+        rgb, w = torch.empty(N, 3, **f), torch.empty(N, S, **f)
+        depth, ins = torch.empty(N, **f), torch.empty(N, C - 1, **f)
+        part = torch.empty(N, 4, dtype=torch.float64, device=raw.device)
+        tol, k2w, kh = consts
+        _lib.check(lib.dmnerf_composite_pen_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays_d), N, S, C, tol, k2w, kh, _lib.ptr(rgb), _lib.ptr(w),
+                                                _lib.ptr(depth), _lib.ptr(ins), _lib.ptr(part), _lib.stream()), "dmnerf_composite_pen_fwd")
+        ctx.save_for_backward(raw, z, rays_d, ins, depth)
+        ctx.consts = consts
+        return rgb, w, depth, ins, part
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_w, g_depth, g_ins, g_part):
+        lib = _lib.load()
+        raw, z, rays_d, ins, depth = ctx.saved_tensors
+        N, S, ch = raw.shape
+        C = ch - 4
+
+        def prep(g, shape):
+            if g is None:
+                return None
+            return _lib.f32(g.expand(shape) if g.shape != torch.Size(shape) else g)
+        g_rgb = prep(g_rgb, (N, 3)) if g_rgb is not None else torch.zeros(N, 3, device=raw.device)
+        g_ins = prep(g_ins, (N, C - 1)) if g_ins is not None else torch.zeros(N, C - 1, device=raw.device)
+        g_w, g_depth = prep(g_w, (N, S)), prep(g_depth, (N,))
+        d_raw = torch.empty_like(raw)
+        if g_part is None or N == 0:
+            _lib.check(lib.dmnerf_composite_bwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays_d), _lib.ptr(ins), _lib.ptr(g_rgb), _lib.ptr(g_ins),
+                                                _lib.ptr(g_depth), _lib.ptr(g_w), N, S, C, _lib.ptr(d_raw), _lib.stream()), "dmnerf_composite_bwd")
+        else:
+            row = g_part[0].to(torch.float64).contiguous()          # (a view of the producer's 4 doubles: no copy)
+            tol, k2w, kh = ctx.consts
+            _lib.check(lib.dmnerf_composite_pen_bwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays_d), _lib.ptr(ins), _lib.ptr(depth), _lib.ptr(g_rgb),
+                                                    _lib.ptr(g_ins), _lib.ptr(g_depth), _lib.ptr(g_w), _lib.ptr(row), N, S, C, tol, k2w, kh,
+                                                    _lib.ptr(d_raw), _lib.stream()), "dmnerf_composite_pen_bwd")
+        return d_raw, None, None, None
+
+
+def pen_consts(args):
+    """(tolerance, 2 deta_w^2, 0.4 sqrt(2 pi)) as float32 values formed like the reference (penalizer.py:7-10), or None when the
+    step does not penalise (``args.penalize`` false / tolerance or deta_w unset, train_dmsr.py:51)."""
+    if not getattr(args, "penalize", False) or getattr(args, "tolerance", None) is None or getattr(args, "deta_w", None) is None:
+        return None
+    from .networks.penalizer import _consts
+    k2w, kh = _consts(args.deta_w)
+    return (float(args.tolerance), k2w, kh)
+
+
+def pen_partials(depth, raw, z, rays_d, consts):
+    """The penalizer partial sums the fused compositing pass left for this level, or None: looked up on the ``depth`` tensor of the
+    dict (an OUTPUT of the compositing node, so holding them there creates no reference cycle through the saved ``raw``), and
+    only handed out when the caller is asking for exactly what was computed -- same ``raw`` / ``z`` / ``rays_d`` storage and the
+    same constants."""
+    info = getattr(depth, "_dmn_pen", None)
+    if info is None or consts is None:
+        return None
+    part, p_raw, p_z, p_d, p_consts = info
+    if p_consts != tuple(consts) or p_raw != raw.data_ptr() or p_z != z.data_ptr() or p_d != rays_d.data_ptr():
+        return None
+    return part
+
+
 MAX_TRAIN_SAMPLES = 1048576          # DMNERF_MAX_TRAIN_SAMPLES (include/dmnerf_hip.h)
 
 
@@ -573,15 +648,24 @@ def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=No
     z_coarse = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
     from . import weights
     fused, split = bool(getattr(args, "fuse_heads", False)), weights.split_mode(args)
+    consts = pen_consts(args)                           # the step penalises: composite + penalizer partial sums in one pass
+
+    def composite(raw, z):
+        if consts is None:
+            return CompositeFunction.apply(raw, z, rays_d)
+        raw, z = _lib.f32(raw), _lib.f32(z)
+        rgb, w, depth, ins, part = CompositePenFunction.apply(raw, z, rays_d, consts)
+        depth._dmn_pen = (part, raw.data_ptr(), z.data_ptr(), rays_d.data_ptr(), consts)       # see pen_partials
+        return rgb, w, depth, ins
     raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse, fused, split)
-    rgb_coarse, weights_coarse, depth_coarse, ins_coarse = CompositeFunction.apply(raw_coarse, z_coarse, rays_d)
+    rgb_coarse, weights_coarse, depth_coarse, ins_coarse = composite(raw_coarse, z_coarse)
     with torch.no_grad():                              # z_samples.detach()  (render.py:68)
         if n_imp == 0:                                 # sample_pdf returns [N, 0]: the fine depths are the coarse ones
             z_fine = z_coarse.clone()
         else:
             z_fine = helpers.importance_resample(z_coarse, weights_coarse.detach(), n_imp, det=(perturb == 0.), u=u)
     raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine, fused, split)
-    rgb_fine, weights_fine, depth_fine, ins_fine = CompositeFunction.apply(raw_fine, z_fine, rays_d)
+    rgb_fine, weights_fine, depth_fine, ins_fine = composite(raw_fine, z_fine)
     if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
         ins_fine = ins_fine[-args.N_ins:]
         ins_coarse = ins_coarse[-args.N_ins:]

@@ -87,6 +87,7 @@ struct TailBwdArgs {
     float* d_rgb[2];
     float* gout8;                // {g, 0, 0, 0} per level: upstream of the criterion's four outputs
     float* pen_scales4;          // inv * g per level
+    double* g_part8;             // nullable: {scale_b, 0, scale_m, 0} per level, the row dmnerf_composite_pen_bwd reads
 };
 
 __global__ __launch_bounds__(256) void loss_tail_bwd_kernel(const TailBwdArgs a) {
@@ -102,7 +103,14 @@ __global__ __launch_bounds__(256) void loss_tail_bwd_kernel(const TailBwdArgs a)
     }
     if (blockIdx.x == 0 && threadIdx.x < 4) {
         a.gout8[4 * lvl + threadIdx.x] = threadIdx.x == 0 ? g : 0.f;
-        if (threadIdx.x < 2) a.pen_scales4[2 * lvl + threadIdx.x] = a.pen_inv4[2 * lvl + threadIdx.x] * g;
+        if (threadIdx.x < 2) {
+            const float sc = a.pen_inv4[2 * lvl + threadIdx.x] * g;
+            a.pen_scales4[2 * lvl + threadIdx.x] = sc;
+            if (a.g_part8) {
+                a.g_part8[4 * lvl + 2 * threadIdx.x] = (double)sc;
+                a.g_part8[4 * lvl + 2 * threadIdx.x + 1] = 0.0;
+            }
+        }
     }
 }
 
@@ -124,13 +132,13 @@ extern "C" int dmnerf_loss_tail_fwd(const float* d_rgb_a, const float* d_rgb_b, 
 
 extern "C" int dmnerf_loss_tail_bwd(const float* d_rgb_a, const float* d_rgb_b, const float* d_target, int64_t N,
                                     const float* d_g_total, const float* d_pen_inv4, float* d_grad_rgb_a, float* d_grad_rgb_b,
-                                    float* d_gout8, float* d_pen_scales4, void* stream) {
+                                    float* d_gout8, float* d_pen_scales4, double* d_g_partials8, void* stream) {
     if (N < 1) return dmn_fail(DMNERF_E_ARG, "loss_tail_bwd: bad N=%lld", (long long)N);
     if (!d_rgb_a || !d_rgb_b || !d_target || !d_g_total || !d_pen_inv4 || !d_grad_rgb_a || !d_grad_rgb_b || !d_gout8 || !d_pen_scales4)
         return dmn_fail(DMNERF_E_ARG, "loss_tail_bwd: null pointer");
     TailBwdArgs a{};
     a.rgb[0] = d_rgb_a; a.rgb[1] = d_rgb_b; a.target = d_target; a.N = N; a.g_total = d_g_total; a.pen_inv4 = d_pen_inv4;
-    a.d_rgb[0] = d_grad_rgb_a; a.d_rgb[1] = d_grad_rgb_b; a.gout8 = d_gout8; a.pen_scales4 = d_pen_scales4;
+    a.d_rgb[0] = d_grad_rgb_a; a.d_rgb[1] = d_grad_rgb_b; a.gout8 = d_gout8; a.pen_scales4 = d_pen_scales4; a.g_part8 = d_g_partials8;
     const int64_t n = N * 3;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, a);

@@ -160,18 +160,14 @@ __global__ void embed_kernel(const float* __restrict__ x, int64_t M, int L, floa
 // ------------------------------------------------------------------------------------------
 // render_train  (networks/render.py:6-28): one wave per ray
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
-    const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int64_t N,
+// (one ray = one wave; returns the ray's depth, the same float in every lane)
+__device__ __forceinline__ float composite_ray(
+    const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int64_t n, int lane,
     int S, int C, int n_ins, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map,
-    float* __restrict__ ins_map) {
-    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
-    if (n >= N) return;
+    float* __restrict__ ins_map, float* wl) {
     const int ch = 4 + C;
     const float* __restrict__ rr = raw + n * (int64_t)S * ch;
     const float* __restrict__ zr = z + n * (int64_t)S;
-    float* wl = w_lds[wv];
 
     const float dx = rays_d[n * 3 + 0], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);            // torch.norm(rays_d[..., None, :], dim=-1)
@@ -204,7 +200,8 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
         carry = carry * shfl_d(incl, WAVE - 1);
     }
     depth_acc = wave_sum_d(depth_acc);
-    if (lane == 0) depth_map[n] = (float)depth_acc;
+    const float depth_f = (float)depth_acc;
+    if (lane == 0) depth_map[n] = depth_f;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS writes above are read below by other lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -240,7 +237,7 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
             // sigmoid after the sum; n_ins = C-1 drops the last channel (render.py:24-26), n_ins = C keeps it (manipulator.py:101-102)
             else if (lane - 4 < n_ins) ins_map[n * (int64_t)n_ins + (lane - 4)] = sigmoidf_ref((float)tot);
         }
-        return;
+        return depth_f;
     }
     for (int c = lane; c < ch; c += WAVE) {
         if (c == 3) continue;
@@ -254,6 +251,18 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
             ins_map[n * (int64_t)n_ins + (c - 4)] = sigmoidf_ref((float)acc);
         }
     }
+    return depth_f;
+}
+
+__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int64_t N,
+    int S, int C, int n_ins, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map,
+    float* __restrict__ ins_map) {
+    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (n >= N) return;
+    composite_ray(raw, z, rays_d, n, lane, S, C, n_ins, rgb_map, weights, depth_map, ins_map, w_lds[wv]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -263,13 +272,25 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
 //   d raw_s3 = [raw_s3 > 0] dL/da_s dist_s exp(-relu(raw_s3) dist_s)
 //   d raw_sc = g_rgb_c w_s s(1-s), c < 3;   d raw_s(4+k) = g_ins_k m_k (1 - m_k) w_s, k < C-1;  0 for the dropped channel
 // ------------------------------------------------------------------------------------------
+// PEN (extension, dmnerf_composite_pen_bwd): the emptiness penalizer's gradient w.r.t. raw[..., 4:] (penalizer_kernel<1> below,
+// same arithmetic) is ADDED to the compositing gradient in the same pass over the ray: one kernel and one write of d raw instead
+// of two kernels, two writes and an elementwise add.
+struct PenBwd {
+    const float* depth;          // [N] the forward's depth map (the penalizer's detached argument)
+    const double* g_part;        // [>= 4] d loss / d (the ray's four partial sums): {scale_b, -, scale_m, -}, the same for every ray
+    float tol, k2w, kh;
+};
+
+template <bool PEN>
 __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
     const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
     const float* __restrict__ ins_map, const float* __restrict__ g_rgb, const float* __restrict__ g_ins,
-    const float* __restrict__ g_depth, const float* __restrict__ g_w, int64_t N, int S, int C, float* __restrict__ d_raw) {
+    const float* __restrict__ g_depth, const float* __restrict__ g_w, int64_t N, int S, int C, float* __restrict__ d_raw,
+    const PenBwd pen) {
     __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
     __shared__ float t_lds[RAYS_PER_BLOCK][MAX_S];
     __shared__ float g_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float wm_lds[PEN ? RAYS_PER_BLOCK : 1][PEN ? MAX_S : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (n >= N) return;
@@ -339,6 +360,27 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
         after += total;
     }
 
+    // (PEN) the penalizer's per-sample weights: A m_b -> the G row (dead after pass 2), G m_m -> its own row
+    float sc_b = 0.f, sc_m = 0.f;
+    if constexpr (PEN) {
+        sc_b = (float)pen.g_part[0];
+        sc_m = (float)pen.g_part[2];
+        lds_sync_wave();
+        float* wb = gl;
+        float* wm = wm_lds[wv];
+        const float dep = pen.depth[n];
+        const float d_before = (dep - pen.tol) * nrm, d_after = (dep + pen.tol) * nrm, d_depth = dep * nrm;
+        for (int s2 = lane; s2 < S; s2 += WAVE) {
+            const float p = zr[s2] * nrm;
+            const float dd = d_depth - p;
+            const float G = expf(-(dd * dd) / pen.k2w) / pen.kh + 1e-8f;
+            const float mb = p < d_before ? 1.f : 0.f;
+            const float ma = p > d_after ? 1.f : 0.f;
+            const float mm = 1.f - (ma + mb);
+            wb[s2] = (1.f - G) * mb;
+            wm[s2] = G * mm;
+        }
+    }
     // pass 3: channel gradients.  Per-channel coefficients once (the sample weights' LDS row is reused: t is dead), then
     // the ray's S x (4 + C) block as ONE contiguous stream, lane <-> element (coalesced 256-byte stores, every lane busy)
     lds_sync_wave();
@@ -361,7 +403,17 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
                 const float sg = sigmoidf_ref(rr[e]);
                 dr[e] = (cl[c] * wl[s]) * ((1.f - sg) * sg);
             } else {
-                dr[e] = cl[c] * wl[s];
+                float v = cl[c] * wl[s];
+                if constexpr (PEN) {                      // + penalizer_kernel<1>'s value for this element (autograd's add, in place)
+                    const float P = sigmoidf_ref(rr[e]);
+                    const float q = (1.f - P) + 1e-8f;
+                    const float sp = P * (1.f - P);
+                    const bool last = c == ch - 1;
+                    float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * gl[s] * sc_b;
+                    if (last) g += (sp / q) * wm_lds[wv][s] * sc_m;
+                    v = v + g;
+                }
+                dr[e] = v;
             }
         }
         s += ds; c += dc;
@@ -387,20 +439,12 @@ struct PenArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void penalizer_kernel(const PenArgs a) {
-    __shared__ float wb_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float wm_lds[RAYS_PER_BLOCK][MAX_S];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
-    if (n >= a.N) return;
+__device__ __forceinline__ void penalizer_ray(const PenArgs& a, int64_t n, int lane, float dep, float* wb, float* wm) {
     const int S = a.S, C = a.C, ch = 4 + C;
     const float* __restrict__ rr = a.raw + n * (int64_t)S * ch;
     const float* __restrict__ zr = a.z + n * (int64_t)S;
-    float* wb = wb_lds[wv];
-    float* wm = wm_lds[wv];
     const float dx = a.rays_d[n * 3 + 0], dy = a.rays_d[n * 3 + 1], dz = a.rays_d[n * 3 + 2];
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float dep = a.depth[n];
     const float d_before = (dep - a.tol) * nrm, d_after = (dep + a.tol) * nrm, d_depth = dep * nrm;
     double n_b = 0.0, n_m = 0.0;
     for (int s = lane; s < S; s += WAVE) {
@@ -448,6 +492,31 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void penalizer_kernel(const P
             a.out4[n * 4 + 0] = s_b; a.out4[n * 4 + 1] = n_b; a.out4[n * 4 + 2] = s_m; a.out4[n * 4 + 3] = n_m;
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void penalizer_kernel(const PenArgs a) {
+    __shared__ float wb_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float wm_lds[RAYS_PER_BLOCK][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (n >= a.N) return;
+    penalizer_ray<MODE>(a, n, lane, a.depth[n], wb_lds[wv], wm_lds[wv]);
+}
+
+// render_train + the penalizer's per-ray partial sums in ONE pass over the ray (extension, dmnerf_composite_pen_fwd): the
+// penalizer's only extra input is the ray's own depth, which the compositing pass has just produced; the second walk over
+// raw[..., 4:] hits the cache lines the first one loaded.
+__global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_pen_kernel(
+    const PenArgs a, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map, float* __restrict__ ins_map) {
+    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float wb_lds[RAYS_PER_BLOCK][MAX_S];
+    __shared__ float wm_lds[RAYS_PER_BLOCK][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (n >= a.N) return;
+    const float dep = composite_ray(a.raw, a.z, a.rays_d, n, lane, a.S, a.C, a.C - 1, rgb_map, weights, depth_map, ins_map, w_lds[wv]);
+    penalizer_ray<0>(a, n, lane, dep, wb_lds[wv], wm_lds[wv]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -783,9 +852,39 @@ extern "C" int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const 
     if (N == 0) return DMNERF_OK;
     if (!d_raw || !d_z || !d_rays_d || !d_ins_map || !d_g_rgb || !d_g_ins || !d_grad_raw)
         return dmn_fail(DMNERF_E_ARG, "composite_bwd: null pointer");
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
-                       d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw);
+    hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+                       d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw, PenBwd{});
     return dmn_check_launch("composite_bwd");
+}
+
+extern "C" int dmnerf_composite_pen_fwd(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N, int S, int C,
+                                        float tolerance, float two_deta_w_sq, float gauss_norm, float* d_rgb_map, float* d_weights,
+                                        float* d_depth_map, float* d_ins_map, double* d_partials, void* stream) {
+    if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "composite_pen_fwd: bad N=%lld S=%d (max %d) C=%d", (long long)N, S, MAX_S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_rays_d || !d_rgb_map || !d_weights || !d_depth_map || !d_ins_map || !d_partials)
+        return dmn_fail(DMNERF_E_ARG, "composite_pen_fwd: null pointer");
+    PenArgs a{};
+    a.raw = d_raw; a.z = d_z; a.depth = d_depth_map; a.rays_d = d_rays_d; a.N = N; a.S = S; a.C = C;
+    a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.out4 = d_partials;
+    hipLaunchKernelGGL(composite_pen_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+                       a, d_rgb_map, d_weights, d_depth_map, d_ins_map);
+    return dmn_check_launch("composite_pen_fwd");
+}
+
+extern "C" int dmnerf_composite_pen_bwd(const float* d_raw, const float* d_z, const float* d_rays_d, const float* d_ins_map,
+                                        const float* d_depth_map, const float* d_g_rgb, const float* d_g_ins, const float* d_g_depth,
+                                        const float* d_g_weights, const double* d_g_partials, int64_t N, int S, int C, float tolerance,
+                                        float two_deta_w_sq, float gauss_norm, float* d_grad_raw, void* stream) {
+    if (N < 0 || S < 1 || S > MAX_S || C < 1) return dmn_fail(DMNERF_E_ARG, "composite_pen_bwd: bad N=%lld S=%d (max %d) C=%d", (long long)N, S, MAX_S, C);
+    if (N == 0) return DMNERF_OK;
+    if (!d_raw || !d_z || !d_rays_d || !d_ins_map || !d_depth_map || !d_g_rgb || !d_g_ins || !d_g_partials || !d_grad_raw)
+        return dmn_fail(DMNERF_E_ARG, "composite_pen_bwd: null pointer");
+    PenBwd pen{};
+    pen.depth = d_depth_map; pen.g_part = d_g_partials; pen.tol = tolerance; pen.k2w = two_deta_w_sq; pen.kh = gauss_norm;
+    hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+                       d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw, pen);
+    return dmn_check_launch("composite_pen_bwd");
 }
 
 extern "C" int dmnerf_penalizer_fwd(const float* d_raw, const float* d_z, const float* d_depth, const float* d_rays_d,

@@ -248,7 +248,8 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     n_ins = getattr(args, "N_ins", None)
     largs.N_ins = None                                   # the label slice is taken on the gathered batch
     render = render or (lambda r, z, a, tr, uu: R.dm_nerf(r, None, None, models[0], models[1], z, a, t_rand=tr, u=uu))
-    out = render(rays[:, sl].contiguous(), z_vals[sl].contiguous(), largs,
+    local_rays = rays[:, sl].contiguous()                # (kept: the loss tail recognises the tensors the render was called with)
+    out = render(local_rays, z_vals[sl].contiguous(), largs,
                  None if t_rand is None else t_rand[sl].contiguous(),
                  None if u is None else (u if u.dim() == 1 else u[sl].contiguous()))      # a 1-D u is the grid shared by all rays
     penalize = bool(getattr(args, "penalize", False))    # train_dmsr.py:51: the emptiness term is optional (--penalize)
@@ -269,7 +270,7 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
         from . import losses
         if n_ins is not None:
             ins_f, ins_c = ins_f[-n_ins:], ins_c[-n_ins:]
-        loss, _ = losses.train_losses(out, rays[1, sl], target, labels, ins_num, largs, rgb_ins=(rgb_f, rgb_c, ins_f, ins_c),
+        loss, _ = losses.train_losses(out, local_rays[1], target, labels, ins_num, largs, rgb_ins=(rgb_f, rgb_c, ins_f, ins_c),
                                       sharded=world > 1)
     else:
         mse = mse or E.img2mse

@@ -27,7 +27,7 @@ from .networks.penalizer import _consts
 
 class _TrainLosses(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_f, rgb_c, ins_f, ins_c, raw_f, raw_c, z_f, z_c, depth_f, depth_c, rays_d, target, labels, cfg):
+    def forward(ctx, rgb_f, rgb_c, ins_f, ins_c, raw_f, raw_c, part_f, part_c, z_f, z_c, depth_f, depth_c, rays_d, target, labels, cfg):
         lib = _lib.load()
         dev = rgb_f.device
         N = rgb_f.shape[0]
@@ -50,13 +50,16 @@ class _TrainLosses(torch.autograd.Function):
         if penalize:
             k2w, kh = _consts(deta_w)
             consts = (float(tol), k2w, kh)
-            parts = []
-            for raw, z, depth in ((raw_f, z_f, depth_f), (raw_c, z_c, depth_c)):
-                n, S, _ = raw.shape
-                part = torch.empty(n, 4, dtype=torch.float64, device=dev)
-                _lib.check(lib.dmnerf_penalizer_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(depth), _lib.ptr(rays_d), n, S, C,
-                                                    consts[0], k2w, kh, _lib.ptr(part), _lib.stream()), "dmnerf_penalizer_fwd")
-                parts.append(part)
+            if part_f is not None:                             # the fused compositing pass already formed the per-ray sums
+                parts = [part_f, part_c]
+            else:
+                parts = []
+                for raw, z, depth in ((raw_f, z_f, depth_f), (raw_c, z_c, depth_c)):
+                    n, S, _ = raw.shape
+                    part = torch.empty(n, 4, dtype=torch.float64, device=dev)
+                    _lib.check(lib.dmnerf_penalizer_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(depth), _lib.ptr(rays_d), n, S, C,
+                                                        consts[0], k2w, kh, _lib.ptr(part), _lib.stream()), "dmnerf_penalizer_fwd")
+                    parts.append(part)
             sums = torch.empty(2, 4, dtype=torch.float64, device=dev)
             _lib.check(lib.dmnerf_penalizer_sums2(_lib.ptr(parts[0]), parts[0].shape[0], _lib.ptr(parts[1]), parts[1].shape[0],
                                                   _lib.ptr(sums), _lib.stream()), "dmnerf_penalizer_sums2")
@@ -68,8 +71,11 @@ class _TrainLosses(torch.autograd.Function):
         _lib.check(lib.dmnerf_loss_tail_fwd(_lib.ptr(rgb_f), _lib.ptr(rgb_c), _lib.ptr(target), N, _lib.ptr(crit[0]), _lib.ptr(crit[1]),
                                             _lib.ptr(None if sums is None else sums[0]), _lib.ptr(None if sums is None else sums[1]),
                                             C, _lib.ptr(terms), _lib.ptr(inv), _lib.stream()), "dmnerf_loss_tail_fwd")
-        ctx.save_for_backward(rgb_f, rgb_c, ins_f, ins_c, raw_f, raw_c, z_f, z_c, depth_f, depth_c, rays_d, target, labels, work, inv)
+        keep_raw = penalize and part_f is None                  # (the per-ray backward kernels of this node need raw; the fused form does not)
+        ctx.save_for_backward(rgb_f, rgb_c, ins_f, ins_c, raw_f if keep_raw else None, raw_c if keep_raw else None, z_f, z_c, depth_f, depth_c,
+                              rays_d, target, labels, work, inv)
         ctx.cfg, ctx.consts = cfg, consts
+        ctx.from_parts = (part_f.shape[0], part_c.shape[0]) if (penalize and part_f is not None) else None
         total = terms[6]
         out_terms = terms[:6]
         ctx.mark_non_differentiable(out_terms, work)
@@ -87,14 +93,18 @@ class _TrainLosses(torch.autograd.Function):
         d_rgb_f, d_rgb_c = torch.empty_like(rgb_f), torch.empty_like(rgb_c)
         gout = torch.empty(8, dtype=torch.float32, device=dev)
         scales = torch.empty(4, dtype=torch.float32, device=dev)
+        g_part = torch.empty(2, 4, dtype=torch.float64, device=dev) if ctx.from_parts is not None else None
         _lib.check(lib.dmnerf_loss_tail_bwd(_lib.ptr(rgb_f), _lib.ptr(rgb_c), _lib.ptr(target), N, _lib.ptr(g), _lib.ptr(inv), _lib.ptr(d_rgb_f),
-                                            _lib.ptr(d_rgb_c), _lib.ptr(gout), _lib.ptr(scales), _lib.stream()), "dmnerf_loss_tail_bwd")
+                                            _lib.ptr(d_rgb_c), _lib.ptr(gout), _lib.ptr(scales), _lib.ptr(g_part), _lib.stream()), "dmnerf_loss_tail_bwd")
         d_ins_f, d_ins_c = torch.empty_like(ins_f), torch.empty_like(ins_c)
         _lib.check(lib.dmnerf_ins_criterion_bwd2(_lib.ptr(ins_f), _lib.ptr(ins_c), _lib.ptr(labels), ins_f.shape[0], ins_num, _lib.ptr(work[0]),
                                                  _lib.ptr(work[1]), _lib.ptr(gout[:4]), _lib.ptr(gout[4:]), _lib.ptr(d_ins_f), _lib.ptr(d_ins_c),
                                                  _lib.stream()), "dmnerf_ins_criterion_bwd2")
-        d_raw_f = d_raw_c = None
-        if penalize:
+        d_raw_f = d_raw_c = d_part_f = d_part_c = None
+        if penalize and ctx.from_parts is not None:
+            # d raw is formed inside the compositing node's backward kernel from the gradient of its partial sums
+            d_part_f, d_part_c = g_part[0].expand(ctx.from_parts[0], 4), g_part[1].expand(ctx.from_parts[1], 4)
+        elif penalize:
             tolf, k2w, kh = ctx.consts
             grads = []
             for lvl, (raw, z, depth) in enumerate(((raw_f, z_f, depth_f), (raw_c, z_c, depth_c))):
@@ -104,7 +114,7 @@ class _TrainLosses(torch.autograd.Function):
                                                     _lib.ptr(scales[2 * lvl:2 * lvl + 2]), _lib.ptr(d_raw), _lib.stream()), "dmnerf_penalizer_bwd")
                 grads.append(d_raw)
             d_raw_f, d_raw_c = grads
-        return (d_rgb_f, d_rgb_c, d_ins_f, d_ins_c, d_raw_f, d_raw_c) + (None,) * 8
+        return (d_rgb_f, d_rgb_c, d_ins_f, d_ins_c, d_raw_f, d_raw_c, d_part_f, d_part_c) + (None,) * 8
 
 
 def train_losses(out, rays_d, target, labels, ins_num, args, rgb_ins=None, sharded=False, check=None):
@@ -131,7 +141,16 @@ def train_losses(out, rays_d, target, labels, ins_num, args, rgb_ins=None, shard
     rays_d = det(rays_d)
     _lib.require_gpu(rgb_f, rgb_c, ins_f, ins_c, raw_f, raw_c, z_f, z_c, depth_f, depth_c, rays_d, target, lab)
     cfg = (int(ins_num), penalize, getattr(args, "tolerance", None), getattr(args, "deta_w", None), bool(sharded))
-    total, terms, work = _TrainLosses.apply(rgb_f, rgb_c, ins_f, ins_c, raw_f, raw_c, z_f, z_c, depth_f, depth_c, rays_d, target, lab, cfg)
+    part_f = part_c = None
+    if penalize:                                            # per-ray sums left by the fused compositing pass (both levels or neither)
+        from . import autograd
+        consts = autograd.pen_consts(args)
+        part_f = autograd.pen_partials(out['depth_fine'], raw_f, z_f, rays_d, consts)
+        part_c = autograd.pen_partials(out['depth_coarse'], raw_c, z_c, rays_d, consts)
+        if part_f is None or part_c is None:
+            part_f = part_c = None
+    total, terms, work = _TrainLosses.apply(rgb_f, rgb_c, ins_f, ins_c, raw_f, raw_c, part_f, part_c, z_f, z_c, depth_f, depth_c, rays_d, target,
+                                            lab, cfg)
     if check is None:
         import os
         check = os.environ.get("DMNERF_CHECK_LABELS", "0") == "1"

@@ -345,13 +345,14 @@ int dmnerf_ins_criterion_bwd2(const float* d_pred_a, const float* d_pred_b, cons
  * nullable), added in f32 in the training loop's order.  _fwd: d_terms8 = {mse_a, crit_a, pen_a, mse_b, crit_b, pen_b, total, 0},
  * d_pen_inv4 = the penalizer's two normalisers per level.  _bwd, for the upstream scalar d_g_total: d loss / d rgb of both
  * levels ((g / 3N) * (2 (rgb - target)), the products autograd forms), d_gout8 = {g, 0, 0, 0} x 2 for dmnerf_ins_criterion_bwd2
- * and d_pen_scales4 = d_pen_inv4 * g for dmnerf_penalizer_bwd.  One launch each. */
+ * and d_pen_scales4 = d_pen_inv4 * g for dmnerf_penalizer_bwd; d_g_partials8 (nullable) = the same factors as the 4-double rows
+ * {scale_b, 0, scale_m, 0} per level that dmnerf_composite_pen_bwd reads.  One launch each. */
 int dmnerf_loss_tail_fwd(const float* d_rgb_a, const float* d_rgb_b, const float* d_target, int64_t N,
                          const float* d_crit_out4_a, const float* d_crit_out4_b, const double* d_pen_sums4_a,
                          const double* d_pen_sums4_b, int C, float* d_terms8, float* d_pen_inv4, void* stream);
 int dmnerf_loss_tail_bwd(const float* d_rgb_a, const float* d_rgb_b, const float* d_target, int64_t N,
                          const float* d_g_total, const float* d_pen_inv4, float* d_grad_rgb_a, float* d_grad_rgb_b,
-                         float* d_gout8, float* d_pen_scales4, void* stream);
+                         float* d_gout8, float* d_pen_scales4, double* d_g_partials8, void* stream);
 
 /* ---- manipulator.py (scene editing at render time) -----------------------------------
  * manipulator_render (networks/manipulator.py:86-105): render_train whose object map keeps all C channels
@@ -392,6 +393,19 @@ int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const float* d_de
  * writes d_loss1 = (float)(S0 / (C max(S1,1e-8)) + S2 / max(S3,1e-8)) and d_inv2 = {1 / (C max(S1,1e-8)), 1 / max(S3,1e-8)}
  * (float; d_scales of _bwd = d_inv2 * upstream gradient). */
 int dmnerf_penalizer_sums(const double* d_partials, int64_t N, double* d_sums4, void* stream);
+/* render_train AND the penalizer's per-ray partial sums in one pass over the ray (extension, SURVEY 8(f)-1: the penalizer's only
+ * other input is the ray's own depth, which the compositing pass has just produced): the outputs of dmnerf_composite_fwd plus
+ * d_partials [N,4] of dmnerf_penalizer_fwd called with that depth map -- bit-equal to the two calls.  _bwd: dmnerf_composite_bwd
+ * plus the penalizer's gradient (dmnerf_penalizer_bwd's values) ADDED in the same pass; d_g_partials = d loss / d partials of ONE
+ * ray, 4 doubles, the same for every ray ({up / (C max(sum m_b, 1e-8)), -, up / max(sum m_m, 1e-8), -}: the normalisers are
+ * batch sums).  One kernel and one write of d raw instead of two kernels, two writes and an elementwise add. */
+int dmnerf_composite_pen_fwd(const float* d_raw, const float* d_z, const float* d_rays_d, int64_t N, int S, int C,
+                             float tolerance, float two_deta_w_sq, float gauss_norm, float* d_rgb_map, float* d_weights,
+                             float* d_depth_map, float* d_ins_map, double* d_partials, void* stream);
+int dmnerf_composite_pen_bwd(const float* d_raw, const float* d_z, const float* d_rays_d, const float* d_ins_map,
+                             const float* d_depth_map, const float* d_g_rgb, const float* d_g_ins, const float* d_g_depth,
+                             const float* d_g_weights, const double* d_g_partials, int64_t N, int S, int C, float tolerance,
+                             float two_deta_w_sq, float gauss_norm, float* d_grad_raw, void* stream);
 /* ... of two levels in one launch: d_sums8 = the four sums of a, then of b. */
 int dmnerf_penalizer_sums2(const double* d_partials_a, int64_t N_a, const double* d_partials_b, int64_t N_b, double* d_sums8,
                            void* stream);

@@ -41,8 +41,13 @@ def _scene(A, N, ins_num=INS):
 LEAVES = ('rgb_fine', 'rgb_coarse', 'ins_fine', 'ins_coarse', 'raw_fine', 'raw_coarse')
 
 
-@pytest.mark.parametrize("penalize,n_ins,ins_num", [(True, None, 13), (False, None, 13), (True, 70, 13), (True, None, 59)])
-def test_fused_tail_equals_the_drop_in_losses(A, penalize, n_ins, ins_num):
+@pytest.mark.parametrize("penalize,n_ins,ins_num,ref_pen", [(True, None, 13, "separate"), (True, None, 13, "drop_in"), (False, None, 13, "separate"),
+                                                             (True, 70, 13, "separate"), (True, None, 59, "separate")])
+def test_fused_tail_equals_the_drop_in_losses(A, penalize, n_ins, ins_num, ref_pen):
+    """``ref_pen``: how the REFERENCE side evaluates the emptiness term -- "separate": ``emptiness_penalizer`` on plain tensors, i.e.
+    the stand-alone forward / backward kernels (dmnerf_penalizer_fwd / _bwd) and autograd's add of the two d raw; "drop_in":
+    ``ins_penalizer`` on the dict's own tensors, which finds the per-ray sums the fused compositing pass left behind and lets that
+    pass's backward kernel add the gradient.  The fused tail must equal both, bit for bit."""
     N = 200
     (mc, mf), rays, z, target, g = _scene(A, N, ins_num)
     labels = torch.randint(0, 7, (n_ins or N,), generator=g).cuda()
@@ -59,8 +64,12 @@ def test_fused_tail_equals_the_drop_in_losses(A, penalize, n_ins, ins_num):
     for lvl in ("fine", "coarse"):
         t = [A.E.img2mse(out['rgb_' + lvl], target), A.E.ins_criterion(cut(out['ins_' + lvl]), labels, ins_num)[0]]
         loss_ref = loss_ref + t[0] + t[1]
-        if penalize:
+        if penalize and ref_pen == "drop_in":
             t.append(A.P.ins_penalizer(out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl], rays[1], args).sum())
+            loss_ref = loss_ref + t[2]
+        elif penalize:
+            t.append(A.P.emptiness_penalizer(out['raw_' + lvl], out['z_vals_' + lvl], out['depth_' + lvl][..., None].detach(), rays[1],
+                                             args.tolerance, args.deta_w).sum())
             loss_ref = loss_ref + t[2]
         else:
             t.append(torch.zeros((), device="cuda"))
@@ -71,7 +80,10 @@ def test_fused_tail_equals_the_drop_in_losses(A, penalize, n_ins, ins_num):
                                     rgb_ins=(out['rgb_fine'], out['rgb_coarse'], cut(out['ins_fine']), cut(out['ins_coarse'])))
     grads = torch.autograd.grad(total, leaves if penalize else leaves[:4], retain_graph=True)
     assert terms.shape == (6,) and not terms.requires_grad and total.requires_grad
-    for i, (a, b) in enumerate(zip(terms.tolist(), [float(t) for t in terms_ref])):
+    if penalize:                                                 # the step penalises: the compositing pass carried the per-ray sums
+        from dm_nerf_amd import autograd as G
+        assert G.pen_partials(out['depth_fine'], out['raw_fine'], out['z_vals_fine'], rays[1], G.pen_consts(args)) is not None
+    for i, (a, b) in enumerate(zip(terms.tolist(), [float(t.detach()) for t in terms_ref])):
         if i % 3 == 0:                                           # squared error: summed in double here, f32 tree in ATen
             assert abs(a - b) <= 2e-7 * abs(b), (i, a, b)
         else:                                                    # same kernels, same arithmetic
