@@ -1,4 +1,4 @@
-"""Build-container script (CPU, ~55 min on 8 cores): the ORACLE's training trajectory on the analytic scene, for
+"""Build-container script (CPU, ~1 h alone on 8 cores; ~2 h next to other work): the ORACLE's training trajectory on the analytic scene, for
 tests/test_gpu_convergence.py::test_training_trajectory_follows_the_oracle (the first STEPS = 300 steps, loss by loss) and
 ::test_trained_psnr_matches_the_oracle_at_the_plateau (all LONG_STEPS = 2000 steps, held-out PSNR at EVAL_AT).
 

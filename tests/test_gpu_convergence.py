@@ -15,8 +15,9 @@ intersection), so there is a right answer without a dataset:
   chaotic, so the PSNR bound is not a guess: the same training is repeated on the HIP path with only the SUMMATION ORDER of the
   weight-gradient split changed (autograd.PLAN_MAX_WGS), and the allowed gap to the oracle is 1.5 x the spread of those runs
   (never below 0.05 dB).
-* ``test_trained_psnr_matches_the_oracle_at_the_plateau`` -- the same run continued to 2000 steps, where the PSNR has stopped
-  climbing: mean held-out PSNR at steps 1000 / 1500 / 2000 against the oracle's, bounded the same way.
+* ``test_trained_psnr_matches_the_oracle_at_the_plateau`` -- the same run continued to 2000 steps.  From ~1000 steps on the
+  held-out PSNR no longer climbs steadily (oracle: 24.79 / 26.79 / 25.14 dB at 1000 / 1500 / 2000 -- a 512-ray Adam run at lr 5e-4
+  moves a dB between checkpoints), so the comparison is the MEAN over those three checkpoints, bounded the same way.
 """
 import os
 import sys
@@ -228,10 +229,11 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
 
 @pytest.mark.timeout(900)
 def test_trained_psnr_matches_the_oracle_at_the_plateau(golden, capsys):
-    """The same run continued to 2000 steps (the oracle's: ~55 min of CPU in the build container, make_train_traj.py): by 1000
-    steps the held-out PSNR has stopped climbing, so single checkpoints no longer carry the slope of the curve.  Mean PSNR over
-    steps 1000 / 1500 / 2000, default kernels against the oracle, bounded by the chaos floor measured alongside (three HIP runs
-    that differ in the summation order of the weight gradients only): |gap| <= max(0.05 dB, 1.5 x HIP-vs-HIP spread)."""
+    """The same run continued to 2000 steps (the oracle's: ~2 h of CPU in the build container, make_train_traj.py): from ~1000
+    steps on the held-out PSNR has no steady slope left (oracle 24.79 / 26.79 / 25.14 dB at 1000 / 1500 / 2000: it wanders by a dB
+    between checkpoints), so single checkpoints say little.  Mean PSNR over steps 1000 / 1500 / 2000, default kernels against the
+    oracle, bounded by the chaos floor measured alongside (three HIP runs that differ in the summation order of the weight
+    gradients only): |gap| <= max(0.05 dB, 1.5 x HIP-vs-HIP spread)."""
     g = golden("train_traj")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_train_traj as T
