@@ -293,12 +293,13 @@ def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=
     return {"ms_per_step": dt * 1e3, "rays_per_s": n / dt, "batch_rays": n, "final_loss": float(loss)}
 
 
-def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full):
+def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full, t_3072_ms=None):
     """What ONE GPU can say about the 8-GPU strong-scaling run (SURVEY 8(e) caveat): the complete optimisation step at the
     per-rank shard of an 8-way split of the shipped batch sizes -- 384 rays (N_train 3072 / 8) and 512 rays (4096 / 8) -- eager
     and as one HIP graph (graph_train_leg).  predicted_strong_efficiency_8 = (t_full / 8) / t_shard: the fixed per-step cost
     (launch overheads, the loss / Adam kernels that do not shrink with the batch) is what keeps it below 1; the exchange itself
-    (0.2 MB gather + one 5.57 MB all-reduce) is not in it."""
+    (0.2 MB gather + one 5.57 MB all-reduce) is not in it.  The step is the product's default: fused loss tail, and at 384 rays the
+    two levels' network backwards on two streams (distributed.overlap_enabled: it removes the partial round there)."""
     out = {}
     for n in (384, 512):
         r = train_leg(mc, mf, ro, rd, z, steps, dev, n=n)
@@ -310,6 +311,9 @@ def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full):
     full = t_full_ms * (4096.0 / n_full)
     out["predicted_strong_efficiency_8"] = {"eager_n512_of_4096": (full / 8.0) / out["n512"]["ms_per_step"],
                                             "graph_n512_of_4096": (full / 8.0) / out["n512"]["graph_ms_per_step"]}
+    if t_3072_ms:                                            # the shipped N_train: 3072 rays over 8 ranks = 384 each
+        out["full_3072_ms"] = t_3072_ms
+        out["predicted_strong_efficiency_8"]["eager_n384_of_3072"] = (t_3072_ms / 8.0) / out["n384"]["ms_per_step"]
     out["note"] = ("full optimisation step (same recipe as `train`) at the per-rank shard of an 8-way strong split, eager and as one HIP graph; "
                    "efficiency = (t_full / 8) / t_shard with t_full = the eager 4096-ray step")
     return out
@@ -764,7 +768,8 @@ def main():
                 res["train_loop"] = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
                 res["train_graph"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS)
                 res["train_graph"]["note"] = "the `train` step (4096 rays) replayed from one HIP graph (GraphedTrainStep)"
-                res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS)
+                res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS,
+                                                           t_3072_ms=res["train_loop"]["step_ms_resident_batch"])
                 if INS_NUM != 59:
                     t9 = train_leg(mc9, mf9, ro, rd, z, a.train_steps, dev, ins_num=59)
                     res["train_ins59"] = {k: t9[k] for k in ("rays_per_s", "ms_per_step", "tflops", "frac_of_mfma_peak", "roofline", "ins_num")}
