@@ -238,15 +238,18 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop_exec / dt / 1e12, "tflops_reference_flops": flop_ref / dt / 1e12,
             "frac_of_mfma_peak": {"executed": flop_exec / dt / 1e12 / (peak * world), "peak": peak,
                                   "note": "whole step incl. losses, compositing, Adam, on the MFMA work the three MLP kernels issue (mac_counts); "
-                                          "`tflops_reference_flops` = the same time against SURVEY 8(d)'s 1013 MFLOP/ray (the head re-association removed work, "
+                                          "`tflops_reference_flops` = the same time against SURVEY 8(d)'s 1013 MFLOP/ray "
+                                          "(the head re-association removed work, "
                                           "so it is not a fraction of any roof)"},
             "final_loss": float(loss.detach()),
             "batch_rays": n, "ins_num": ins_num,
             "roofline": None if worst is None else {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "kernel": worst["kernel"],
                                                     "kernel_ms": worst["kernel_ms"], "achieved": worst["achieved"], "frac": worst["frac"],
                                                     "samples_per_launch": m_fine, "all": kernels,
-                                                    "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; `kernel` = the one furthest below "
-                                                            "the roof on EXECUTED MACs; algorithmic_tflops = the reference's FLOP count of the stage over the same time"},
+                                                    "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; "
+                                                            "`kernel` = the one furthest below "
+                                                            "the roof on EXECUTED MACs; algorithmic_tflops = the reference's FLOP count "
+                                                            "of the stage over the same time"},
             "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"
                     + (f"; one batch sharded over {world} ranks (sharded_train_step)" if world > 1 else "")}
 
@@ -261,8 +264,10 @@ def split_products(mode):
 def split_kernel_names(mode, obi):
     obx = 4 if obi == 3 else obi
     if str(mode) == "f16x2":
-        return {"mlp_fwd_train": f"mlp_f16_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_f16_kernel<{obi}>", "mlp_bwd_weights": "wgrad_f16_kernel + reduce + unfuse"}
-    return {"mlp_fwd_train": f"mlp_split_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_split_kernel<{obi}>", "mlp_bwd_weights": "wgrad_split_kernel + reduce + unfuse"}
+        return {"mlp_fwd_train": f"mlp_f16_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_f16_kernel<{obi}>",
+                "mlp_bwd_weights": "wgrad_f16_kernel + reduce + unfuse"}
+    return {"mlp_fwd_train": f"mlp_split_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_split_kernel<{obi}>",
+            "mlp_bwd_weights": "wgrad_split_kernel + reduce + unfuse"}
 
 
 def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=None):
@@ -377,7 +382,8 @@ def train_loop_leg(mc, mf, dev, steps, mfma_split=False):
     return {"rays_per_s": N / (loop_ms * 1e-3), "batch_rays": N, "loop_ms": loop_ms, "step_ms_resident_batch": step_ms,
             "overhead_ms": loop_ms - step_ms, "overhead_frac": (loop_ms - step_ms) / step_ms, "inline_selection_ms": inline_ms,
             "final_loss": float(loss.detach()), "steps": steps,
-            "note": "shipped N_train=3072: prefetched batch selection (reference numpy stream, side thread, pinned index upload, resident dataset) + full optimisation step"}
+            "note": "shipped N_train=3072: prefetched batch selection (reference numpy stream, side thread, pinned index upload, "
+                    "resident dataset) + full optimisation step"}
 
 
 def frame_leg(mc, mf, K, c2w, dev, mfma_split=False):
@@ -451,7 +457,8 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
     return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"optimisation step on N={n} rays of the same chunk (64+128 samples, perturb=1, penalize on), oracle/ref_cpu + torch autograd + "
                       f"scipy assignment + Adam; median of {reps} after warm-up: {dt:.2f} s (all: {[round(t, 2) for t in ts]}), anomaly detection off",
-            "anomaly_on": {"value": n / dt_on, "seconds": dt_on, "note": "one step with torch.autograd.set_detect_anomaly(True), as the reference ships (dm_nerf.py:5)"},
+            "anomaly_on": {"value": n / dt_on, "seconds": dt_on,
+                           "note": "one step with torch.autograd.set_detect_anomaly(True), as the reference ships (dm_nerf.py:5)"},
             "host": host_info()}
 
 
@@ -499,7 +506,8 @@ def render_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref=None, fuse_heads=False,
 def manipulator_leg(mc, mf, K, dev, steps=3):
     """BASELINE config 5's render: ``manipulator`` (networks/manipulator.py:137-205) on one 4096-ray chunk with T = 1 and T = 2
     moved objects -- per call 1 + T coarse and 1 + T fine network passes of 64 / 192 samples per ray plus 2 T passes on the merged
-    64 + 128 + 128 T depths (T = 1: 1152 network samples per ray = 4.5 x a dm_nerf render), three resamplings with random u (sample_pdf(det=False) even at evaluation), two exchanger
+    64 + 128 + 128 T depths (T = 1: 1152 network samples per ray = 4.5 x a dm_nerf render), three resamplings with random u
+    (sample_pdf(det=False) even at evaluation), two exchanger
     rounds, the final composite.  Rays: the bench camera for the original view; each target view is the same camera
     moved by a rigid transform (what manipulator_demo does with the edited object's pose, :346-371)."""
     quiesce()
@@ -528,7 +536,8 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
         samples = (1 + T) * (2 * S_COARSE + N_IMP) + 2 * T * (S_COARSE + N_IMP + N_IMP * T)   # network evaluations per ray
         mac = mac_counts(INS_NUM)["fwd"]
         out[f"T{T}"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "network_samples_per_ray": samples,
-                        "tflops": 2.0 * mac * samples * N_RAYS / dt / 1e12, "frac_of_f32_mfma_peak": 2.0 * mac * samples * N_RAYS / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        "tflops": 2.0 * mac * samples * N_RAYS / dt / 1e12,
+                        "frac_of_f32_mfma_peak": 2.0 * mac * samples * N_RAYS / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
                         "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all())}
     if HAVE_F16X2:                                       # opt-in (args.mfma_split = "f16x2"), T = 1; not an MFMA-roof fraction: three products per MAC
         args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, target_labels=[1], mfma_split="f16x2")
@@ -544,7 +553,8 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
         out["T1_split_f16x2"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all()),
                                  "note": "opt-in split-f16 network kernels (f32-class, not bitwise the default); not part of the T1 / T2 numbers"}
     out["note"] = ("manipulator() on one 4096-ray chunk, 64 + 128 samples, T moved objects (default f32 kernels); network_samples_per_ray = "
-                   "(1+T)(64+192) + 2T(192+128T) -- the reference re-evaluates the original rays once per target (:190-193); frac = whole call (incl. resampling, exchanger, composites) against the f32 MFMA roof")
+                   "(1+T)(64+192) + 2T(192+128T) -- the reference re-evaluates the original rays once per target (:190-193); "
+                   "frac = whole call (incl. resampling, exchanger, composites) against the f32 MFMA roof")
     return out
 
 
@@ -721,11 +731,13 @@ def main():
             "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / max(a.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,") + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
+            "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,")
+                                   + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
                                    f"{n_step}-ray chunk per step per GPU, det sampling, ins_num={INS_NUM}, random-init weights",
                        "rays_per_step_per_gpu": n_step, "rays_in_timed_region": rays_total,
                        "chunks_per_band": n_chunks, "ragged_chunk_rays": (chunk_rays[-1] if chunk_rays and chunk_rays[-1] != n_step else 0),
-                       "parallelism": f"ray-sharded x{world}" + (f" + one RCCL all-gather of the rank's band per frame ({gathers[0]} in the timed region)" if world > 1 else "")},
+                       "parallelism": f"ray-sharded x{world}" + (
+                           f" + one RCCL all-gather of the rank's band per frame ({gathers[0]} in the timed region)" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,false,false> (fine network, {n_step}x192 samples)", "kernel_ms": k_ms,
@@ -778,8 +790,10 @@ def main():
                                             "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
                 for key, mode in (("train_split_bf16", True),) + ((("train_split_f16x2", "f16x2"),) if HAVE_F16X2 else ()):
                     ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=mode)
-                    res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"], "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
-                                "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the split-operand 16-bit MFMA kernels "
+                    res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
+                                "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
+                                "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the "
+                                        "split-operand 16-bit MFMA kernels "
                                         f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
                     tl = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20), mfma_split=mode)
                     res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
