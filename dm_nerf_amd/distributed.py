@@ -183,7 +183,7 @@ def allreduce_sums(t):
     return t
 
 
-def overlap_enabled(n_local, n_coarse, n_fine, device):
+def overlap_enabled(n_local, n_coarse, n_fine, device, cus=None):
     """Whether the step runs the two levels' network backwards on two streams (autograd.overlapped_backward).
 
     Worth it exactly when it removes a partial round: the data-gradient kernel runs one 128-sample workgroup per CU at a time, so
@@ -194,9 +194,10 @@ def overlap_enabled(n_local, n_coarse, n_fine, device):
     env = os.environ.get("DMNERF_OVERLAP_BWD")
     if env is not None:
         return env != "0"
-    if device.type != "cuda":
-        return False
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if cus is None:
+        if device.type != "cuda":
+            return False
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
     wg_f, wg_c = -(-n_local * n_fine // 128), -(-n_local * n_coarse // 128)
     rounds = lambda w: -(-w // cus)
     return rounds(wg_f) + rounds(wg_c) > rounds(wg_f + wg_c)

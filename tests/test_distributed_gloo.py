@@ -127,6 +127,22 @@ def test_row_bands_partition_the_frame():
     assert D.row_band(480, 3, 8) == (180, 60)            # 60 rows = 38 400 rays per rank
 
 
+def test_two_stream_backward_is_chosen_where_it_removes_a_partial_round(monkeypatch):
+    """distributed.overlap_enabled: 128-sample workgroups on 256 CUs -- the 384-ray shard of an 8-way split is 576 + 192 workgroups
+    (3 + 1 rounds one after the other, 3 side by side); 512, 3072 and 4096 rays are whole rounds either way."""
+    monkeypatch.delenv("DMNERF_OVERLAP_BWD", raising=False)
+    dev = torch.device("cpu")
+    pick = lambda n: D.overlap_enabled(n, 64, 192, dev, cus=256)
+    assert pick(384) and pick(96) and pick(64)
+    assert not pick(131)                                            # 197 + 66 workgroups: 1 + 1 rounds one after the other, 2 side by side
+    assert not pick(512) and not pick(1024) and not pick(3072) and not pick(4096)
+    assert D.overlap_enabled(384, 64, 192, dev) is False             # no GPU: nothing to overlap
+    monkeypatch.setenv("DMNERF_OVERLAP_BWD", "1")
+    assert D.overlap_enabled(4096, 64, 192, dev) is True
+    monkeypatch.setenv("DMNERF_OVERLAP_BWD", "0")
+    assert D.overlap_enabled(384, 64, 192, dev, cus=256) is False
+
+
 def test_single_process_frame_matches_direct_oracle():
     rgb, ins, depth = _frame()
     K, c2w, sd_c, sd_f = _scene()
