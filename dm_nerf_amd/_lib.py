@@ -136,7 +136,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 4:
+    if lib.dmnerf_abi_version() != 5:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

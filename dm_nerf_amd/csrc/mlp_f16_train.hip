@@ -3,7 +3,7 @@
 // 1-bit ReLU masks into the SaveLayout workspace that the backward kernels consume (the f32 ones of mlp_bwd.hip / wgrad.hip as
 // well as their split twins).  The stores and the mask packing ride in the MFMA gaps with the rest of the epilogue (four gaps
 // per element pair); this translation unit is built with -DDMN_STORE_AUX=2 (csrc/Makefile): the 7.8 GB of row stores per fine launch
-// are `nt`, which took the kernel from 2.75 to 2.36 ms.  The forward is the fused-heads function, i.e. exactly the form the re-associated backward
+// are `nt`, which took the kernel from 2.75 to 2.36 ms (docs/EXPERIMENTS.md section 8).  The forward is the fused-heads function, i.e. exactly the form the re-associated backward
 // differentiates; values are f32-class (2e-7 against float64) but not the bitwise fmaf chain of the default path.
 #include "mlp_f16_impl.h"
 

@@ -1,7 +1,7 @@
 // wgrad_split.hip -- OPT-IN weight-gradient kernel on the split-bf16 MFMA path (training with args.mfma_split = True / "bf16x3"):
 // wgrad_split_impl.h's schedule with three planes of packed bf16 pairs (truncation split: exact, split_bf16.h) and six
 // v_mfma_f32_32x32x16_bf16 per 16-sample step of a tile pair (hi hi, hi mid, hi lo, mid hi, mid mid, lo hi): 96 NBA NBB MFMA
-// cycles per 32-sample chunk instead of 256 NBA NBB.  Measured: a 32-sample chunk of a 256 x 256 job
+// cycles per 32-sample chunk instead of 256 NBA NBB.  Measured (docs/EXPERIMENTS.md section 8): a 32-sample chunk of a 256 x 256 job
 // 7 025 -> 4 436 ns (its MFMAs alone: 2 560 ns at 2.4 GHz); the skinny jobs were HBM- / hand-over-bound already and do not move.
 #include "split_bf16.h"
 #include "wgrad_split_impl.h"

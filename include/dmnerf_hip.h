@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 4
+#define DMNERF_ABI_VERSION 5
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -231,7 +231,7 @@ int dmnerf_mlp_fwd_rays_fused(const float* d_blob_fused, int ins_num, const floa
                               const float* d_rays_d, const float* d_z, int64_t N, int S,
                               float* d_raw, void* stream);
 
-/* ---- opt-in split-bf16 ("bf16x3") inference -----------------------------------------
+/* ---- opt-in split-bf16 ("bf16x3") inference (docs/EXPERIMENTS.md section 8) -----------------------------------------
  * The MLP on v_mfma_f32_32x32x16_bf16 with every f32 operand split by truncation into three bf16 planes
  * (x = hi + mid + lo exactly) and the six leading products accumulated in f32: the rounding class of an f32 GEMM
  * at 2.7x fewer MFMA cycles; not the bitwise fmaf chain of dmnerf_mlp_fwd_rays, hence opt-in.  The blob is
