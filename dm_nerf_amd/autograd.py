@@ -477,6 +477,7 @@ class CompositeFunction(torch.autograd.Function):
         _lib.check(lib.dmnerf_composite_fwd(_lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays_d), N, S, C, _lib.ptr(rgb), _lib.ptr(w),
                                             _lib.ptr(depth), _lib.ptr(ins), _lib.stream()), "dmnerf_composite_fwd")
         ctx.save_for_backward(raw, z, rays_d, ins)
+        ctx.set_materialize_grads(False)                 # unused outputs (weights, depth) arrive as None, not as zero-filled tensors
         return rgb, w, depth, ins
 
     @staticmethod
@@ -521,6 +522,7 @@ class CompositePenFunction(torch.autograd.Function):
                                                 _lib.ptr(depth), _lib.ptr(ins), _lib.ptr(part), _lib.stream()), "dmnerf_composite_pen_fwd")
         ctx.save_for_backward(raw, z, rays_d, ins, depth)
         ctx.consts = consts
+        ctx.set_materialize_grads(False)                 # unused outputs (weights, depth, part) arrive as None: no zero fills
         return rgb, w, depth, ins, part
 
     @staticmethod

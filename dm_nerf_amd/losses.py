@@ -79,6 +79,7 @@ class _TrainLosses(torch.autograd.Function):
         total = terms[6]
         out_terms = terms[:6]
         ctx.mark_non_differentiable(out_terms, work)
+        ctx.set_materialize_grads(False)                        # (no zero-filled "gradients" for the two non-differentiable outputs)
         return total, out_terms, work
 
     @staticmethod
@@ -89,6 +90,8 @@ class _TrainLosses(torch.autograd.Function):
         C = ins_num + 1
         dev = rgb_f.device
         N = rgb_f.shape[0]
+        if g_total is None:                                     # the total was not used
+            return (None,) * 16
         g = _lib.f32(g_total.reshape(1))
         d_rgb_f, d_rgb_c = torch.empty_like(rgb_f), torch.empty_like(rgb_c)
         gout = torch.empty(8, dtype=torch.float32, device=dev)
