@@ -29,10 +29,13 @@ class _InsCriterion(torch.autograd.Function):
         ctx.save_for_backward(pred, labels, work)
         ctx.ins_num = ins_num
         ctx.mark_non_differentiable(work)
+        ctx.set_materialize_grads(False)                 # (no zero-filled "gradient" for the work buffer)
         return out, work
 
     @staticmethod
     def backward(ctx, g_out, _g_work=None):
+        if g_out is None:
+            return None, None, None
         pred, labels, work = ctx.saved_tensors
         grad = torch.empty_like(pred)
         g = _lib.f32(g_out)
