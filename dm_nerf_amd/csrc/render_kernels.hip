@@ -160,6 +160,17 @@ __global__ void embed_kernel(const float* __restrict__ x, int64_t M, int L, floa
 // ------------------------------------------------------------------------------------------
 // render_train  (networks/render.py:6-28): one wave per ray
 // ------------------------------------------------------------------------------------------
+// Per-ray LDS rows of the wave-per-ray kernels: dynamic shared memory, `rows` arrays of RAYS_PER_BLOCK rows of row_len(S, C)
+// floats -- sized for the launch's S instead of MAX_S (at S = 192 a block of the fused backward needs 16 KiB instead of 80 KiB:
+// 8 blocks per CU instead of 1; these kernels are latency-bound and live on occupancy).
+__host__ __device__ inline int ray_row_len(int S, int C) {
+    const int need = S > 4 + C ? S : 4 + C;              // (the backward reuses a row for its 4 + C channel coefficients)
+    return (need + 63) & ~63;
+}
+__device__ __forceinline__ float* ray_row(float* base, int k, int wv, int SP) { return base + ((size_t)k * RAYS_PER_BLOCK + wv) * SP; }
+inline size_t ray_lds_bytes(int rows, int S, int C) { return (size_t)rows * RAYS_PER_BLOCK * ray_row_len(S, C) * sizeof(float); }
+constexpr size_t RAY_LDS_MAX = (size_t)4 * RAYS_PER_BLOCK * MAX_S * sizeof(float);      // 80 KiB: four rows at MAX_S
+
 // (one ray = one wave; returns the ray's depth, the same float in every lane)
 __device__ __forceinline__ float composite_ray(
     const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int64_t n, int lane,
@@ -258,11 +269,11 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_kernel(
     const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d, int64_t N,
     int S, int C, int n_ins, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map,
     float* __restrict__ ins_map) {
-    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
+    extern __shared__ float ray_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (n >= N) return;
-    composite_ray(raw, z, rays_d, n, lane, S, C, n_ins, rgb_map, weights, depth_map, ins_map, w_lds[wv]);
+    composite_ray(raw, z, rays_d, n, lane, S, C, n_ins, rgb_map, weights, depth_map, ins_map, ray_row(ray_lds, 0, wv, ray_row_len(S, C)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -287,20 +298,19 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
     const float* __restrict__ ins_map, const float* __restrict__ g_rgb, const float* __restrict__ g_ins,
     const float* __restrict__ g_depth, const float* __restrict__ g_w, int64_t N, int S, int C, float* __restrict__ d_raw,
     const PenBwd pen) {
-    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float t_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float g_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float wm_lds[PEN ? RAYS_PER_BLOCK : 1][PEN ? MAX_S : 1];
+    extern __shared__ float ray_lds[];                     // 3 rows per ray (+ 1 with PEN): w, t, G (, G m_m)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (n >= N) return;
+    const int SP = ray_row_len(S, C);
     const int ch = 4 + C;
     const float* __restrict__ rr = raw + n * (int64_t)S * ch;
     const float* __restrict__ zr = z + n * (int64_t)S;
     float* __restrict__ dr = d_raw + n * (int64_t)S * ch;
-    float* wl = w_lds[wv];
-    float* tl = t_lds[wv];
-    float* gl = g_lds[wv];
+    float* wl = ray_row(ray_lds, 0, wv, SP);
+    float* tl = ray_row(ray_lds, 1, wv, SP);
+    float* gl = ray_row(ray_lds, 2, wv, SP);
+    float* wml = PEN ? ray_row(ray_lds, 3, wv, SP) : nullptr;
     const float dx = rays_d[n * 3 + 0], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
     const float gr0 = g_rgb[n * 3 + 0], gr1 = g_rgb[n * 3 + 1], gr2 = g_rgb[n * 3 + 2];
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
         sc_m = (float)pen.g_part[2];
         lds_sync_wave();
         float* wb = gl;
-        float* wm = wm_lds[wv];
+        float* wm = wml;
         const float dep = pen.depth[n];
         const float d_before = (dep - pen.tol) * nrm, d_after = (dep + pen.tol) * nrm, d_depth = dep * nrm;
         for (int s2 = lane; s2 < S; s2 += WAVE) {
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
                     const float sp = P * (1.f - P);
                     const bool last = c == ch - 1;
                     float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * gl[s] * sc_b;
-                    if (last) g += (sp / q) * wm_lds[wv][s] * sc_m;
+                    if (last) g += (sp / q) * wml[s] * sc_m;
                     v = v + g;
                 }
                 dr[e] = v;
@@ -496,12 +506,12 @@ __device__ __forceinline__ void penalizer_ray(const PenArgs& a, int64_t n, int l
 
 template <int MODE>
 __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void penalizer_kernel(const PenArgs a) {
-    __shared__ float wb_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float wm_lds[RAYS_PER_BLOCK][MAX_S];
+    extern __shared__ float ray_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (n >= a.N) return;
-    penalizer_ray<MODE>(a, n, lane, a.depth[n], wb_lds[wv], wm_lds[wv]);
+    const int SP = ray_row_len(a.S, a.C);
+    penalizer_ray<MODE>(a, n, lane, a.depth[n], ray_row(ray_lds, 0, wv, SP), ray_row(ray_lds, 1, wv, SP));
 }
 
 // render_train + the penalizer's per-ray partial sums in ONE pass over the ray (extension, dmnerf_composite_pen_fwd): the
@@ -509,14 +519,14 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void penalizer_kernel(const P
 // raw[..., 4:] hits the cache lines the first one loaded.
 __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_pen_kernel(
     const PenArgs a, float* __restrict__ rgb_map, float* __restrict__ weights, float* __restrict__ depth_map, float* __restrict__ ins_map) {
-    __shared__ float w_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float wb_lds[RAYS_PER_BLOCK][MAX_S];
-    __shared__ float wm_lds[RAYS_PER_BLOCK][MAX_S];
+    extern __shared__ float ray_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (n >= a.N) return;
-    const float dep = composite_ray(a.raw, a.z, a.rays_d, n, lane, a.S, a.C, a.C - 1, rgb_map, weights, depth_map, ins_map, w_lds[wv]);
-    penalizer_ray<0>(a, n, lane, dep, wb_lds[wv], wm_lds[wv]);
+    const int SP = ray_row_len(a.S, a.C);
+    const float dep = composite_ray(a.raw, a.z, a.rays_d, n, lane, a.S, a.C, a.C - 1, rgb_map, weights, depth_map, ins_map,
+                                    ray_row(ray_lds, 0, wv, SP));
+    penalizer_ray<0>(a, n, lane, dep, ray_row(ray_lds, 1, wv, SP), ray_row(ray_lds, 2, wv, SP));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -728,6 +738,15 @@ __global__ void gather_kernel(const float* __restrict__ flat, const int32_t* __r
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// dynamic LDS of the wave-per-ray kernels may exceed the 64 KiB default at large S: raise the kernel's limit once per device
+template <class K>
+int ray_lds_allow(K kernel, DmnOncePerDevice& once, const char* what) {
+    if (hipError_t e = once.run([&] { return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RAY_LDS_MAX); });
+        e != hipSuccess)
+        return dmn_fail_hip(e, what);
+    return DMNERF_OK;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -789,7 +808,9 @@ extern "C" int dmnerf_composite_fwd(const float* d_raw, const float* d_z, const 
     if (N == 0) return DMNERF_OK;
     if (!d_raw || !d_z || !d_rays_d || !d_rgb_map || !d_weights || !d_depth_map || !d_ins_map)
         return dmn_fail(DMNERF_E_ARG, "composite_fwd: null pointer");
-    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(composite_kernel, once, "composite_fwd: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(1, S, C), (hipStream_t)stream,
                        d_raw, d_z, d_rays_d, N, S, C, C - 1, d_rgb_map, d_weights, d_depth_map, d_ins_map);
     return dmn_check_launch("composite_fwd");
 }
@@ -801,7 +822,9 @@ extern "C" int dmnerf_manipulator_render(const float* d_raw, const float* d_z, c
     if (N == 0) return DMNERF_OK;
     if (!d_raw || !d_z || !d_rays_d || !d_rgb_map || !d_weights || !d_depth_map || !d_ins_map)
         return dmn_fail(DMNERF_E_ARG, "manipulator_render: null pointer");
-    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(composite_kernel, once, "manipulator_render: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(1, S, C), (hipStream_t)stream,
                        d_raw, d_z, d_rays_d, N, S, C, C, d_rgb_map, d_weights, d_depth_map, d_ins_map);
     return dmn_check_launch("manipulator_render");
 }
@@ -852,7 +875,9 @@ extern "C" int dmnerf_composite_bwd(const float* d_raw, const float* d_z, const 
     if (N == 0) return DMNERF_OK;
     if (!d_raw || !d_z || !d_rays_d || !d_ins_map || !d_g_rgb || !d_g_ins || !d_grad_raw)
         return dmn_fail(DMNERF_E_ARG, "composite_bwd: null pointer");
-    hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(composite_bwd_kernel<false>, once, "composite_bwd: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(3, S, C), (hipStream_t)stream,
                        d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw, PenBwd{});
     return dmn_check_launch("composite_bwd");
 }
@@ -867,7 +892,9 @@ extern "C" int dmnerf_composite_pen_fwd(const float* d_raw, const float* d_z, co
     PenArgs a{};
     a.raw = d_raw; a.z = d_z; a.depth = d_depth_map; a.rays_d = d_rays_d; a.N = N; a.S = S; a.C = C;
     a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.out4 = d_partials;
-    hipLaunchKernelGGL(composite_pen_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(composite_pen_kernel, once, "composite_pen_fwd: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(composite_pen_kernel, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(3, S, C), (hipStream_t)stream,
                        a, d_rgb_map, d_weights, d_depth_map, d_ins_map);
     return dmn_check_launch("composite_pen_fwd");
 }
@@ -882,7 +909,9 @@ extern "C" int dmnerf_composite_pen_bwd(const float* d_raw, const float* d_z, co
         return dmn_fail(DMNERF_E_ARG, "composite_pen_bwd: null pointer");
     PenBwd pen{};
     pen.depth = d_depth_map; pen.g_part = d_g_partials; pen.tol = tolerance; pen.k2w = two_deta_w_sq; pen.kh = gauss_norm;
-    hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream,
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(composite_bwd_kernel<true>, once, "composite_pen_bwd: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(4, S, C), (hipStream_t)stream,
                        d_raw, d_z, d_rays_d, d_ins_map, d_g_rgb, d_g_ins, d_g_depth, d_g_weights, N, S, C, d_grad_raw, pen);
     return dmn_check_launch("composite_pen_bwd");
 }
@@ -896,7 +925,9 @@ extern "C" int dmnerf_penalizer_fwd(const float* d_raw, const float* d_z, const 
     PenArgs a{};
     a.raw = d_raw; a.z = d_z; a.depth = d_depth; a.rays_d = d_rays_d; a.N = N; a.S = S; a.C = C;
     a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.out4 = d_partials;
-    hipLaunchKernelGGL(penalizer_kernel<0>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, a);
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(penalizer_kernel<0>, once, "penalizer_fwd: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(penalizer_kernel<0>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(2, S, C), (hipStream_t)stream, a);
     return dmn_check_launch("penalizer_fwd");
 }
 
@@ -909,7 +940,9 @@ extern "C" int dmnerf_penalizer_bwd(const float* d_raw, const float* d_z, const 
     PenArgs a{};
     a.raw = d_raw; a.z = d_z; a.depth = d_depth; a.rays_d = d_rays_d; a.N = N; a.S = S; a.C = C;
     a.tol = tolerance; a.k2w = two_deta_w_sq; a.kh = gauss_norm; a.scales = d_scales; a.d_raw = d_grad_raw;
-    hipLaunchKernelGGL(penalizer_kernel<1>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), 0, (hipStream_t)stream, a);
+    static DmnOncePerDevice once;
+    if (int rc = ray_lds_allow(penalizer_kernel<1>, once, "penalizer_bwd: hipFuncSetAttribute")) return rc;
+    hipLaunchKernelGGL(penalizer_kernel<1>, dim3(blocks_for(N, RAYS_PER_BLOCK)), dim3(WAVE * RAYS_PER_BLOCK), ray_lds_bytes(2, S, C), (hipStream_t)stream, a);
     return dmn_check_launch("penalizer_bwd");
 }
 
