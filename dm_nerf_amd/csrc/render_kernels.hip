@@ -407,27 +407,41 @@ __global__ __launch_bounds__(WAVE* RAYS_PER_BLOCK) void composite_bwd_kernel(
     lds_sync_wave();
     int s = lane / ch, c = lane - s * ch;
     const int ds = WAVE / ch, dc = WAVE - ds * ch;
-    for (int e = lane; e < S * ch; e += WAVE) {
-        if (c != 3) {
-            if (c < 3) {
-                const float sg = sigmoidf_ref(rr[e]);
-                dr[e] = (cl[c] * wl[s]) * ((1.f - sg) * sg);
+    const int total = S * ch;
+    // four trips per iteration: their loads are issued together (one wave per ray: nothing else hides the memory latency)
+    for (int e0 = lane; e0 < total; e0 += 4 * WAVE) {
+        float x[4];
+        int ss[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * WAVE;
+            ss[u] = s; cc[u] = c;
+            const bool need = e < total && (c < 3 || (PEN && c > 3));
+            x[u] = need ? rr[e] : 0.f;
+            s += ds; c += dc;
+            if (c >= ch) { c -= ch; ++s; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * WAVE;
+            if (e >= total || cc[u] == 3) continue;
+            if (cc[u] < 3) {
+                const float sg = sigmoidf_ref(x[u]);
+                dr[e] = (cl[cc[u]] * wl[ss[u]]) * ((1.f - sg) * sg);
             } else {
-                float v = cl[c] * wl[s];
+                float v = cl[cc[u]] * wl[ss[u]];
                 if constexpr (PEN) {                      // + penalizer_kernel<1>'s value for this element (autograd's add, in place)
-                    const float P = sigmoidf_ref(rr[e]);
+                    const float P = sigmoidf_ref(x[u]);
                     const float q = (1.f - P) + 1e-8f;
                     const float sp = P * (1.f - P);
-                    const bool last = c == ch - 1;
-                    float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * gl[s] * sc_b;
-                    if (last) g += (sp / q) * wml[s] * sc_m;
+                    const bool last = cc[u] == ch - 1;
+                    float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * gl[ss[u]] * sc_b;
+                    if (last) g += (sp / q) * wml[ss[u]] * sc_m;
                     v = v + g;
                 }
                 dr[e] = v;
             }
         }
-        s += ds; c += dc;
-        if (c >= ch) { c -= ch; ++s; }
     }
 }
 
@@ -475,25 +489,42 @@ __device__ __forceinline__ void penalizer_ray(const PenArgs& a, int64_t n, int l
     double s_b = 0.0, s_m = 0.0;
     const unsigned total = (unsigned)S * (unsigned)ch;
     float* __restrict__ dr = MODE == 1 ? a.d_raw + n * (int64_t)S * ch : nullptr;
-    for (unsigned e = lane; e < total; e += WAVE) {
-        const unsigned s = e / (unsigned)ch;
-        const int c = (int)(e - s * (unsigned)ch) - 4;
-        if (c < 0) {
-            if (MODE == 1) dr[e] = 0.f;
-            continue;
+    // four trips per iteration, loads first (latency-bound otherwise); elements are visited in the same order as before
+    for (unsigned e0 = lane; e0 < total; e0 += 4 * WAVE) {
+        float x[4];
+        unsigned ss[4];
+        int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned e = e0 + u * WAVE;
+            const unsigned sq = e / (unsigned)ch;
+            ss[u] = sq;
+            cc[u] = (int)(e - sq * (unsigned)ch) - 4;
+            x[u] = (e < total && cc[u] >= 0) ? rr[e] : 0.f;
         }
-        const float P = sigmoidf_ref(rr[e]);
-        const float q = (1.f - P) + 1e-8f;                   // 1 - pred_ins + 1e-8
-        const bool last = c == C - 1;
-        if (MODE == 0) {
-            const float lb = last ? -logf(P + 1e-8f) : -logf(q);
-            s_b += (double)(lb * wb[s]);
-            if (last) s_m += (double)(-logf(q) * wm[s]);
-        } else {
-            const float sp = P * (1.f - P);                  // sigmoid backward
-            float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * wb[s] * sc_b;
-            if (last) g += (sp / q) * wm[s] * sc_m;
-            dr[e] = g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned e = e0 + u * WAVE;
+            if (e >= total) continue;
+            const int c = cc[u];
+            const unsigned s = ss[u];
+            if (c < 0) {
+                if (MODE == 1) dr[e] = 0.f;
+                continue;
+            }
+            const float P = sigmoidf_ref(x[u]);
+            const float q = (1.f - P) + 1e-8f;                   // 1 - pred_ins + 1e-8
+            const bool last = c == C - 1;
+            if (MODE == 0) {
+                const float lb = last ? -logf(P + 1e-8f) : -logf(q);
+                s_b += (double)(lb * wb[s]);
+                if (last) s_m += (double)(-logf(q) * wm[s]);
+            } else {
+                const float sp = P * (1.f - P);                  // sigmoid backward
+                float g = (last ? -(sp / (P + 1e-8f)) : sp / q) * wb[s] * sc_b;
+                if (last) g += (sp / q) * wm[s] * sc_m;
+                dr[e] = g;
+            }
         }
     }
     if (MODE == 0) {
