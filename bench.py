@@ -2,6 +2,7 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --gpus N ...          (no torchrun environment: launches exactly that command itself, see self_launch)
 
 A "step" is one pass of the hot path (``dm_nerf``: coarse MLP -> composite -> resample -> fine MLP ->
 composite) over one 4096-ray chunk of a synthetic 640x480 DM-SR 'study' frame, 64 + 128 samples,
@@ -592,9 +593,44 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
             "host": host_info()}, psnr, n, want
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: launch the N ranks ourselves -- the documented command
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same
+    arguments>`` (one process per GPU over RCCL) -- relay rank 0's JSON line on stdout, everything else on stderr, and return the
+    launcher's exit code.  The torchrun form (WORLD_SIZE set) never comes here."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or a.gpus) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in p.stdout:                                        # relay as it comes: a hung rank must not hide what was printed before
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            sys.stderr.write(out)
+            sys.stderr.flush()
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line if line.endswith("\n") else line + "\n")
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the launched ranks exited 0 but printed no JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     global INS_NUM, MAC_PER_SAMPLE, HAVE_F16X2
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     INS_NUM = a.ins_num
     MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))

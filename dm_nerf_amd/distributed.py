@@ -30,8 +30,9 @@ def init_from_env(backend=None):
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         kw = {"device_id": device} if use_cuda else {}
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kw)
     return rank, world, device
@@ -41,6 +42,25 @@ def world_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+_force = [False]
+
+
+def force_collectives(on=None):
+    """``DMNERF_FORCE_COLLECTIVES=1`` (or ``force_collectives(True)``): issue every collective of this module even in a world of
+    ONE rank, where they are otherwise skipped as no-ops.  A one-GPU box can then drive the exact RCCL calls of the 8-GPU run --
+    the packed all-gather, the 64-B all-reduce, the in-place arena all-reduce, the frame gather -- through the product code with
+    ``init_process_group("nccl", world_size=1, device_id=...)`` and compare against the skipped path bit for bit
+    (tests/test_gpu_rccl.py).  Needs an initialised process group; returns the current setting."""
+    if on is not None:
+        _force[0] = bool(on)
+    return _force[0] or os.environ.get("DMNERF_FORCE_COLLECTIVES") == "1"
+
+
+def _active(world):
+    """Whether collectives are issued: more than one rank, or forced in an initialised world of one."""
+    return world > 1 or (force_collectives() and dist.is_available() and dist.is_initialized())
 
 
 def row_band(H, rank, world):
@@ -58,7 +78,7 @@ def ray_slice(N, rank, world):
 def all_gather_cat(t, sizes=None):
     """Concatenate ``t`` (dim 0) over ranks.  ``sizes``: per-rank dim-0 lengths when they differ."""
     rank, world = world_info()
-    if world == 1:
+    if not _active(world):
         return t
     t = t.contiguous()
 
@@ -95,7 +115,7 @@ def allreduce_grads(models, average=False, arena=None):
     its bucket); one flag per parameter rides in the same message, and a tensor no rank had a gradient for keeps ``grad = None``
     (single-process semantics: the optimizer skips it).  The result is copied back."""
     rank, world = world_info()
-    if world == 1:
+    if not _active(world):
         return 0
     if arena is not None and arena.resident():
         dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM)
@@ -169,7 +189,7 @@ def gather_batch(local, sizes):
     """``[n_local, ...] -> [N, ...]`` on every rank, differentiable w.r.t. the local rows (the small
     per-ray outputs -- rgb ``[N,3]``, ins ``[N,ins_num]`` -- that batch-global losses need: ≈0.2 MB per step)."""
     rank, world = world_info()
-    if world == 1:
+    if not _active(world):
         return local
     return _GatherBatch.apply(local, list(sizes))
 
@@ -178,7 +198,7 @@ def allreduce_sums(t):
     """In-place sum over ranks of a small tensor of batch-global partial sums (the emptiness penalizer's mask
     normalisers, networks/penalizer.py:43,52).  No-op in a single process."""
     rank, world = world_info()
-    if world > 1:
+    if _active(world):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -229,9 +249,10 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     covered on CPU with gloo.  Returns the (global) loss and the number of bytes all-reduced."""
     from .networks import evaluator as E, penalizer as P, render as R
     rank, world = world_info()
+    multi = _active(world)                               # (a forced world of one takes every multi-rank branch below)
     arena = None
     render_is_hip = render is None
-    if render is None and world > 1:                     # HIP path: backward writes both models' gradients into one buffer
+    if render is None and multi:                     # HIP path: backward writes both models' gradients into one buffer
         from . import autograd
         arena = autograd.grad_arena(models)
     N = rays.shape[1]
@@ -260,7 +281,7 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     # arithmetic: the gathered columns are the same floats, and autograd routes each rank the rows of its own slice.
     levels = ("fine", "coarse")
     widths = [out['rgb_' + l].shape[-1] for l in levels] + [out['ins_' + l].shape[-1] for l in levels]
-    if world > 1:
+    if multi:
         packed = gather_batch(torch.cat([out['rgb_' + l] for l in levels] + [out['ins_' + l] for l in levels], -1), sizes)
         rgb_f, rgb_c, ins_f, ins_c = torch.split(packed, widths, -1)
     else:
@@ -272,7 +293,7 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
         if n_ins is not None:
             ins_f, ins_c = ins_f[-n_ins:], ins_c[-n_ins:]
         loss, _ = losses.train_losses(out, local_rays[1], target, labels, ins_num, largs, rgb_ins=(rgb_f, rgb_c, ins_f, ins_c),
-                                      sharded=world > 1)
+                                      sharded=multi)
     else:
         mse = mse or E.img2mse
         criterion = criterion or (lambda pred, gt: E.ins_criterion(pred, gt, ins_num)[0])
@@ -398,7 +419,7 @@ class FrameRenderer:
         if self.band is None:                                      # no model width, no ins_num=, and no chunk rendered yet
             raise RuntimeError("FrameRenderer.gather(): the band was never sized -- render a chunk first or pass ins_num= "
                                "(required when a rank's band can be empty)")
-        if self.world == 1:
+        if not _active(self.world):
             full = self.band
         else:
             full = all_gather_cat(self.band)

@@ -9,7 +9,17 @@ reference's lr decay): STEPS steps x BATCH rays of the analytic scene (oracle/an
 Everything random is drawn from seeds that the GPU test re-creates bit for bit (numpy RandomState for the view / pixel
 selection, a CPU torch Generator for the jitter), so the fixture holds only results: the seven loss terms of every step, and the
 held-out view's PSNR / label purity at steps 0 and EVAL_AT.  Draws are sequential: the first STEPS steps of the long run ARE the
-300-step run of earlier rounds (its losses / PSNR regenerate bit for bit)."""
+300-step run of earlier rounds (its losses / PSNR regenerate bit for bit).
+
+Round 5 -- the oracle's OWN chaos floor (tests/test_gpu_convergence.py compares two samples, HIP runs against oracle runs):
+
+    TRAJ_VARIANT=k TRAJ_THREADS=t python tests/golden/make_train_traj.py   -> tests/golden/train_traj_v{k}.npz
+
+repeats the identical training with the rays of every batch visited in another order (a permutation of the batch rows drawn
+from RandomState(1000 + k); each ray keeps its pixel and its jitter).  Every loss is a mean / sum over the rays of the batch, so
+the run is the same mathematics with the f32 sums -- the loss means, the cost-matrix sums, the K = 98 304-row weight-gradient
+contractions -- taken in another order, which is all that separates two correct f32 implementations.  Only the held-out
+PSNR / purity at EVAL_AT are kept for the variants."""
 import os
 import sys
 import time
@@ -27,14 +37,20 @@ TOL, DW = 0.05, 0.05
 THETAS = list(np.linspace(0.0, 360.0, VIEWS, endpoint=False)) + [17.0]         # the last view is held out
 
 
-def draws(steps=STEPS):
-    """The batch selection and jitter of every step, generated lazily: (view, pixel index [BATCH], t_rand [BATCH,64], u [BATCH,128])."""
+def draws(steps=STEPS, variant=0):
+    """The batch selection and jitter of every step, generated lazily: (view, pixel index [BATCH], t_rand [BATCH,64], u [BATCH,128]).
+    variant k > 0: the same rays with the same jitter, rows permuted (summation-order variant, see the module docstring)."""
     rs = np.random.RandomState(0)
     gen = torch.Generator().manual_seed(0)
+    prs = np.random.RandomState(1000 + variant) if variant else None
     for _ in range(steps):
         v = int(rs.choice(VIEWS))
         idx = torch.from_numpy(rs.choice(H * W, BATCH, replace=False))
-        yield v, idx, torch.rand(BATCH, 64, generator=gen), torch.rand(BATCH, 128, generator=gen)
+        t_rand, u = torch.rand(BATCH, 64, generator=gen), torch.rand(BATCH, 128, generator=gen)
+        if prs is not None:
+            perm = torch.from_numpy(prs.permutation(BATCH))
+            idx, t_rand, u = idx[perm], t_rand[perm].contiguous(), u[perm].contiguous()
+        yield v, idx, t_rand, u
 
 
 def start_weights():
@@ -42,6 +58,7 @@ def start_weights():
 
 
 def main():
+    variant = int(os.environ.get("TRAJ_VARIANT", "0"))
     torch.set_num_threads(max(1, min(16, int(os.environ.get("TRAJ_THREADS", os.cpu_count() or 1)))))
     poses, ims, labs = S.make_views(H, W, THETAS, INS_NUM)
     K = S.dmsr_intrinsics(H, W)
@@ -66,7 +83,7 @@ def main():
     losses = np.zeros((LONG_STEPS, 7), dtype=np.float64)
     evals = [(0, psnr0, pur0)]
     t0 = time.time()
-    for it, (v, idx, t_rand, u) in enumerate(draws(LONG_STEPS), 1):
+    for it, (v, idx, t_rand, u) in enumerate(draws(LONG_STEPS, variant), 1):
         rays = rays_v[v][:, idx]
         tc, ti = ims[v].reshape(-1, 3)[idx], labs[v].reshape(-1)[idx]
         o = O.dm_nerf(rays, sdc, sdf, z, perturb=1.0, t_rand=t_rand, u=u)
@@ -85,6 +102,13 @@ def main():
             evals.append((it,) + evaluate())
             print(f"step {it}: PSNR {evals[-1][1]:.3f} dB, purity {evals[-1][2]:.4f}", flush=True)
     at = {e[0]: e for e in evals}
+    here = os.path.dirname(os.path.abspath(__file__))
+    if variant:
+        np.savez(os.path.join(here, f"train_traj_v{variant}.npz"), eval_steps=np.array([e[0] for e in evals], dtype=np.int64),
+                 eval_psnr=np.array([e[1] for e in evals]), eval_purity=np.array([e[2] for e in evals]),
+                 loss_windows=losses[:, 0].reshape(-1, 20).mean(1), threads=np.int64(torch.get_num_threads()),
+                 config=np.array([INS_NUM, H, W, VIEWS, STEPS, BATCH], dtype=np.int64))
+        return
     np.savez(os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_traj.npz"), losses=losses,
              psnr=np.array([psnr0, at[STEPS][1]]), purity=np.array([pur0, at[STEPS][2]]),
              eval_steps=np.array([e[0] for e in evals], dtype=np.int64), eval_psnr=np.array([e[1] for e in evals]),
