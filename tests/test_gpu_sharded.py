@@ -106,6 +106,23 @@ def _run_bench(world, steps, scaling, train_steps=1, timeout=800):
     return json.loads([l for l in p.stdout.strip().split("\n") if l.startswith("{")][-1])
 
 
+def _run_bench_plain(world, steps, timeout=800):
+    """The PLAIN command ``python bench.py --gpus N ...`` with no torchrun environment (what the driver's BENCH run looks like
+    at N = 1): bench.py launches its own ranks (bench.self_launch) and relays rank 0's line and the exit code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DMNERF_BENCH_ONE_DEVICE="1", DMNERF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "1", "--train-steps", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines          # stdout carries the ONE JSON line, nothing else
+    return json.loads(lines[0])
+
+
 def _check_line(r, world, steps, scaling, rays_expected, gathers):
     assert r["n_gpus"] == world and r["steps"] == steps and r["warmup"] == 1 and r["unit"] == "rays/s" and r["scaling"] == scaling
     per_rank = 4096 if scaling == "weak" else 4096 // world
@@ -133,6 +150,28 @@ def test_bench_multi_rank_code_path_prints_a_valid_line(scaling):
     r = _run_bench(2, 4, scaling)
     per_rank = 4096 if scaling == "weak" else 2048
     _check_line(r, 2, 4, scaling, 2 * per_rank * 4, 1)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("world", [2, 8])
+def test_plain_bench_command_launches_its_own_ranks(world):
+    """``python bench.py --gpus N`` WITHOUT torch.distributed.run around it (the form of the driver's N = 1
+    command) must not die on the world-size check: it re-launches itself under torch.distributed.run and relays the line."""
+    steps = 4 if world == 2 else 10
+    r = _run_bench_plain(world, steps, timeout=1400)
+    _check_line(r, world, steps, "weak", (2 * 4096 * 4) if world == 2 else 480 * 640, 1)
+
+
+def test_plain_bench_command_relays_a_failing_exit_code():
+    """... and a failure of the launched ranks is the launcher's exit code, not a silent 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DMNERF_BENCH_ONE_DEVICE="1", DMNERF_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--scaling", "strong",
+                        "--no-train"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode != 0 and not p.stdout.strip(), (p.returncode, p.stdout[-500:])     # 4096 rays do not split three ways
 
 
 @pytest.mark.timeout(1500)
