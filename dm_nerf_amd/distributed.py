@@ -342,6 +342,17 @@ def _compact_index(sizes, mx, device):
     return _compact_index_cache[key]
 
 
+def _gather_band(band, sizes, world, dev):
+    """The frame from the ranks' packed bands: ONE all-gather of ``band [max(sizes), cols]`` (every rank allocates the largest
+    band's size, so uneven bands gather without a padding copy), then one indexed row copy that drops the padding rows."""
+    if not _active(world):
+        return band
+    full = all_gather_cat(band)
+    if len(set(sizes)) != 1:
+        full = full.index_select(0, _compact_index(sizes, max(sizes), dev))
+    return full
+
+
 class FrameRenderer:
     """One pose, rows sharded over the ranks: the per-pose body of ``render_test`` (networks/tester.py:58-85) as a resumable
     object -- ``step(i)`` renders chunk i of this rank's band into ONE packed band buffer
@@ -352,8 +363,9 @@ class FrameRenderer:
     ``render_frame`` is ``step`` over all chunks + ``gather``; bench.py drives the same object chunk by chunk."""
 
     def __init__(self, H, W, K, c2w, models, near, far, args, chunk=4096, n_samples=64,
-                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None, ins_num=None):
+                 raygen=None, render_chunk=None, z_fn=None, labels_only=False, label_conf=None, ins_num=None, dtype=None):
         self.rank, self.world = world_info()
+        self.dtype = dtype                                         # band dtype (default f32, what every kernel writes)
         self.H, self.W, self.models, self.args, self.chunk = int(H), int(W), models, args, int(chunk)
         self.labels_only = bool(labels_only)
         self.render_chunk = render_chunk or _default_render_chunk
@@ -381,7 +393,7 @@ class FrameRenderer:
         if ins_num is None and models is not None:
             ins_num = getattr(models[-1], "ins_num", None)
         if ins_num is not None:
-            self._alloc_band(int(ins_num), torch.float32)
+            self._alloc_band(int(ins_num), self.dtype or torch.float32)
 
     def _alloc_band(self, n_ins, dtype):
         self.n_ins = n_ins
@@ -397,11 +409,15 @@ class FrameRenderer:
             c_rgb, c_ins, c_depth = self.render_chunk(self.rays_o[s:e], self.rays_d[s:e], z, self.models, self.args, events=events)
         else:
             c_rgb, c_ins, c_depth = self.render_chunk(self.rays_o[s:e], self.rays_d[s:e], z, self.models, self.args)
-        if self.band is None or self.band.dtype != c_rgb.dtype or self.n_ins != c_ins.shape[-1]:
-            if self.band is not None and self.world > 1:           # every rank must gather the same shape: fail before the collective
-                raise RuntimeError(f"FrameRenderer: the chunk renderer returned ins width {c_ins.shape[-1]} / {c_rgb.dtype}, the band "
-                                   f"was sized for {self.n_ins} / {self.band.dtype} (pass ins_num=, or a model with .ins_num)")
-            self._alloc_band(c_ins.shape[-1], c_rgb.dtype)
+        if self.band is None:
+            self._alloc_band(c_ins.shape[-1], self.dtype or c_rgb.dtype)
+        elif self.n_ins != c_ins.shape[-1]:
+            # (a WIDTH the band was not sized for cannot be stored; every rank that renders sees the same renderer and raises the
+            # same error.  A different DTYPE is converted by the assignments below instead -- ranks never disagree on the buffer.)
+            if self.world > 1:
+                raise RuntimeError(f"FrameRenderer: the chunk renderer returned object-code width {c_ins.shape[-1]}, the band was sized "
+                                   f"for {self.n_ins} (pass ins_num= / a model with .ins_num matching the renderer)")
+            self._alloc_band(c_ins.shape[-1], self.dtype or c_rgb.dtype)
         t = self.band[s:e]
         t[:, :3] = c_rgb
         if self.labels_only:
@@ -419,12 +435,7 @@ class FrameRenderer:
         if self.band is None:                                      # no model width, no ins_num=, and no chunk rendered yet
             raise RuntimeError("FrameRenderer.gather(): the band was never sized -- render a chunk first or pass ins_num= "
                                "(required when a rank's band can be empty)")
-        if not _active(self.world):
-            full = self.band
-        else:
-            full = all_gather_cat(self.band)
-            if len(set(self.sizes)) != 1:
-                full = full.index_select(0, _compact_index(self.sizes, max(self.sizes), self.dev))
+        full = _gather_band(self.band, self.sizes, self.world, self.dev)
         rgb, depth = full[:, :3].reshape(H, W, 3), full[:, -1].reshape(H, W)
         if self.labels_only:
             return rgb, full[:, 3].to(torch.int64).reshape(H, W), full[:, 4].reshape(H, W), depth
@@ -482,3 +493,118 @@ def render_path(render_poses, hwk, models, args, gt_imgs=None, crop_mask=None, l
             mse = torch.mean((cols["rgb"][-1] - gt) ** 2)
             cols.setdefault("psnr", []).append(-10.0 * torch.log10(mse))
     return {k: torch.stack(v, 0) for k, v in cols.items()}
+
+
+def _default_manipulate_chunk(ori_rays, tar_rays, models, args, us):
+    from .networks import manipulator as Mn
+    return Mn.manipulator(None, None, models[0], models[1], ori_rays, tar_rays, args, us=us)
+
+
+def _default_draws(n, n_imp, count, device):
+    return [torch.rand([n, n_imp], device=device) for _ in range(count)]
+
+
+class ManipulationFrameRenderer:
+    """One pose of the manipulation render, rows sharded over the ranks: the per-pose body of ``manipulator_eval``
+    (networks/manipulator.py:232-270) -- original rays of ``ori_pose``, target rays of ``trans @ ori_pose``, the chunk loop around
+    ``manipulator()`` (:137-205) and its four O(chunks^2) ``torch.cat`` accumulations -- as a resumable object (BASELINE config 5).
+
+    * rank r owns a contiguous band of image rows and generates the original AND the ``T = len(trans_list)`` target rays of that
+      band itself (raygen kernel, no scatter; the reference evaluates one transformation per call, ``trans_list`` generalises it
+      the way ``manipulator()``'s ``f_tar_rays`` list does);
+    * the chunks are those of the WHOLE frame -- ``[c N_test, (c + 1) N_test)``, ragged last chunk (:241-244) -- and a rank renders
+      the part of each chunk that falls into its band.  ``step(c)`` makes, on EVERY rank, the ``2 + T`` draws
+      ``torch.rand([chunk rays, N_importance])`` that ``manipulator()`` makes for chunk c in a single process (it resamples with
+      ``det=False`` even at evaluation, :148,:170,:187), in the reference's order, and uses the rows of its own part: the device
+      generator advances identically on all ranks, and **the assembled frame is bit-identical whatever the world size**
+      (tests/test_gpu_manipulator_frame.py) -- which a per-rank chunking of the band could not be;
+    * each part's four outputs go into ONE packed band ``[band rays, 2 (3 + C)]`` = ``final_rgb | final_ins | tar_rgb | tar_ins``
+      (C = ins_num + 1: the manipulation render keeps the last object channel, :101-102), and ``gather()`` is ONE all-gather per
+      frame.
+
+    ``manipulate_chunk(ori_rays [2,n,3], tar_rays [T,2,n,3], models, args, us)`` and ``raygen`` / ``draws`` are injectable
+    (CPU / gloo tests of the sharding logic); ``rank=`` / ``world=`` override the process group's view for the band arithmetic
+    (a single process can then render band r of N, without collectives)."""
+
+    def __init__(self, H, W, K, ori_pose, trans_list, models, args, chunk=None, raygen=None, manipulate_chunk=None, draws=None,
+                 ins_num=None, rank=None, world=None, dtype=torch.float32):
+        r_, w_ = world_info()
+        self.rank, self.world = (r_ if rank is None else int(rank)), (w_ if world is None else int(world))
+        self._collective = rank is None and world is None
+        self.H, self.W, self.models = int(H), int(W), models
+        self.chunk = int(chunk if chunk is not None else getattr(args, "N_test", 4096))
+        import copy
+        self.args = copy.copy(args)
+        if not hasattr(self.args, "target_labels"):                 # manipulator.py:229
+            self.args.target_labels = [self.args.target_label]
+        self.n_imp = int(self.args.N_importance)
+        self.manipulate_chunk = manipulate_chunk or _default_manipulate_chunk
+        self.draws = draws or _default_draws
+        raygen = raygen or _default_raygen
+        row0, nrows = row_band(H, self.rank, self.world)
+        pose = torch.as_tensor(ori_pose, dtype=torch.float32)
+        dev_pose = pose.device
+        pose_h = pose.detach().cpu()
+        if pose_h.shape[0] == 3:                                    # [3,4] pose: the homogeneous row the 4 x 4 product needs
+            pose_h = torch.cat([pose_h, torch.tensor([[0., 0., 0., 1.]])], 0)
+        ro, rd = raygen(H, W, K, pose.to(dev_pose), row0, nrows)
+        self.ori = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)])                      # [2, band, 3]
+        tars = []
+        for trans in trans_list:
+            tar_pose = torch.as_tensor(trans, dtype=torch.float32).cpu() @ pose_h           # manipulator.py:235 (f32, on the host)
+            to, td = raygen(H, W, K, tar_pose.to(dev_pose), row0, nrows)
+            tars.append(torch.stack([to.reshape(-1, 3), td.reshape(-1, 3)]))
+        self.T = len(tars)
+        if self.T == 0:
+            raise ValueError("ManipulationFrameRenderer: at least one transformation")
+        self.tar = torch.stack(tars)                                                        # [T, 2, band, 3]
+        self.dev = self.ori.device
+        self.start = row0 * self.W                                                          # first frame ray of this band
+        self.n_local = self.ori.shape[1]
+        self.sizes = [row_band(H, r, self.world)[1] * self.W for r in range(self.world)]
+        self.n_chunks = -(-(self.H * self.W) // self.chunk)
+        if ins_num is None and models is not None:
+            ins_num = getattr(models[-1], "ins_num", None)
+        if ins_num is None:
+            raise ValueError("ManipulationFrameRenderer: pass ins_num= (no model with .ins_num given)")
+        self.C = int(ins_num) + 1
+        self.band = torch.empty(max(max(self.sizes), 1), 2 * (3 + self.C), dtype=dtype, device=self.dev)
+
+    def owned(self, c):
+        """Rows of the band that chunk ``c`` of the frame covers: (first, last + 1) in band coordinates; empty if first >= last."""
+        a = max(c * self.chunk, self.start) - self.start
+        b = min(min((c + 1) * self.chunk, self.H * self.W), self.start + self.n_local) - self.start
+        return a, b
+
+    def step(self, c):
+        """Chunk ``c`` of the frame: the ``2 + T`` draws on every rank, the render of this rank's part of it (if any)."""
+        s = c * self.chunk
+        n = min(self.chunk, self.H * self.W - s)
+        us = self.draws(n, self.n_imp, 2 + self.T, self.dev)
+        a, b = self.owned(c)
+        if b <= a:
+            return None
+        off = self.start + a - s                                    # this part's first row inside the chunk's draws
+        us = [u[off:off + (b - a)].contiguous() for u in us]
+        out = self.manipulate_chunk(self.ori[:, a:b].contiguous(), self.tar[:, :, a:b].contiguous(), self.models, self.args, us)
+        t, C = self.band[a:b], self.C
+        t[:, 0:3], t[:, 3:3 + C], t[:, 3 + C:6 + C], t[:, 6 + C:6 + 2 * C] = out
+        return out
+
+    def gather(self):
+        """ONE all-gather of the packed band -> ``final_rgb [H,W,3], final_ins [H,W,C], tar_rgb [H,W,3], tar_ins [H,W,C]``."""
+        full = _gather_band(self.band, self.sizes, self.world, self.dev) if self._collective else self.band[:self.n_local]
+        rows = self.H if self._collective else self.n_local // self.W
+        C = self.C
+        return (full[:, 0:3].reshape(rows, self.W, 3), full[:, 3:3 + C].reshape(rows, self.W, C),
+                full[:, 3 + C:6 + C].reshape(rows, self.W, 3), full[:, 6 + C:6 + 2 * C].reshape(rows, self.W, C))
+
+
+def manipulate_frame(H, W, K, ori_pose, trans_list, models, args, **kw):
+    """One manipulated pose, rows sharded over the ranks, ONE all-gather (``ManipulationFrameRenderer``): what the chunk loop of
+    ``manipulator_eval`` (networks/manipulator.py:232-270) leaves in ``full_rgb, full_ins, full_tar_rgb, full_tar_ins``, reshaped
+    ``[H, W, .]`` as :273-274 does.  ``args``: N_samples, N_importance, near, far, N_test, target_labels (or target_label)."""
+    fr = ManipulationFrameRenderer(H, W, K, ori_pose, trans_list, models, args, **kw)
+    for c in range(fr.n_chunks):
+        fr.step(c)
+    return fr.gather()

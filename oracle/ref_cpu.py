@@ -477,6 +477,31 @@ def manipulator(sd_coarse, sd_fine, ori_rays, f_tar_rays, N_samples, N_importanc
     return final_rgb, final_ins, tar_rgb, tar_ins_accum
 
 
+def manipulate_frame(sd_coarse, sd_fine, H, W, K, ori_pose, trans, N_test, N_samples, N_importance, near, far, target_labels, us=None):
+    """The per-pose body of ``manipulator_eval`` (networks/manipulator.py:230-274): original rays of ``ori_pose``, target rays of
+    ``trans @ ori_pose`` (:235), the chunk loop of ``N_test`` rays with its ragged last chunk (:241-244) around ``manipulator``
+    (one transformation: ``tar_batch_rays[None]``, :255), the four accumulations (:260-266) and the ``[H, W, .]`` reshape
+    (:271-272).  ``us``: per chunk the ``2 + 1`` draws ``manipulator`` makes.  Returns
+    ``(full_rgb [H,W,3], full_ins [H,W,C], full_tar_rgb [H,W,3], full_tar_ins [H,W,C], tar_pose)``."""
+    ori_pose, trans = torch.as_tensor(ori_pose, dtype=torch.float32), torch.as_tensor(trans, dtype=torch.float32)
+    ro, rd = get_rays_k(H, W, K, ori_pose)
+    ro, rd = torch.reshape(ro, [-1, 3]).float(), torch.reshape(rd, [-1, 3]).float()
+    tar_pose = trans @ ori_pose
+    to, td = get_rays_k(H, W, K, tar_pose)
+    to, td = torch.reshape(to, [-1, 3]).float(), torch.reshape(td, [-1, 3]).float()
+    cols = [[], [], [], []]
+    for c, step in enumerate(range(0, H * W, N_test)):
+        n = min(N_test, H * W - step)
+        ori = torch.stack([ro[step:step + n], rd[step:step + n]], dim=0)
+        tar = torch.stack([to[step:step + n], td[step:step + n]], dim=0)[None, ...]
+        out = manipulator(sd_coarse, sd_fine, ori, tar, N_samples, N_importance, near, far, target_labels,
+                          us=None if us is None else us[c])
+        for col, t in zip(cols, out):
+            col.append(t)
+    full = [torch.cat(col, dim=0) for col in cols]
+    return tuple(t.reshape([H, W, t.shape[-1]]) for t in full) + (tar_pose,)
+
+
 # --------------------------------------------------------------------------------------
 # synthetic scene (SURVEY.md section 8(d)); used by tests and bench
 # --------------------------------------------------------------------------------------

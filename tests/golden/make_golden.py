@@ -662,6 +662,85 @@ def gen_manipulator_stages():
 
 
 
+def gen_manipulator_frame():
+    """ONE pose through the reference's own ``manipulator_eval`` (networks/manipulator.py:208-270), unmodified: the function is
+    CALLED (cwd = the reference, its ``./data/color_dict.json``; image / metric modules stubbed) with ``manipulator`` and
+    ``sample_pdf`` wrapped by recorders, on a small frame (8 x 10 rays, N_test = 32: chunks of 32, 32 and a ragged 16).  With
+    ``gt_rgbs=None`` the function fails AFTER the pose's chunk loop (it reads ``gt_rgbs[i]`` unconditionally, :319) -- everything
+    this fixture needs has been recorded by then: per chunk the original / target ray batches the loop built from
+    ``get_rays_k(ori_pose)`` / ``get_rays_k(trans @ ori_pose)``, the 2 + 1 draws, and the four outputs it accumulates."""
+    import tempfile
+    from unittest.mock import MagicMock
+    for mod in ("imageio", "lpips", "cv2", "skimage", "skimage.metrics", "open3d", "matplotlib", "matplotlib.pyplot",
+                "matplotlib.cm", "h5py", "configargparse", "trimesh"):
+        sys.modules.setdefault(mod, MagicMock())
+    import networks.manipulator as R_mani
+    H_, W_, N_test, ins_num, label = 8, 10, 32, 7, 2
+    sd_c, sd_f = O.make_weights(721, ins_num, **O.PEAKY), O.make_weights(722, ins_num, **O.PEAKY)
+    mc, mf = ref_model(sd_c, ins_num), ref_model(sd_f, ins_num)
+    pe, _ = R_model.get_embedder(10, 0); ve, _ = R_model.get_embedder(4, 0)
+    K = O.dmsr_intrinsics(H_, W_)
+    ori_pose = O.pose_spherical(75.0, -65.0, 7.0)                                    # [4,4]
+    ang = 0.2
+    trans = torch.tensor([[np.cos(ang), -np.sin(ang), 0., 0.3], [np.sin(ang), np.cos(ang), 0., -0.2], [0., 0., 1., 0.1], [0., 0., 0., 1.]],
+                         dtype=torch.float32)
+    calls, pdf_us = [], []
+    orig_m, orig_pdf = R_mani.manipulator, R_mani.sample_pdf
+
+    def w_pdf(bins, weights, N, det=False):
+        st = torch.get_rng_state()
+        r = orig_pdf(bins, weights, N, det)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st); u = torch.rand(list(weights.shape[:-1]) + [N]); torch.set_rng_state(after)
+        pdf_us.append(u)
+        return r
+
+    def w_mani(p, v, c, f, ori_rays, tar_rays, a):
+        k = len(pdf_us)
+        r = orig_m(p, v, c, f, ori_rays, tar_rays, a)
+        calls.append(dict(ori=ori_rays.clone(), tar=tar_rays.clone(), us=pdf_us[k:], out=[t.clone() for t in r]))
+        return r
+
+    a = types.SimpleNamespace(N_samples=64, N_importance=128, near=4.0, far=15.0, target_label=label, N_test=N_test,
+                              datadir="./data/dmsr/study", device="cpu", ins_num=ins_num)
+    R_mani.manipulator, R_mani.sample_pdf = w_mani, w_pdf
+    cwd = os.getcwd()
+    failed_after_loop = None
+    try:
+        os.chdir(REF)
+        with tempfile.TemporaryDirectory() as tmp, torch.no_grad():
+            torch.manual_seed(741)
+            try:
+                R_mani.manipulator_eval(pe, ve, mc, mf, [ori_pose], (H_, W_, K),
+                                        {"transformations": [{"transformation": trans.tolist(), "mode": "golden"}]}, tmp, None, a)
+            except (TypeError, NameError, UnboundLocalError) as e:                   # after the chunk loop, see the docstring
+                failed_after_loop = repr(e)
+    finally:
+        os.chdir(cwd)
+        R_mani.manipulator, R_mani.sample_pdf = orig_m, orig_pdf
+    assert failed_after_loop is not None and len(calls) == 3 and [c["ori"].shape[1] for c in calls] == [32, 32, 16], (failed_after_loop, len(calls))
+    assert a.target_labels == [label] and all(len(c["us"]) == 3 and c["tar"].shape[0] == 1 for c in calls)
+    full = [torch.cat([c["out"][k] for c in calls], 0) for k in range(4)]
+    # the oracle's restatement of the loop reproduces the run bit for bit from the recorded draws
+    with torch.no_grad():
+        ora = O.manipulate_frame(sd_c, sd_f, H_, W_, K, ori_pose, trans, N_test, 64, 128, 4.0, 15.0, [label], us=[c["us"] for c in calls])
+    for a_, b_, n_ in zip(ora[:4], full, ("full_rgb", "full_ins", "full_tar_rgb", "full_tar_ins")):
+        beq(a_.reshape(b_.shape), b_, f"manipulator_eval {n_}")
+    ro, rd = R_helpers.get_rays_k(H_, W_, K, torch.Tensor(ora[4]))
+    beq(torch.cat([c["tar"][0, 0] for c in calls]), ro.reshape(-1, 3), "target origins = get_rays_k(trans @ pose)")
+    beq(torch.cat([c["tar"][0, 1] for c in calls]), rd.reshape(-1, 3), "target directions")
+    out = dict(HWN=np.array([H_, W_, N_test]), K=K, ori_pose=ori_pose, trans=trans, tar_pose=ora[4], seeds=np.array([721, 722]),
+               ins_num=np.int64(ins_num), label=np.int64(label),
+               ori_rays=torch.cat([c["ori"] for c in calls], 1), tar_rays=torch.cat([c["tar"][0] for c in calls], 1),
+               full_rgb=full[0], full_ins=full[1], full_tar_rgb=full[2], full_tar_ins=full[3])
+    for ci, c in enumerate(calls):
+        for ui, u in enumerate(c["us"]):
+            out[f"u{ci}_{ui}"] = u
+    print(f"  manipulator_eval: stopped after the pose's chunk loop with {failed_after_loop}; final labels "
+          f"{np.bincount(full[1].argmax(-1).numpy(), minlength=ins_num + 1).tolist()}")
+    save("manipulator_frame", **out)
+
+
 def gen_select_stream():
     """The host RNG stream of the training loops over several iterations: the three draws of train_dmsr.py:25,
     helpers.py:104 and train_dmsr.py:92 around the reference's own ``get_select_full`` (6 iterations, i_test every 3),
@@ -720,5 +799,6 @@ if __name__ == "__main__":
     gen_scannet_step()
     gen_checkpoint_format()
     gen_manipulator_stages()
+    gen_manipulator_frame()
     gen_select_stream()
     print("all oracle == reference checks passed (bit-exact)")

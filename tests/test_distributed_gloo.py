@@ -378,3 +378,112 @@ def test_wide_worlds_frame_and_training_equal_single_process(world):
         assert D.ray_slice(TN, r, world)[1] in (TN // world, TN // world + 1)
     idx = D._compact_index([D.row_band(5, r, world)[1] * W for r in range(world)], W, "cpu")
     assert idx.numel() == 5 * W and torch.equal(idx, torch.arange(5 * W))   # (ranks 0..4 own one row each, contiguous at the front)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the manipulation render's frame driver (distributed.ManipulationFrameRenderer; networks/manipulator.py:232-270)
+# ---------------------------------------------------------------------------------------------------------------------
+MH, MW, MCHUNK, MINS, MIMP = 10, 12, 32, 5, 8          # 120 rays: chunks of 32, 32, 32 and a ragged 24 that straddle the bands
+
+
+def _mani_scene():
+    K = O.dmsr_intrinsics(MH, MW)
+    pose = O.pose_spherical(75.0, -65.0, 7.0)
+    trans = [torch.tensor([[1., 0., 0., 0.3], [0., 1., 0., -0.2], [0., 0., 1., 0.1], [0., 0., 0., 1.]]),
+             torch.tensor([[0., -1., 0., 0.], [1., 0., 0., 0.5], [0., 0., 1., 0.], [0., 0., 0., 1.]])]
+    sd_c = O.make_weights(31, MINS, W=32, **O.PEAKY)
+    sd_f = O.make_weights(32, MINS, W=32, **O.PEAKY)
+    return K, pose, trans, sd_c, sd_f
+
+
+def _mani_chunk(ori, tars, models, args, us):
+    with torch.no_grad():
+        return O.manipulator(models[0], models[1], ori, list(tars), 8, MIMP, 4.0, 15.0, args.target_labels, us=us)
+
+
+def _mani_chunk_exact(ori, tars, models, args, us):
+    """A stand-in chunk renderer built from single IEEE operations only (bitwise independent of which rows share a call -- the CPU
+    oracle's MKL GEMMs are not: 1 ulp between a 24-row and a 32-row call), touching every input the driver routes: original rays,
+    each target's rays, each of the 2 + T draws."""
+    C = MINS + 1
+    mix = sum(u[:, :3] for u in us)
+    return (ori[0] + ori[1] * us[0][:, :3], us[-1][:, :C] * ori[1][:, :1] + us[1][:, 1:C + 1],
+            tars[-1][0] * mix + tars[-1][1], us[len(tars)][:, :C] - tars[0][1][:, 2:3])
+
+
+def _mani_frame(T, log=None, exact=False, **kw):
+    import types
+    K, pose, trans, sd_c, sd_f = _mani_scene()
+    gen = torch.Generator().manual_seed(77)                 # every rank owns an identically seeded generator, as on the device
+
+    def draws(n, n_imp, count, dev):
+        us = [torch.rand(n, n_imp, generator=gen) for _ in range(count)]
+        if log is not None:
+            log.append((n, count))
+        return us
+    args = types.SimpleNamespace(N_samples=8, N_importance=MIMP, near=4.0, far=15.0, N_test=MCHUNK, target_label=2)
+    return D.manipulate_frame(MH, MW, K, pose, trans[:T], (sd_c, sd_f), args, raygen=_raygen,
+                              manipulate_chunk=_mani_chunk_exact if exact else _mani_chunk, draws=draws, ins_num=MINS, **kw)
+
+
+def _mani_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+        real_gather = dist.all_gather
+        dist.all_gather = lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1]
+        log = []
+        f1 = _mani_frame(1, log)
+        n1 = len(calls)
+        f2 = _mani_frame(2)
+        n2 = len(calls) - n1
+        e1, e2 = _mani_frame(1, exact=True), _mani_frame(2, exact=True)
+        dist.all_gather = real_gather
+        q.put((rank, [t.numpy() for t in f1], [t.numpy() for t in f2], n1, n2, log, [t.numpy() for t in e1], [t.numpy() for t in e2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 7])
+def test_sharded_manipulation_frame_equals_single_process(world):
+    """World 2 (bands of 5 rows = 60 rays: the chunks of 32 straddle the band boundary) and world 7 (bands of 2 / 1 rows, ranks that
+    own a fraction of one chunk): the gathered frame equals the single-process frame -- every rank makes the ``2 + T`` draws of
+    EVERY chunk of the frame in the reference's order and uses its rows -- with ONE collective per frame.  Bit for bit with a chunk
+    renderer that is bitwise row-independent (as the HIP kernels are: tests/test_gpu_manipulator_frame.py); with the CPU oracle's
+    ``manipulator`` as the renderer to 1 ulp (its GEMMs round differently for different row counts) and with identical labels."""
+    torch.set_num_threads(1)
+    want1, want2 = _mani_frame(1), _mani_frame(2)
+    wante1, wante2 = _mani_frame(1, exact=True), _mani_frame(2, exact=True)
+    assert want1[0].shape == (MH, MW, 3) and want1[1].shape == (MH, MW, MINS + 1) and want1[3].shape == (MH, MW, MINS + 1)
+    assert len(np.unique(want1[1].argmax(-1).numpy())) >= 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mani_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, f1, f2, n1, n2, log, e1, e2 in res:
+        assert n1 == 1 and n2 == 1                                                   # ONE all-gather per frame
+        assert log == [(32, 3), (32, 3), (32, 3), (24, 3)]                           # every rank: all four chunks, 2 + T draws each
+        for got, want in zip(e1 + e2, wante1 + wante2):
+            assert np.array_equal(got, want.numpy())
+        for got, want in zip(f1 + f2, want1 + want2):
+            assert np.abs(got - want.numpy()).max() <= 2.5e-7                        # (a misrouted draw or ray moves values by 1e-2 .. 1)
+        for f, w in ((f1, want1), (f2, want2)):
+            assert np.array_equal(f[1].argmax(-1), w[1].argmax(-1).numpy())
+
+
+def test_manipulation_frame_band_override_renders_rows_of_the_frame():
+    """``rank=`` / ``world=``: one process renders band r of N without a process group; its rows are the frame's rows."""
+    whole = _mani_frame(1, exact=True)
+    for world, rank in ((3, 1), (4, 3)):
+        r0, nr = D.row_band(MH, rank, world)
+        part = _mani_frame(1, exact=True, rank=rank, world=world)
+        for got, want in zip(part, whole):
+            assert got.shape[0] == nr and torch.equal(got, want[r0:r0 + nr])

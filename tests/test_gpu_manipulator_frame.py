@@ -1,0 +1,207 @@
+"""GPU tests (-m gpu) of the manipulation render's frame driver (dm_nerf_amd.distributed.ManipulationFrameRenderer /
+manipulate_frame; BASELINE config 5): the per-pose chunk loop of the reference's ``manipulator_eval``
+(networks/manipulator.py:232-270) with the rows sharded over ranks and ONE all-gather per frame.
+
+* the driver's frame == chunk-by-chunk ``manipulator()`` calls with the same draws, bit for bit (T = 1 and 2, ragged last chunk);
+* the frame is bit-identical whatever the world size, INCLUDING the device generator's draws (bands of worlds 2 / 7 / 8 rendered
+  by one process through ``rank=`` / ``world=``, and a real 2-rank run over gloo on the box's one GPU);
+* against the reference's own ``manipulator_eval`` run (tests/golden/manipulator_frame.npz): target pose and rays, the plain target
+  render tightly, the edited outputs as loosely as the whole chain allows (tests/test_gpu_manipulator.py explains why)."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+H, W, CHUNK, INS = 12, 64, 256, 7            # 768 rays: chunks of 256 (x3) -- or CHUNK_R = 160: 160 x 4 + a ragged 128
+CHUNK_R = 160
+
+
+def _mk(seed):
+    from dm_nerf_amd.networks import dm_nerf as M
+    m = M.DM_NeRF(8, 256, 63, 27, [4], INS)
+    m.load_state_dict(O.make_weights(seed, INS, **O.PEAKY))
+    return m.cuda().eval()
+
+
+def _scene():
+    K = O.dmsr_intrinsics(H, W)
+    pose = O.pose_spherical(75.0, -65.0, 7.0)
+    ang = 0.2
+    trans = [torch.tensor([[np.cos(ang), -np.sin(ang), 0., 0.3], [np.sin(ang), np.cos(ang), 0., -0.2], [0., 0., 1., 0.1], [0., 0., 0., 1.]],
+                          dtype=torch.float32),
+             torch.tensor([[1., 0., 0., -0.4], [0., 1., 0., 0.25], [0., 0., 1., 0.], [0., 0., 0., 1.]])]
+    return K, pose, trans
+
+
+def _args(chunk, labels):
+    return types.SimpleNamespace(N_samples=64, N_importance=128, near=4.0, far=15.0, N_test=chunk, target_labels=labels)
+
+
+@pytest.mark.parametrize("T,chunk", [(1, CHUNK), (2, CHUNK_R)])
+def test_frame_driver_equals_chunk_by_chunk_manipulator_calls(T, chunk):
+    from dm_nerf_amd import distributed as D
+    from dm_nerf_amd.networks import helpers as Hh, manipulator as MA
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    K, pose, trans = _scene()
+    mc, mf = _mk(721), _mk(722)
+    a = _args(chunk, [2, 4][:T])
+    n_chunks = -(-H * W // chunk)
+    gen = torch.Generator().manual_seed(5)
+    us = [[torch.rand(min(chunk, H * W - c * chunk), 128, generator=gen).cuda() for _ in range(2 + T)] for c in range(n_chunks)]
+    calls = []
+
+    def draws(n, n_imp, count, dev):
+        c = len(calls)
+        calls.append((n, n_imp, count))
+        return us[c]
+    with torch.no_grad():
+        frame = D.manipulate_frame(H, W, K, pose.cuda(), trans[:T], (mc, mf), a, draws=draws)
+        assert calls == [(min(chunk, H * W - c * chunk), 128, 2 + T) for c in range(n_chunks)]
+        # the loop of manipulator.py:232-270, spelled out on the drop-in functions
+        ro, rd = Hh.get_rays_k(H, W, K, pose.cuda())
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        tr = []
+        for t in trans[:T]:
+            to, td = Hh.get_rays_k(H, W, K, (t @ pose).cuda())
+            tr.append((to.reshape(-1, 3), td.reshape(-1, 3)))
+        cols = [[], [], [], []]
+        for c, s in enumerate(range(0, H * W, chunk)):
+            e = min(s + chunk, H * W)
+            ori = torch.stack([ro[s:e], rd[s:e]])
+            tars = [torch.stack([to[s:e], td[s:e]]) for to, td in tr]
+            for col, t in zip(cols, MA.manipulator(None, None, mc, mf, ori, tars, a, us=us[c])):
+                col.append(t)
+    torch.cuda.synchronize()
+    C = INS + 1
+    for got, col, width in zip(frame, cols, (3, C, 3, C)):
+        want = torch.cat(col, 0).reshape(H, W, width)
+        assert got.shape == want.shape and torch.equal(got, want)
+    assert len(torch.unique(frame[1].argmax(-1))) >= 3 and bool(torch.isfinite(torch.cat([f.reshape(-1) for f in frame])).all())
+
+
+def _whole_and_bands(worlds, seed=11):
+    from dm_nerf_amd import distributed as D
+    K, pose, trans = _scene()
+    mc, mf = _mk(721), _mk(722)
+    a = _args(CHUNK_R, [2])
+    out = {}
+    with torch.no_grad():
+        torch.manual_seed(seed); torch.cuda.manual_seed(seed)
+        out["whole"] = D.manipulate_frame(H, W, K, pose.cuda(), trans[:1], (mc, mf), a)
+        state_after = torch.cuda.get_rng_state()
+        for world in worlds:
+            bands = []
+            for rank in range(world):
+                torch.manual_seed(seed); torch.cuda.manual_seed(seed)       # every rank starts from the same generator state
+                bands.append(D.manipulate_frame(H, W, K, pose.cuda(), trans[:1], (mc, mf), a, rank=rank, world=world))
+                assert torch.equal(torch.cuda.get_rng_state(), state_after)  # ... and leaves it where a single process leaves it
+            out[world] = bands
+    torch.cuda.synchronize()
+    return out
+
+
+def test_frame_is_bit_identical_for_every_world_size_including_the_device_draws():
+    """Default draws (the device generator; ``manipulator`` resamples with det=False at evaluation, manipulator.py:148,170,187):
+    the bands of worlds 2, 7 (uneven: 2 2 2 2 2 1 1 rows) and 8 (ranks owning 1 or 2 rows of 64 rays: fractions of a 160-ray chunk)
+    concatenate to exactly the single-process frame, and every rank's generator ends where the single process's ends."""
+    r = _whole_and_bands((2, 7, 8))
+    for world in (2, 7, 8):
+        for k in range(4):
+            got = torch.cat([b[k] for b in r[world]], 0)
+            assert torch.equal(got, r["whole"][k]), (world, k)
+
+
+def _worker(rank, world, port, q):
+    from dm_nerf_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        K, pose, trans = _scene()
+        mc, mf = _mk(721), _mk(722)
+        calls = []
+        real = dist.all_gather
+        dist.all_gather = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
+        with torch.no_grad():
+            torch.manual_seed(11); torch.cuda.manual_seed(11)
+            frame = D.manipulate_frame(H, W, K, pose.cuda(), trans[:1], (mc, mf), _args(CHUNK_R, [2]))
+        torch.cuda.synchronize()
+        dist.all_gather = real
+        q.put((rank, [t.cpu().numpy() for t in frame], len(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_frame_over_a_real_process_group_equals_single_process():
+    want = _whole_and_bands(())["whole"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, frame, n_coll in res:
+        assert n_coll == 1                                                    # ONE all-gather per frame
+        for got, w in zip(frame, want):
+            assert np.array_equal(got, w.cpu().numpy())
+
+
+def test_against_the_reference_manipulator_eval_run(golden, capsys):
+    """tests/golden/manipulator_frame.npz: ONE pose through the reference's own ``manipulator_eval`` (8 x 10 rays, N_test = 32:
+    32 + 32 + a ragged 16), every chunk's ray batches, draws and outputs recorded."""
+    from dm_nerf_amd import distributed as D
+    from dm_nerf_amd.networks import dm_nerf as M
+    g = golden("manipulator_frame")
+    H_, W_, N_test = [int(v) for v in g["HWN"]]
+    ins_num, label = int(g["ins_num"]), int(g["label"])
+    models = []
+    for seed in g["seeds"]:
+        m = M.DM_NeRF(8, 256, 63, 27, [4], ins_num)
+        m.load_state_dict(O.make_weights(int(seed), ins_num, **O.PEAKY))
+        models.append(m.cuda().eval())
+    n_chunks = -(-H_ * W_ // N_test)
+    us = [[g[f"u{c}_{i}"].cuda() for i in range(3)] for c in range(n_chunks)]
+    k = [0]
+
+    def draws(n, n_imp, count, dev):
+        k[0] += 1
+        assert count == 3 and us[k[0] - 1][0].shape == (n, n_imp)
+        return us[k[0] - 1]
+    a = types.SimpleNamespace(N_samples=64, N_importance=128, near=4.0, far=15.0, N_test=N_test, target_label=label)   # (:229 sets target_labels)
+    fr = D.ManipulationFrameRenderer(H_, W_, g["K"].numpy(), g["ori_pose"].cuda(), [g["trans"]], models, a, draws=draws)
+    assert fr.n_chunks == n_chunks and fr.args.target_labels == [label] and not hasattr(a, "target_labels")
+    with torch.no_grad():
+        for c in range(fr.n_chunks):
+            fr.step(c)
+        frame = [t.cpu() for t in fr.gather()]
+    # rays: origins exact (the translation column of trans @ pose, formed in f32 on the host like the reference), directions to 1 ulp
+    assert torch.equal(fr.ori[0].cpu(), g["ori_rays"][0]) and torch.equal(fr.tar[0, 0].cpu(), g["tar_rays"][0])
+    assert torch.allclose(fr.ori[1].cpu(), g["ori_rays"][1], rtol=3e-7, atol=1e-7)
+    assert torch.allclose(fr.tar[0, 1].cpu(), g["tar_rays"][1], rtol=3e-7, atol=1e-7)
+    n = H_ * W_
+    err = {name: (got.reshape(n, -1) - g[name]).abs().amax(-1) for got, name in zip(frame, ("full_rgb", "full_ins", "full_tar_rgb", "full_tar_ins"))}
+    flips = int((frame[1].reshape(n, -1).argmax(-1) != g["full_ins"].argmax(-1)).sum())
+    with capsys.disabled():
+        print("\n[manipulation frame vs the reference's manipulator_eval] max |d|: " + ", ".join(f"{k_} {float(v.max()):.2e}" for k_, v in err.items())
+              + "; fraction of pixels within 5e-3: " + ", ".join(f"{k_} {float((v <= 5e-3).float().mean()):.3f}" for k_, v in err.items())
+              + f"; label flips {flips} / {n}")
+    assert float(err["full_tar_rgb"].max()) <= 2e-5                           # the plain coarse render of the target view
+    for name in ("full_rgb", "full_ins", "full_tar_ins"):
+        assert float((err[name] <= 5e-3).float().mean()) >= 0.75, (name, err[name].tolist())
+    assert flips <= n // 10

@@ -203,6 +203,27 @@ def test_manipulator_stages(golden):
     close(rgb, g["final_rgb"]); close(ins, g["final_ins"])
 
 
+def test_manipulator_frame(golden):
+    """One pose through the reference's own ``manipulator_eval`` chunk loop (tests/golden/make_golden.py::gen_manipulator_frame):
+    the oracle's restatement of the loop reproduces rays, target pose and the four accumulated outputs from the recorded draws."""
+    g = golden("manipulator_frame")
+    H, W, N_test = [int(v) for v in g["HWN"]]
+    sd_c = O.make_weights(int(g["seeds"][0]), int(g["ins_num"]), **O.PEAKY)
+    sd_f = O.make_weights(int(g["seeds"][1]), int(g["ins_num"]), **O.PEAKY)
+    n_chunks = -(-H * W // N_test)
+    us = [[g[f"u{c}_{i}"] for i in range(3)] for c in range(n_chunks)]
+    with torch.no_grad():
+        out = O.manipulate_frame(sd_c, sd_f, H, W, g["K"].numpy(), g["ori_pose"], g["trans"], N_test, 64, 128, 4.0, 15.0, [int(g["label"])], us=us)
+    assert torch.equal(out[4], g["tar_pose"])
+    ro, rd = O.get_rays_k(H, W, g["K"].numpy(), out[4])
+    assert torch.equal(ro.reshape(-1, 3), g["tar_rays"][0]) and torch.equal(rd.reshape(-1, 3), g["tar_rays"][1])
+    for got, name in zip(out[:4], ("full_rgb", "full_ins", "full_tar_rgb", "full_tar_ins")):
+        want = g[name]
+        assert got.shape == (H, W, want.shape[-1])
+        close(got.reshape(want.shape), want, rtol=1e-5, atol=1e-5)
+    assert int((out[1].reshape(-1, out[1].shape[-1]).argmax(-1) != g["full_ins"].argmax(-1)).sum()) == 0
+
+
 def test_checkpoint_format_matches_the_module():
     """The checkpoint structure the reference writes (train_dmsr.py:78-86; checkpoint_format.json was produced from the
     reference's own DM_NeRF + Adam) against the drop-in module's state_dict -- no GPU needed for key names and shapes."""
