@@ -17,7 +17,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 its own per-kernel roofline and CPU baseline), `train_loop` (the shipped N_train = 3072 loop incl. batch selection),
 `render_fused_heads`, `render_split_bf16`, `frame_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes),
 `render_ins59` / `train_ins59` (BASELINE config 3: Replica-width object head), `manipulator` (BASELINE config 5: the
-manipulation render of networks/manipulator.py:137-205, T = 1 and 2 moved objects), `train_shard_proxy` (the full step at the
+manipulation render of networks/manipulator.py:137-205, T = 1 and 2 moved objects), `manipulator_frame` (the same as a whole
+640x480 pose through the sharded frame driver, manipulator_eval's chunk loop :232-270; at N > 1 across the ranks), `train_shard_proxy` (the full step at the
 384 / 512 rays one of 8 ranks sees under strong scaling: what a one-GPU box can say about the 8-GPU run).
 """
 import argparse
@@ -559,6 +560,59 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
     return out
 
 
+def manipulator_frame_leg(mc, mf, K, dev, world=1):
+    """BASELINE config 5's manipulation render as a FRAME: one whole 640 x 480 pose through the product's sharded frame driver
+    (distributed.manipulate_frame = the per-pose chunk loop of manipulator_eval, networks/manipulator.py:232-270; T = 1 as the
+    reference evaluates it), 75 chunks of N_test = 4096 rays, target view = ``trans @ pose``, the 2 + T draws per chunk from the
+    device generator, ONE all-gather of the packed band per frame at N > 1.  At N = 1 also the time of ONE band of an 8-way split
+    (``rank=0, world=8``: 38 400 rays) -- what one of 8 GPUs would take for its share of the same frame."""
+    quiesce()
+    from dm_nerf_amd import distributed as D
+    from dm_nerf_amd.synthetic import pose_spherical
+    pose = pose_spherical(30.0, -65.0, 7.0)
+    ang = 0.15
+    trans = torch.tensor([[np.cos(ang), -np.sin(ang), 0., 0.3], [np.sin(ang), np.cos(ang), 0., -0.2], [0., 0., 1., 0.1], [0., 0., 0., 1.]],
+                         dtype=torch.float32)
+    args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, N_test=N_RAYS, target_label=1)
+    T = 1
+    samples = (1 + T) * (2 * S_COARSE + N_IMP) + 2 * T * (S_COARSE + N_IMP + N_IMP * T)
+    mac = mac_counts(INS_NUM)["fwd"]
+
+    def timed(**kw):
+        torch.manual_seed(0); torch.cuda.manual_seed(0)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            frame = D.manipulate_frame(H_IMG, W_IMG, K, pose.to(dev), [trans], (mc, mf), args, **kw)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, frame
+    with torch.no_grad():                                      # warm-up: the first rows of the frame as one chunk
+        D.manipulate_frame(8, W_IMG, K, pose.to(dev), [trans], (mc, mf), args, rank=0, world=1)
+    dt, frame = timed()
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    n = H_IMG * W_IMG
+    out = {"rays_per_s": n / dt, "s_per_frame": dt, "n_gpus": world, "T": T, "chunks": -(-n // N_RAYS), "network_samples_per_ray": samples,
+           "tflops": 2.0 * mac * samples * n / dt / 1e12,
+           "frac_of_f32_mfma_peak": 2.0 * mac * samples * n / dt / 1e12 / (F32_MFMA_PEAK_TFLOPS * world),
+           "finite": bool(all(torch.isfinite(t).all() for t in frame)), "labels_in_frame": int(len(torch.unique(frame[1].argmax(-1)))),
+           "note": "one whole 640x480 pose through distributed.manipulate_frame (manipulator_eval's chunk loop: 75 x 4096 rays, T = 1, "
+                   "default f32 kernels); the whole frame incl. raygen of both views, resampling, exchanger, composites and the band "
+                   "gather against the f32 MFMA roof of the GPUs used"}
+    if world == 1:
+        dt8, _ = timed(rank=0, world=8)
+        out["band_of_8"] = {"rays": n // 8, "s": dt8, "predicted_8gpu_rays_per_s": n / dt8, "predicted_efficiency_before_gather": dt / 8 / dt8}
+    return out
+
+
 def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
     """the oracle (CPU port of the reference path) on this host's cores, the SAME 4096-ray chunk the GPU
     rendered last (64+128 samples, det): median of up to 3 timed renders after a warm-up.  On a slow host the repetitions,
@@ -746,6 +800,13 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             train_multi = {"error": f"{type(e).__name__}: {e}"}
 
+    mani_multi = None
+    if world > 1 and not a.no_extras:
+        try:                                                    # BASELINE config 5's render across the ranks (never `value`)
+            mani_multi = manipulator_frame_leg(mc, mf, K, dev, world=world)
+        except Exception as e:                                  # noqa: BLE001
+            mani_multi = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         if world == 1:
             # the full 10-key dict of the chunk the timed loop rendered last (the frame driver keeps rgb / ins / depth only):
@@ -801,6 +862,7 @@ def main():
                 res["render_split_f16x2"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
                 res["frame_split_f16x2"] = frame_leg(mc, mf, K, c2w, dev, mfma_split="f16x2")
             res["manipulator"] = manipulator_leg(mc, mf, K, dev)
+            res["manipulator_frame"] = manipulator_frame_leg(mc, mf, K, dev)
             if INS_NUM != 59:                           # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
                 pe9, ve9, mc9, mf9 = build_models(dev, 59)
                 res["render_ins59"] = render_leg(pe9, ve9, mc9, mf9, ro, rd, z, a.steps, ins_num=59)
@@ -836,6 +898,8 @@ def main():
                     res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
         if train_multi is not None:
             res["train"] = train_multi
+        if mani_multi is not None:
+            res["manipulator_frame"] = mani_multi
         t = res.get("train")
         if isinstance(t, dict) and "error" not in t:            # top-level scalars: the training claim in the driver's parsed record
             res["train_ms_per_step"] = t["ms_per_step"]

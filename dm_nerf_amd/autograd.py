@@ -46,6 +46,9 @@ def f16_check_enabled(args=None):
     return os.environ.get("DMNERF_CHECK_F16", "0") == "1"
 
 
+PROBE_SAMPLES = 262144              # f16x2_probe: samples per piece (a 2.6 GB scratch workspace)
+
+
 def _f16_flags_word(device):
     key = str(device)
     if key not in _f16_flags:
@@ -81,16 +84,21 @@ def check_f16x2(device=None, reset=True, warn=True):
 
 
 def f16x2_probe(model, rays_o, rays_d, z):
-    """Inference with the check on: the same launch through the training forward (which SAVES what it converts) into a scratch
-    workspace, scanned for saturation.  Doubles the cost of the call -- a diagnostic."""
+    """Inference with the check on: the same rays through the training forward (which SAVES what it converts) into a scratch
+    workspace, scanned for saturation.  Doubles the cost of the call -- a diagnostic.  Runs in pieces of at most
+    MAX_TRAIN_SAMPLES // S rays (the training forward's launch limit; one piece's workspace is ~2466 floats per sample), so an
+    inference chunk of any size can be probed."""
     lib = _lib.load()
     N, S = z.shape
-    M = N * S
-    raw = torch.empty(N, S, 4 + model.ins_num + 1, dtype=torch.float32, device=z.device)
-    save = torch.empty(lib.dmnerf_train_save_floats(M), dtype=torch.float32, device=z.device)
-    _lib.check(lib.dmnerf_mlp_fwd_rays_train_f16(_lib.ptr(model.blob_f16()), model.ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
-                                                 N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train_f16")
-    _f16_range_scan(save, M, False)
+    step = max(1, min(N, MAX_TRAIN_SAMPLES // S, max(1, PROBE_SAMPLES // S)))
+    raw = torch.empty(step, S, 4 + model.ins_num + 1, dtype=torch.float32, device=z.device)
+    save = torch.empty(lib.dmnerf_train_save_floats(step * S), dtype=torch.float32, device=z.device)
+    for s0 in range(0, N, step):
+        n = min(step, N - s0)
+        _lib.check(lib.dmnerf_mlp_fwd_rays_train_f16(_lib.ptr(model.blob_f16()), model.ins_num, _lib.ptr(rays_o[s0:s0 + n]),
+                                                     _lib.ptr(rays_d[s0:s0 + n]), _lib.ptr(z[s0:s0 + n]), n, S, _lib.ptr(raw), _lib.ptr(save),
+                                                     _lib.stream()), "dmnerf_mlp_fwd_rays_train_f16")
+        _f16_range_scan(save, n * S, False)
 
 
 class _timed:
@@ -289,7 +297,8 @@ class MLPRaysFunction(torch.autograd.Function):
         with _timed("mlp_fwd_train", M):
             _lib.check(fn(_lib.ptr(fwd_blob), ins_num, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z),
                           N, S, _lib.ptr(raw), _lib.ptr(save), _lib.stream()), "dmnerf_mlp_fwd_rays_train")
-        if mode == "f16" and f16_check_enabled():
+        ctx.check_f16 = mode == "f16" and (_check_f16_call[0] if _check_f16_call[0] is not None else f16_check_enabled())
+        if ctx.check_f16:
             _f16_range_scan(save, M, False)
         ctx.model, ctx.M, ctx.save = model, M, save
         ctx.blob, ctx.flat = blob, model.flat()                                   # the weights this forward used
@@ -321,6 +330,7 @@ class _Overlap:
     active = False
     streams = {}
     pending = None          # (done event, [tensors the side-stream kernels read that the main stream's allocator must not reuse yet])
+    seen = set()            # ids of the models that already had a network backward in this pass (see _mlp_backward)
 
 
 class overlapped_backward:
@@ -346,11 +356,13 @@ class overlapped_backward:
     def __enter__(self):
         self.prev = _Overlap.active
         _Overlap.active = self.enabled
+        _Overlap.seen = set()
         return self
 
     def __exit__(self, *exc):
         _join_side()
         _Overlap.active = self.prev
+        _Overlap.seen = set()
         return False
 
 
@@ -365,8 +377,18 @@ def _join_side():
 
 def _mlp_backward(ctx, g_raw):
     """dgrad + wgrad of one saved forward (rays or pre-embedded rows): the parameter gradients as views of one flat vector.
-    Inside ``overlapped_backward`` the first call of a pass runs on the side stream (see there)."""
-    if (_Overlap.active and _Overlap.pending is None and ctx.M > 0 and g_raw.is_cuda
+    Inside ``overlapped_backward`` the first call of a pass runs on the side stream (see there).
+
+    Only the FIRST backward launch of a model in a pass may go to the side stream.  A model whose batch exceeds
+    MAX_TRAIN_SAMPLES runs as several launches F3, F2, F1 (autograd calls them last chunk first); ``p.grad`` stays ``None`` until
+    all of them have returned (AccumulateGrad waits for every input), so "gradients are None and nothing is pending" also holds
+    at F1 -- after F3 went to the side stream and F2 joined it -- and F1 on the side stream would let the engine's input buffer
+    add its output to (F3 + F2) on the main stream while the weight-gradient kernel is still writing it.  Hence the
+    per-pass set of models already seen: their later launches stay on the main stream, after a join."""
+    first_of_model = id(ctx.model) not in _Overlap.seen
+    if _Overlap.active:
+        _Overlap.seen.add(id(ctx.model))
+    if (_Overlap.active and _Overlap.pending is None and first_of_model and ctx.M > 0 and g_raw.is_cuda
             and all(p.grad is None for p in ctx.model.parameters())):
         dev = g_raw.device
         side = _Overlap.streams.get(dev.index)
@@ -412,7 +434,7 @@ def _mlp_backward_on_stream(ctx, g_raw):
             _lib.check(lib.dmnerf_grad_scale(_lib.ptr(g), g.numel(), _lib.ptr(scale), _lib.stream()), "dmnerf_grad_scale")
             _lib.check(lib.dmnerf_mlp_bwd_data_f16(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
                                                    _lib.ptr(dsave), _lib.ptr(gt), _lib.ptr(scale), _lib.stream()), "dmnerf_mlp_bwd_data_f16")
-            if f16_check_enabled():
+            if getattr(ctx, "check_f16", None) if getattr(ctx, "check_f16", None) is not None else f16_check_enabled():
                 _f16_range_scan(dsave, M, True)
         elif split:
             _lib.check(lib.dmnerf_mlp_bwd_data_split(_lib.ptr(ctx.blob_ts), ins_num, _lib.ptr(ctx.save), _lib.ptr(g), M,
@@ -583,13 +605,25 @@ def _params(model):
     return [p for _, p in model.named_parameters()]
 
 
-def run_network_train(model, rays_o, rays_d, z, fused=False, split=None):
+_check_f16_call = [None]            # run_network_train(check_f16=): the caller's args.check_f16 for the launches of this call
+
+
+def run_network_train(model, rays_o, rays_d, z, fused=False, split=None, check_f16=None):
     """Differentiable (w.r.t. the parameters) fused points + encoding + MLP.  Opt-in variants: ``fused`` (``args.fuse_heads``)
     runs the FORWARD on the fused-heads blob (-19 % MACs; values equal up to f32 re-association, not bit-equal to the inference
     default; default f32 backward); ``split`` (``weights.split_mode(args)``: "bf16x3" | "f16x2") runs forward, data gradients and
     weight gradients on the split-operand 16-bit MFMA kernels (fused heads + six bf16 / three f16 products per f32 product:
-    f32-class values)."""
+    f32-class values).  ``check_f16`` (``f16_check_enabled(args)``): scan what the f16x2 forward AND the
+    backward of these launches convert for saturation (None: the module flag / DMNERF_CHECK_F16)."""
     mode = {"bf16x3": "split", "f16x2": "f16", True: "split"}[split] if split else ("fused" if fused else None)
+    _check_f16_call[0] = None if check_f16 is None else bool(check_f16)
+    try:
+        return _run_network_train(model, rays_o, rays_d, z, mode)
+    finally:
+        _check_f16_call[0] = None
+
+
+def _run_network_train(model, rays_o, rays_d, z, mode):
     if not model._fused_ok():                              # another network shape: layer by layer, its own autograd Function
         from . import generic
         return generic.run_network(model, rays_o, rays_d, z, train=True)
@@ -650,6 +684,7 @@ def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=No
     z_coarse = helpers.stratify(z_in, t_rand) if t_rand is not None else z_in
     from . import weights
     fused, split = bool(getattr(args, "fuse_heads", False)), weights.split_mode(args)
+    chk = f16_check_enabled(args) if split == "f16x2" else None     # args.check_f16 reaches the training-side scans too
     consts = pen_consts(args)                           # the step penalises: composite + penalizer partial sums in one pass
 
     def composite(raw, z):
@@ -659,14 +694,14 @@ def dm_nerf_train(rays, model_coarse, model_fine, z_vals_coarse, args, t_rand=No
         rgb, w, depth, ins, part = CompositePenFunction.apply(raw, z, rays_d, consts)
         depth._dmn_pen = (part, raw.data_ptr(), z.data_ptr(), rays_d.data_ptr(), consts)       # see pen_partials
         return rgb, w, depth, ins
-    raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse, fused, split)
+    raw_coarse = run_network_train(model_coarse, rays_o, rays_d, z_coarse, fused, split, check_f16=chk)
     rgb_coarse, weights_coarse, depth_coarse, ins_coarse = composite(raw_coarse, z_coarse)
     with torch.no_grad():                              # z_samples.detach()  (render.py:68)
         if n_imp == 0:                                 # sample_pdf returns [N, 0]: the fine depths are the coarse ones
             z_fine = z_coarse.clone()
         else:
             z_fine = helpers.importance_resample(z_coarse, weights_coarse.detach(), n_imp, det=(perturb == 0.), u=u)
-    raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine, fused, split)
+    raw_fine = run_network_train(model_fine, rays_o, rays_d, z_fine, fused, split, check_f16=chk)
     rgb_fine, weights_fine, depth_fine, ins_fine = composite(raw_fine, z_fine)
     if getattr(args, "is_train", False) and getattr(args, "N_ins", None) is not None:
         ins_fine = ins_fine[-args.N_ins:]

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1024) void loss_tail_fwd_kernel(const TailArgs a) {
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    float total = 0.f;
+    float crit2[2] = {0.f, 0.f}, pen2[2] = {0.f, 0.f};
     for (int lvl = 0; lvl < 2; ++lvl) {
         float pen = 0.f;
         if (a.pen_sums4[lvl]) {                                    // penalizer.py:43-55 (same arithmetic as penalizer_finish_kernel)
@@ -70,10 +70,17 @@ __global__ __launch_bounds__(1024) void loss_tail_fwd_kernel(const TailArgs a) {
         a.terms8[3 * lvl + 0] = s_mse[lvl];
         a.terms8[3 * lvl + 1] = crit;
         a.terms8[3 * lvl + 2] = pen;
-        total = total + s_mse[lvl];                                // train_dmsr.py:38-58: the order the loop adds the terms
-        if (a.crit_out4[lvl]) total = total + crit;
-        if (a.pen_sums4[lvl]) total = total + pen;
+        crit2[lvl] = crit;
+        pen2[lvl] = pen;
     }
+    // The reference's association order (train_dmsr.py:47-58; level a = fine, b = coarse):
+    //   ins_loss = ins_fine + ins_coarse; rgb_loss = rgb_fine + rgb_coarse; total = ins_loss + rgb_loss;
+    //   [penalize] total = total + (emptiness_fine + emptiness_coarse)
+    // (each term is this library's f32 value -- the squared error is summed in double here, an f32 tree in ATen -- so the total is
+    // the reference's up to the rounding of the terms, not bit for bit)
+    float total = s_mse[0] + s_mse[1];
+    if (a.crit_out4[0] || a.crit_out4[1]) total = (crit2[0] + crit2[1]) + total;
+    if (a.pen_sums4[0] || a.pen_sums4[1]) total = total + (pen2[0] + pen2[1]);
     a.terms8[6] = total;
     a.terms8[7] = 0.f;
 }

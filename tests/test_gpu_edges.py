@@ -406,3 +406,82 @@ def test_f16x2_saturation_is_reported_when_the_check_is_on(A, monkeypatch):
     o = R.dm_nerf(rays, None, None, small_c, small_f, z, targs)
     (o['rgb_fine'].sum() + o['rgb_coarse'].sum()).backward()
     assert G.check_f16x2(warn=False) == 0                                      # inside the range (ragged M too): no false alarm
+
+
+def test_overlapped_backward_with_three_launches_per_model_sends_only_the_first_to_the_side_stream(monkeypatch):
+    """a model whose batch runs as THREE chunk launches inside ``overlapped_backward`` -- F3 on the side
+    stream, F2 on the main stream (joins), and F1, which sees ``p.grad is None`` and nothing pending again, must NOT take the side
+    stream (the engine would add its output to F3 + F2 on the main stream unsynchronised).  With the launch limit lowered to
+    4096 samples a 150-ray x 64-sample batch is 3 launches per model; two models as in a training step.  The gradients equal the
+    one-stream pass bit for bit, over several repetitions, and the side stream is taken exactly once per model-pass that may."""
+    from dm_nerf_amd import autograd as G
+    from dm_nerf_amd.networks import dm_nerf as M
+    torch.manual_seed(5)
+    ins_num, N, S = 13, 150, 64
+    ms = [M.DM_NeRF(8, 256, 63, 27, [4], ins_num).cuda().train() for _ in range(2)]
+    g = torch.Generator(device="cuda").manual_seed(6)
+    ro, rd = torch.randn(N, 3, device="cuda", generator=g), torch.randn(N, 3, device="cuda", generator=g)
+    z = torch.sort(torch.rand(N, S, device="cuda", generator=g) * 5 + 1, -1)[0]
+    cot = torch.randn(N, S, 4 + ins_num + 1, device="cuda", generator=g)
+    monkeypatch.setattr(G, "MAX_TRAIN_SAMPLES", 4096)
+    side_calls = []
+    real = G._mlp_backward_on_stream
+
+    def spy(ctx, g_raw):
+        side_calls.append(torch.cuda.current_stream() != torch.cuda.default_stream())
+        return real(ctx, g_raw)
+    monkeypatch.setattr(G, "_mlp_backward_on_stream", spy)
+
+    def run(overlap):
+        for m in ms:
+            for p in m.parameters():
+                p.grad = None
+        loss = sum((G.run_network_train(m, ro, rd, z) * cot).sum() for m in ms)
+        with G.overlapped_backward(overlap):
+            loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for m in ms for p in m.parameters()]
+
+    want = run(False)
+    assert side_calls == [False] * 6
+    for _ in range(5):
+        del side_calls[:]
+        got = run(True)
+        assert len(side_calls) == 6 and sum(side_calls) == 2, side_calls           # one side-stream launch per model, never its 2nd / 3rd
+        assert side_calls[0] and not side_calls[1] and not side_calls[2]
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
+def test_f16x2_check_via_args_reaches_training_and_the_probe_runs_in_pieces(A, monkeypatch):
+    """(1) ``args.check_f16`` alone -- no env var, no module flag -- switches the TRAINING-side scans on (forward's
+    saved activations, backward's scaled gradients); (2) the inference probe runs in pieces of at most PROBE_SAMPLES samples with one
+    reused workspace, so an inference chunk larger than the training launch limit is probed instead of raising."""
+    import types
+    import warnings
+    from dm_nerf_amd import autograd as G
+    from dm_nerf_amd.networks import render as R
+    ins_num, N = 13, 48
+    K = O.dmsr_intrinsics(480, 640)
+    ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(20.0, -65.0, 7.0))
+    rays = torch.stack([ro.reshape(-1, 3)[5000:5000 + N], rd.reshape(-1, 3)[5000:5000 + N]]).cuda()
+    z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous().cuda()
+    assert G.CHECK_F16 is None and not G.f16_check_enabled()
+    big_c, big_f = model_from(A, O.make_weights(21, ins_num, gain=8.0), ins_num).train(), model_from(A, O.make_weights(22, ins_num, gain=8.0), ins_num).train()
+    for chk, expect in ((True, True), (None, False)):
+        targs = types.SimpleNamespace(perturb=0.0, N_importance=128, is_train=True, N_ins=None, mfma_split="f16x2", check_f16=chk)
+        o = R.dm_nerf(rays, None, None, big_c, big_f, z, targs)
+        (o['rgb_fine'].sum() + o['rgb_coarse'].sum()).backward()
+        assert bool(G.check_f16x2(warn=False) & G.F16_ACT_SATURATED) == expect
+    # the probe in pieces: 48 rays x 192 samples with room for 1000 samples per piece -> 5 rays per launch, ragged last piece
+    monkeypatch.setattr(G, "PROBE_SAMPLES", 1000)
+    calls = []
+    real = G._f16_range_scan
+    monkeypatch.setattr(G, "_f16_range_scan", lambda ws, M, g: (calls.append(M), real(ws, M, g))[1])
+    args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, mfma_split="f16x2", check_f16=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            R.dm_nerf(rays, None, None, big_c.eval(), big_f.eval(), z, args)
+    assert [x for x in w if "65504" in str(x.message)]
+    assert calls == [15 * 64] * 3 + [3 * 64] + [5 * 192] * 9 + [3 * 192], calls

@@ -1,6 +1,6 @@
 """The training step's loss tail as one autograd node (dm_nerf_amd/losses.py, csrc/losses.hip; extension) against the drop-in
 functions the reference's loop calls one by one (train_dmsr.py:33-61: img2mse, ins_criterion, ins_penalizer on both levels):
-same total, same six terms, and the SAME gradients for everything the tail touches -- rgb, ins and raw of both levels --
+the same total to f32 rounding (the tail adds the terms in the association order of train_dmsr.py:47-58), the same six terms, and the SAME gradients for everything the tail touches -- rgb, ins and raw of both levels --
 bit for bit (same criterion / penalizer kernels, the squared-error gradient formed with autograd's own products)."""
 import types
 
