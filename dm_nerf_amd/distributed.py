@@ -495,6 +495,19 @@ def render_path(render_poses, hwk, models, args, gt_imgs=None, crop_mask=None, l
     return {k: torch.stack(v, 0) for k, v in cols.items()}
 
 
+def _matmul4_f32(a, b):
+    """``a @ b`` for two 4 x 4 f32 matrices with a FIXED evaluation order: products and sums rounded to f32 one at a time,
+    k = 0..3 in sequence.  The reference forms ``trans @ ori_pose`` with ``torch.matmul`` on the host (manipulator.py:235), whose
+    BLAS kernel -- and with it the last bit of the result -- depends on the CPU model; this one gives the same target pose on
+    every host (within 1 ulp per entry of whatever the reference's host computes)."""
+    import numpy as np
+    a, b = a.numpy().astype(np.float32), b.numpy().astype(np.float32)
+    out = np.zeros((4, 4), dtype=np.float32)
+    for k in range(4):
+        out = (out + (a[:, k:k + 1] * b[k:k + 1, :]).astype(np.float32)).astype(np.float32)
+    return torch.from_numpy(out)
+
+
 def _default_manipulate_chunk(ori_rays, tar_rays, models, args, us):
     from .networks import manipulator as Mn
     return Mn.manipulator(None, None, models[0], models[1], ori_rays, tar_rays, args, us=us)
@@ -551,7 +564,7 @@ class ManipulationFrameRenderer:
         self.ori = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)])                      # [2, band, 3]
         tars = []
         for trans in trans_list:
-            tar_pose = torch.as_tensor(trans, dtype=torch.float32).cpu() @ pose_h           # manipulator.py:235 (f32, on the host)
+            tar_pose = _matmul4_f32(torch.as_tensor(trans, dtype=torch.float32).cpu(), pose_h)   # manipulator.py:235
             to, td = raygen(H, W, K, tar_pose.to(dev_pose), row0, nrows)
             tars.append(torch.stack([to.reshape(-1, 3), td.reshape(-1, 3)]))
         self.T = len(tars)

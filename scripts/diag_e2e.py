@@ -5,15 +5,16 @@ import numpy as np, torch
 from oracle import ref_cpu as O
 from dm_nerf_amd.networks import dm_nerf as M, render as R
 
-ins_num, N = 13, 48
+ins_num, N = 13, int(sys.argv[1]) if len(sys.argv) > 1 else 48
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 sd_c = O.make_weights(31, ins_num, gain=1.7, sigma_bias=0.3)
 sd_f = O.make_weights(32, ins_num, gain=1.7, sigma_bias=0.3)
 K = O.dmsr_intrinsics(480, 640)
 ro, rd = O.get_rays_k(480, 640, K, O.pose_spherical(25.0, -65.0, 7.0))
-sel = torch.from_numpy(np.random.RandomState(3).choice(480 * 640, N, replace=False))
+sel = torch.from_numpy(np.random.RandomState(SEED).choice(480 * 640, N, replace=False))
 rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
 z = O.z_val_sample(N, 4.0, 15.0, 64).contiguous()
-g = torch.Generator().manual_seed(33)
+g = torch.Generator().manual_seed(30 + SEED)
 t_rand, u = torch.rand(N, 64, generator=g), torch.rand(N, 128, generator=g)
 C = ins_num + 1
 cts = [torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, ins_num, generator=g),
@@ -36,6 +37,7 @@ def oracle(dt):
     return sdc, sdf
 c32, f32_ = oracle(torch.float32)
 c64, f64_ = oracle(torch.float64)
+ratios, eh, eo = [], [], []
 for name, m, o32, o64 in (("coarse", mc, c32, c64), ("fine", mf, f32_, f64_)):
     for k, p in m.named_parameters():
         t = o64[k].grad
@@ -43,3 +45,12 @@ for name, m, o32, o64 in (("coarse", mc, c32, c64), ("fine", mf, f32_, f64_)):
         e_hip = float((p.grad.cpu().double() - t).abs().max())
         e_o32 = float((o32[k].grad.double() - t).abs().max())
         print(f"{name:6s} {k:32s} scale {s:.2e}  hip-vs-f64 {e_hip / s:.2e}  oracle32-vs-f64 {e_o32 / s:.2e}")
+        l_hip = float((p.grad.cpu().double() - t).norm() / (t.norm() + 1e-300))
+        l_o32 = float((o32[k].grad.double() - t).norm() / (t.norm() + 1e-300))
+        if s > 0:
+            ratios.append((e_hip / max(e_o32, 1e-300), l_hip / max(l_o32, 1e-300), name, k)); eh.append((e_hip / s, l_hip)); eo.append((e_o32 / s, l_o32))
+r = np.array([[a, b] for a, b, _, _ in ratios])
+eh, eo = np.array(eh), np.array(eo)
+print(f"N={N} seed={SEED}: tensors {len(r)}; max-err ratio hip/o32: median {np.median(r[:,0]):.2f} max {r[:,0].max():.2f} (at {ratios[int(r[:,0].argmax())][2:]}); "
+      f"l2-err ratio: median {np.median(r[:,1]):.2f} max {r[:,1].max():.2f}; sum max-err hip {eh[:,0].sum():.3e} o32 {eo[:,0].sum():.3e}; "
+      f"sum l2 hip {eh[:,1].sum():.3e} o32 {eo[:,1].sum():.3e}; worst hip max-err {eh[:,0].max():.2e}, worst o32 {eo[:,0].max():.2e}")

@@ -71,7 +71,7 @@ def test_frame_driver_equals_chunk_by_chunk_manipulator_calls(T, chunk):
         ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
         tr = []
         for t in trans[:T]:
-            to, td = Hh.get_rays_k(H, W, K, (t @ pose).cuda())
+            to, td = Hh.get_rays_k(H, W, K, D._matmul4_f32(t, pose).cuda())
             tr.append((to.reshape(-1, 3), td.reshape(-1, 3)))
         cols = [[], [], [], []]
         for c, s in enumerate(range(0, H * W, chunk)):
@@ -190,8 +190,10 @@ def test_against_the_reference_manipulator_eval_run(golden, capsys):
         for c in range(fr.n_chunks):
             fr.step(c)
         frame = [t.cpu() for t in fr.gather()]
-    # rays: origins exact (the translation column of trans @ pose, formed in f32 on the host like the reference), directions to 1 ulp
-    assert torch.equal(fr.ori[0].cpu(), g["ori_rays"][0]) and torch.equal(fr.tar[0, 0].cpu(), g["tar_rays"][0])
+    # rays: original origins exact; the target pose is a 4 x 4 f32 product formed on the host -- the reference's torch.matmul rounds
+    # it as its host's BLAS does (the fixture's host is not this one), the driver in a fixed order: equal to 1 ulp per entry
+    assert torch.equal(fr.ori[0].cpu(), g["ori_rays"][0])
+    assert torch.allclose(fr.tar[0, 0].cpu(), g["tar_rays"][0], rtol=3e-7, atol=1e-7)
     assert torch.allclose(fr.ori[1].cpu(), g["ori_rays"][1], rtol=3e-7, atol=1e-7)
     assert torch.allclose(fr.tar[0, 1].cpu(), g["tar_rays"][1], rtol=3e-7, atol=1e-7)
     n = H_ * W_

@@ -127,7 +127,7 @@ def _loss_from(out, cts):
             + (out['raw_coarse'][..., 4:] * cts[5]).sum())
 
 
-def test_dm_nerf_training_grads_vs_oracle(A):
+def test_dm_nerf_training_grads_vs_oracle(A, capsys):
     ins_num, N = 13, 48
     sd_c = O.make_weights(31, ins_num, gain=1.7, sigma_bias=0.3)
     sd_f = O.make_weights(32, ins_num, gain=1.7, sigma_bias=0.3)
@@ -153,16 +153,35 @@ def test_dm_nerf_training_grads_vs_oracle(A):
     _loss_from(want, cts).backward()
     for k in ('rgb_fine', 'rgb_coarse', 'ins_fine', 'ins_coarse', 'depth_fine', 'raw_coarse'):
         tclose(out[k], want[k], k, rel=2e-5)
-    # 3072 + 9216 samples x 2048 relu units: a handful of units sit within float noise of zero and flip
-    # their mask between the two f32 implementations (scripts/diag_e2e.py: HIP and the f32 oracle are
-    # equally far, ~1e-2, from an f64 run for that reason), so whole-tensor norms are compared here; the
-    # strict per-element check is test_mlp_backward_vs_autograd / test_composite_backward_vs_autograd.
-    for m_, sd_, tag in ((mc, sdc, "coarse"), (mf, sdf, "fine")):
+    # The f64 REFEREE.  48 rays x (64 + 192) samples push ~10^7 ReLU units through the backward; a unit
+    # within float noise of zero takes a different side in f32 than in exact arithmetic, so ANY f32 implementation -- the
+    # reference's included -- sits ~1e-2 of a tensor's scale away from the f64 gradient.  The claim that can be tested is
+    # therefore relative: the HIP gradient is as close to the f64 gradient as the f32 oracle (= the reference's arithmetic) is,
+    #     err(HIP, f64) <= 1.5 x err(oracle f32, f64) + 3e-7 x scale        per parameter tensor, max norm and l2 norm
+    # (the floor is f32 rounding of the tensors whose error is at that level).  Observed: the two error columns agree to three
+    # digits on 55 of 60 tensors (the f32 forward is the same fmaf chain, so both take the same side of every ReLU).
+    sdc64 = {k: v.double().clone().requires_grad_(True) for k, v in sd_c.items()}
+    sdf64 = {k: v.double().clone().requires_grad_(True) for k, v in sd_f.items()}
+    want64 = O.dm_nerf(rays.double(), sdc64, sdf64, z.double(), perturb=1.0, t_rand=t_rand.double(), u=u.double(),
+                       z_fine_override=out['z_vals_fine'].detach().cpu().double())
+    _loss_from(want64, [c.double() for c in cts]).backward()
+    table = []
+    for m_, sd32, sd64, tag in ((mc, sdc, sdc64, "coarse"), (mf, sdf, sdf64, "fine")):
         for k, p in m_.named_parameters():
-            got, want = p.grad.cpu().double(), sd_[k].grad.double()
-            rel_l2 = float((got - want).norm() / (want.norm() + 1e-30))
-            rel_max = float((got - want).abs().max() / (want.abs().max() + 1e-30))
-            assert rel_l2 <= 2e-3 and rel_max <= 1e-2, (tag, k, rel_l2, rel_max)
+            truth = sd64[k].grad
+            scale, nrm = float(truth.abs().max()), float(truth.norm())
+            d_hip, d_o32 = p.grad.cpu().double() - truth, sd32[k].grad.double() - truth
+            e = (float(d_hip.abs().max()), float(d_o32.abs().max()), float(d_hip.norm()), float(d_o32.norm()))
+            table.append((tag, k, scale, e[0] / scale, e[1] / scale, e[2] / nrm, e[3] / nrm))
+            assert e[0] <= 1.5 * e[1] + 3e-7 * scale, (tag, k, e, scale)
+            assert e[2] <= 1.5 * e[3] + 3e-7 * nrm, (tag, k, e, nrm)
+    with capsys.disabled():
+        print("\n[f64 referee, 48 rays] per tensor: |HIP - f64| and |oracle f32 - f64|, max norm / scale  (l2 / l2)")
+        for tag, k, scale, a_, b_, c_, d_ in table:
+            print(f"  {tag:6s} {k:30s} scale {scale:.2e}   HIP {a_:.2e}  oracle-f32 {b_:.2e}   ({c_:.2e}  {d_:.2e})")
+        worst = max(table, key=lambda t: t[3])
+        print(f"  worst HIP column entry {worst[3]:.2e} at {worst[0]}.{worst[1]} (oracle f32 there: {worst[4]:.2e}); "
+              f"sum of the HIP column {sum(t[3] for t in table):.4e}, of the oracle-f32 column {sum(t[4] for t in table):.4e}")
     # the fine-level loss gives the coarse model nothing beyond its own terms: zero the coarse cotangents
     mc.zero_grad(); mf.zero_grad()
     out = A.R.dm_nerf(rays.cuda(), None, None, mc, mf, z.cuda(), args, t_rand=t_rand.cuda(), u=u.cuda())
