@@ -154,7 +154,7 @@ def train_flop_per_ray(ins_num=None):
     return 2.0 * (m["reference_fwd"] + m["reference_wgrad"] + m["reference_dgrad"]) * (2 * S_COARSE + N_IMP)
 
 
-def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, mfma_split=False, ins_num=None):
+def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, mfma_split=False, ins_num=None, flat_adam=False):
     """Secondary measurement: rays/s of one full optimisation step on ONE batch of ``n`` rays (default 4096 per GPU;
     64+128 samples, perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
     levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
@@ -172,7 +172,11 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
     ins_num = INS_NUM if ins_num is None else ins_num
     mc.train(); mf.train()
     params = list(mc.parameters()) + list(mf.parameters())
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    if flat_adam:                                       # extension (dm_nerf_amd.optim.FlatAdam): update + re-pack as two launches
+        from dm_nerf_amd.optim import FlatAdam
+        opt = FlatAdam((mc, mf), lr=5e-4, betas=(0.9, 0.999))
+    else:                                               # the reference's optimizer (train_dmsr.py:124-125)
+        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
     args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
                                  fuse_heads=fuse_heads, mfma_split=mfma_split)
     n = N_RAYS * world if n is None else n
@@ -272,7 +276,7 @@ def split_kernel_names(mode, obi):
             "mlp_bwd_weights": "wgrad_split_kernel + reduce + unfuse"}
 
 
-def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=None):
+def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=None, flat_adam=False):
     """The same optimisation step as `train_leg` replayed from ONE HIP graph (dm_nerf_amd.graphed.GraphedTrainStep: forward,
     losses, every backward kernel, Adam, weight re-packing in a single launch; bit-equal to the eager step,
     tests/test_gpu_driver.py) on a batch of ``n`` rays: ms per step and the eager figure next to it."""
@@ -280,7 +284,11 @@ def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=
     from dm_nerf_amd.graphed import GraphedTrainStep
     ins_num = INS_NUM if ins_num is None else ins_num
     mc.train(); mf.train()
-    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=torch.tensor(5e-4, device=dev), betas=(0.9, 0.999), capturable=True)
+    if flat_adam:
+        from dm_nerf_amd.optim import FlatAdam
+        opt = FlatAdam((mc, mf), lr=5e-4, betas=(0.9, 0.999), capturable=True)
+    else:
+        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=torch.tensor(5e-4, device=dev), betas=(0.9, 0.999), capturable=True)
     args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
                                  mfma_split=mfma_split)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -311,7 +319,10 @@ def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full, t_3072_ms=
     for n in (384, 512):
         r = train_leg(mc, mf, ro, rd, z, steps, dev, n=n)
         gr = graph_train_leg(mc, mf, ro, rd, z, steps, dev, n)
+        rf = train_leg(mc, mf, ro, rd, z, steps, dev, n=n, flat_adam=True)
+        gf = graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, flat_adam=True)
         out[f"n{n}"] = {"ms_per_step": r["ms_per_step"], "rays_per_s": r["rays_per_s"], "graph_ms_per_step": gr["ms_per_step"],
+                        "flat_adam_ms_per_step": rf["ms_per_step"], "flat_adam_graph_ms_per_step": gf["ms_per_step"],
                         "kernel_ms": {k["kernel"].split("<")[0].split(" ")[0]: k["kernel_ms"] for k in (r["roofline"] or {}).get("all", [])}}
     out["full_batch_rays"] = n_full
     out["full_batch_ms"] = t_full_ms
@@ -321,8 +332,12 @@ def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full, t_3072_ms=
     if t_3072_ms:                                            # the shipped N_train: 3072 rays over 8 ranks = 384 each
         out["full_3072_ms"] = t_3072_ms
         out["predicted_strong_efficiency_8"]["eager_n384_of_3072"] = (t_3072_ms / 8.0) / out["n384"]["ms_per_step"]
+        best = min(out["n384"][k] for k in ("ms_per_step", "graph_ms_per_step", "flat_adam_ms_per_step", "flat_adam_graph_ms_per_step"))
+        out["predicted_strong_efficiency_8"]["best_n384_of_3072"] = (t_3072_ms / 8.0) / best
     out["note"] = ("full optimisation step (same recipe as `train`) at the per-rank shard of an 8-way strong split, eager and as one HIP graph; "
-                   "efficiency = (t_full / 8) / t_shard with t_full = the eager 4096-ray step")
+                   "flat_adam_* = the same step with the extension optimizer dm_nerf_amd.optim.FlatAdam (torch.optim.Adam's update + the weight "
+                   "re-packing as two launches) instead of the reference's torch.optim.Adam; "
+                   "efficiency = (t_full / 8) / t_shard with t_full = the eager step with torch.optim.Adam")
     return out
 
 

@@ -31,8 +31,18 @@ class RenderArgs(ctypes.Structure):
     ]
 
 
+class RepackModel(ctypes.Structure):
+    """``dmnerf_repack_model`` (include/dmnerf_hip.h)."""
+    _fields_ = [("d_params_flat", c_vp), ("ins_num", c_int), ("d_flat_copy", c_vp), ("d_idx", c_vp), ("d_blob", c_vp),
+                ("d_idx_t", c_vp), ("d_blob_t", c_vp)]
+
+
+c_double = ctypes.c_double
+
 # name -> (restype, argtypes); exactly the symbols include/dmnerf_hip.h declares
 SIGNATURES = {
+    "dmnerf_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_double, c_vp, c_double, c_double, c_double, c_vp, c_vp]),
+    "dmnerf_repack_train": (c_int, [ctypes.POINTER(RepackModel), c_int, c_vp]),
     "dmnerf_abi_version": (c_int, []),
     "dmnerf_last_error": (ctypes.c_char_p, []),
     "dmnerf_device_count": (c_int, []),
@@ -136,7 +146,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 5:
+    if lib.dmnerf_abi_version() != 6:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -252,7 +252,7 @@ def sharded_train_step(rays, z_vals, target, labels, models, args, optimizer, in
     multi = _active(world)                               # (a forced world of one takes every multi-rank branch below)
     arena = None
     render_is_hip = render is None
-    if render is None and multi:                     # HIP path: backward writes both models' gradients into one buffer
+    if render is None and (multi or getattr(optimizer, "wants_arena", False)):                     # HIP path: backward writes both models' gradients into one buffer
         from . import autograd
         arena = autograd.grad_arena(models)
     N = rays.shape[1]

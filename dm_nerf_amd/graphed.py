@@ -32,6 +32,7 @@ class GraphedTrainStep:
         for grp in optimizer.param_groups:
             if not (grp.get("capturable", False) or grp.get("fused", False)):
                 raise ValueError("GraphedTrainStep: build the optimizer with capturable=True (or fused=True)")
+        own = hasattr(optimizer, "use_persistent_buffers")          # dm_nerf_amd.optim.FlatAdam: snapshot / restore / in-place re-pack
         self.models, self.opt, self.args, self.ins_num = models, optimizer, args, ins_num
         self.rays, self.z = rays.detach().clone(), z_vals.detach().clone()
         self.target, self.labels = target.detach().clone(), labels.detach().clone()
@@ -40,8 +41,11 @@ class GraphedTrainStep:
         params = [p for m in models for p in m.parameters()]
         saved_p = [p.detach().clone() for p in params]
         opt_params = [p for grp in optimizer.param_groups for p in grp["params"]]
-        fresh = all(len(optimizer.state[p]) == 0 for p in opt_params)       # a new optimizer: its state starts at zero
-        saved_s = None if fresh else self._snapshot_opt()
+        if own:
+            saved_s = optimizer.snapshot()
+        else:
+            fresh = all(len(optimizer.state[p]) == 0 for p in opt_params)   # a new optimizer: its state starts at zero
+            saved_s = None if fresh else self._snapshot_opt()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -52,9 +56,14 @@ class GraphedTrainStep:
             with torch.no_grad():
                 for p, s in zip(params, saved_p):
                     p.copy_(s)
-            self._restore_opt(saved_s)
-            for m in models:
-                m.invalidate_blobs()
+            if own:
+                optimizer.restore(saved_s)
+                optimizer.use_persistent_buffers()                  # the captured forward reads what the captured re-pack writes
+                optimizer.repack()
+            else:
+                self._restore_opt(saved_s)
+                for m in models:
+                    m.invalidate_blobs()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -89,11 +98,17 @@ class GraphedTrainStep:
         # kernel-layout caches are keyed on (networks/dm_nerf.py ``blob``): forget them, so that an eager render between replays
         # (the periodic test render of train_dmsr.py:88-100) re-packs from the CURRENT parameters instead of reusing the copy
         # an earlier evaluation packed.  (The graph itself is unaffected: it re-packs into its own buffers on every replay.)
-        for m in self.models:
-            m.invalidate_blobs()
+        if hasattr(self.opt, "use_persistent_buffers"):
+            for m, out, size, (nb, _) in zip(self.opt.models, self.opt._persist, self.opt.sizes, self.opt._n_blob):
+                m.install_packed(out[:size], out[size:size + nb], out[size + nb:])      # what this replay's re-pack just wrote
+        else:
+            for m in self.models:
+                m.invalidate_blobs()
         return self.loss
 
     def set_lr(self, lr):
+        if hasattr(self.opt, "set_lr"):
+            return self.opt.set_lr(lr)
         for grp in self.opt.param_groups:
             if torch.is_tensor(grp["lr"]):
                 grp["lr"].fill_(float(lr))

@@ -107,6 +107,16 @@ class DM_NeRF(nn.Module):
         self._blob_key = self._blob_t_key = self._flat_key = None
         self._blob_f_key = self._blob_s_key = self._blob_ts_key = self._blob_h_key = self._blob_th_key = None
 
+    def install_packed(self, flat, blob, blob_t):
+        """Adopt kernel-layout copies made elsewhere from the CURRENT parameters (dm_nerf_amd.optim.FlatAdam re-packs all of them
+        in the launch that follows its update, csrc/optim.hip::repack_kernel): ``flat()``, ``blob()`` and ``blob_t()`` return them
+        until a parameter changes again.  The opt-in layouts (fused / split) are forgotten: an update THROUGH the flat storage
+        does not bump ``_version``, their keys could not tell."""
+        key = tuple((p.data_ptr(), p._version) for _, p in self.named_parameters())
+        self._flat, self._blob, self._blob_t = flat, blob, blob_t
+        self._flat_key = self._blob_key = self._blob_t_key = key
+        self._blob_f_key = self._blob_s_key = self._blob_ts_key = self._blob_h_key = self._blob_th_key = None
+
     def flat(self):
         """The parameters as ONE flat f32 vector in state_dict order (what the packers gather from and what the backward's
         head kernels read, csrc/heads.hip); a NEW tensor whenever a parameter changed, so a pending backward keeps the

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 5
+#define DMNERF_ABI_VERSION 6
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -466,6 +466,37 @@ int dmnerf_colsum(const float* d_X, int64_t ldx, int64_t M, int J, float* d_out,
 int dmnerf_ray_points(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, float* d_pts,
                       float* d_dirs, void* stream);
 int dmnerf_copy_cols(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, void* stream);
+
+/* ---- EXTENSION: the optimizer update and the weight re-packing of a training step as two launches (csrc/optim.hip).
+ * The reference steps torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr, betas=(0.9, 0.999))
+ * (train_dmsr.py:124-125) after total_loss.backward() (:62-64); the drop-in path keeps exactly that.  These two entries are what
+ * dm_nerf_amd.optim.FlatAdam runs instead when a caller opts in: at small per-rank batches the ~9 multi-tensor launches of the
+ * torch optimizer and the 8 pack / cat launches after it are a measurable part of the step.
+ *   dmnerf_adam_step: ONE pass over flat f32 vectors of n elements -- parameters, gradients (the gradient arena the
+ *     weight-gradient kernels wrote), first and second moments -- applying torch.optim.Adam's update (amsgrad off, no weight
+ *     decay) operation for operation, each rounded to f32 on its own, scalar factors formed in double:
+ *       m <- m + (1-b1)(g - m);  v <- v b2;  v <- v + (1-b2)(g g);  p <- p + (-(lr / (1 - b1^t))) (m / (sqrt(v) / sqrt(1 - b2^t) + eps))
+ *     t = d_state2[0] + 1 is read on the device and stored back by the last workgroup to finish (d_state2[1] is its ticket
+ *     counter; both start at 0): no host synchronisation, HIP-graph capturable.  d_lr (nullable): a device f32 scalar that
+ *     overrides lr (a captured graph changes the learning rate by writing it).
+ *   dmnerf_repack_train: for up to DMNERF_REPACK_MAX_MODELS models in one launch, from each model's (updated) flat parameter
+ *     vector: d_flat_copy (nullable; dmnerf_param_count floats, must not alias the source), the forward blob (what
+ *     dmnerf_pack_weights gathers with dmnerf_build_pack_index) and the W^T blob (dmnerf_build_pack_index_t over
+ *     [parameters | F], F = A . rgb_feature_linear.weight formed inline with dmnerf_head_product's fmaf chain): bit-identical to
+ *     dmnerf_head_product + two dmnerf_pack_weights calls.                                                                  */
+#define DMNERF_REPACK_MAX_MODELS 4
+typedef struct dmnerf_repack_model {
+    const float* d_params_flat;
+    int ins_num;
+    float* d_flat_copy;
+    const int32_t* d_idx;
+    float* d_blob;
+    const int32_t* d_idx_t;
+    float* d_blob_t;
+} dmnerf_repack_model;
+int dmnerf_adam_step(float* d_params, const float* d_grads, float* d_exp_avg, float* d_exp_avg_sq, int64_t n,
+                     double lr, const float* d_lr, double beta1, double beta2, double eps, int64_t* d_state2, void* stream);
+int dmnerf_repack_train(const dmnerf_repack_model* models, int n_models, void* stream);
 
 #ifdef __cplusplus
 }
