@@ -8,9 +8,9 @@
 //                   (torch/optim/adam.py::_multi_tensor_adam, amsgrad = False, weight_decay = 0, maximize = False):
 //                       m <- lerp(m, g, 1 - b1);  v <- v b2;  v <- v + (1 - b2) (g g)
 //                       step_size = lr / (1 - b1^t);  denom = sqrt(v) / sqrt(1 - b2^t) + eps;  p <- p + (-step_size) (m / denom)
-//                   every product, sum, quotient and square root rounded to f32 on its own (the file is built with
-//                   -ffp-contract=off), the scalar factors formed in double and rounded once, as the Python side of the
-//                   reference optimizer does.  HBM-bound: 28 B per parameter (read g p m v, write p m v).
+//                   the same f32 operations in the same order (the three multiply-adds fused, as in ATen's device kernels), the
+//                   scalar factors formed in double and rounded once, as the Python side of the reference optimizer does.
+//                   HBM-bound: 28 B per parameter (read g p m v, write p m v).
 //   repack_kernel   per model, from the UPDATED flat parameters: a fresh copy of the flat vector (what a pending backward's head
 //                   kernels must keep seeing), the forward blob (gather, = dmnerf_pack_weights) and the W^T blob (gather from
 //                   [parameters | F] with F = A W_rf formed inline by the same f32 fmaf chain, k ascending, as
@@ -49,13 +49,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const float g = a.g[i];
         float m = a.m[i], v = a.v[i];
-        m = m + w1 * (g - m);                                       // _foreach_lerp_(exp_avgs, grads, 1 - beta1): weight < 0.5 form
+        // (the three multiply-adds are FUSED, as the device compiler contracts ATen's `self + weight * diff`, `a + alpha * (b * c)`
+        // and `a + alpha * (b / c)` in the foreach kernels; this file is built with -ffp-contract=off, so it is spelled out)
+        m = fmaf(w1, g - m, m);                                     // _foreach_lerp_(exp_avgs, grads, 1 - beta1): weight < 0.5 form
         v = v * b2;                                                 // _foreach_mul_(exp_avg_sqs, beta2)
-        v = v + w2 * (g * g);                                       // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
+        v = fmaf(w2, g * g, v);                                     // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
         float d = sqrtf(v);                                         // _foreach_sqrt
         d = d / bc2_sqrt;                                           // _foreach_div_(., bias_correction2_sqrt)
         d = d + eps;                                                // _foreach_add_(., eps)
-        a.p[i] = a.p[i] + neg_step * (m / d);                       // _foreach_addcdiv_(params, exp_avgs, ., step_size)
+        a.p[i] = fmaf(neg_step, m / d, a.p[i]);                     // _foreach_addcdiv_(params, exp_avgs, ., step_size)
         a.m[i] = m;
         a.v[i] = v;
     }

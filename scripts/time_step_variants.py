@@ -42,7 +42,7 @@ def main():
                     if name == "flat":
                         opt = FlatAdam((mc, mf), lr=5e-4, capturable=graph)
                     elif name == "adam_fused":
-                        opt = torch.optim.Adam(params, lr=torch.tensor(5e-4, device=dev) if graph else 5e-4, fused=True)
+                        opt = torch.optim.Adam(params, lr=torch.tensor(5e-4, device=dev) if graph else 5e-4, fused=True, capturable=graph)
                     else:
                         opt = torch.optim.Adam(params, lr=torch.tensor(5e-4, device=dev) if graph else 5e-4, capturable=graph)
                     if graph:

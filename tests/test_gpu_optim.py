@@ -23,12 +23,6 @@ def models(seeds=(61, 62), ins_num=INS):
     return out
 
 
-def ulps(a, b):
-    """|a - b| in units of the spacing of f32 at max(|a|, |b|) (>= the smallest normal)."""
-    scale = torch.maximum(a.abs(), b.abs()).clamp_min(1.2e-38)
-    return ((a.double() - b.double()).abs() / (2.0 ** torch.floor(torch.log2(scale.double())) * 2.0 ** -23)).max().item()
-
-
 def test_flat_adam_follows_torch_adam_on_identical_gradients(capsys):
     """20 steps on the same synthetic gradient sequence (magnitudes spread over six decades, some exact zeros), the learning rate
     decayed after every step the way train_dmsr.py:68-72 does it: every parameter within 2 ulp of torch.optim.Adam's, the moments
@@ -44,11 +38,13 @@ def test_flat_adam_follows_torch_adam_on_identical_gradients(capsys):
     assert all(torch.equal(a, p) for a, p in zip(before, [p for m in own_models for p in m.parameters()]))
     assert all(p.data_ptr() == own.flat.data_ptr() + 4 * o for p, o in zip(own.params, np.cumsum([0] + [p.numel() for p in own.params[:-1]])))
     g = torch.Generator(device="cuda").manual_seed(3)
+    gmax = [0.0] * len(own.params)
     for it in range(1, 21):
         ref.zero_grad(); own.zero_grad()
-        for pr, po in zip([p for m in ref_models for p in m.parameters()], own.params):
+        for k, (pr, po) in enumerate(zip([p for m in ref_models for p in m.parameters()], own.params)):
             gr = torch.randn(pr.shape, device="cuda", generator=g) * 10.0 ** torch.randint(-6, 1, (1,), device="cuda", generator=g).float()
             gr[torch.rand(pr.shape, device="cuda", generator=g) < 0.05] = 0.0
+            gmax[k] = max(gmax[k], float(gr.abs().max()))
             pr.grad, po.grad = gr, gr.clone()                            # (foreign gradient tensors: gathered into the arena)
         ref.step(); own.step()
         lr = 5e-4 * (0.1 ** (it / 500000.0))
@@ -57,22 +53,32 @@ def test_flat_adam_follows_torch_adam_on_identical_gradients(capsys):
         for grp in own.param_groups:
             grp['lr'] = lr
     torch.cuda.synchronize()
-    worst = 0.0
-    for pr, po in zip([p for m in ref_models for p in m.parameters()], own.params):
-        worst = max(worst, ulps(pr.detach(), po.detach()))
-    o, worst_m, worst_v = 0, 0.0, 0.0
-    for pr in [p for m in ref_models for p in m.parameters()]:
+    # Every operation of the update is the same f32 operation in both, in the same order, with the same three fused multiply-adds
+    # ATen's device kernels contract to (csrc/optim.hip) -- observed on MI355X: bit-equal.  The bounds allow for a build of torch
+    # that contracts differently (half an ulp of the accumulated quantity per step, amplified where a moment passes through
+    # zero): parameters 2 ulp + 2e-8, first moment 2 ulp + 2 ulp of the largest gradient the tensor saw, second moment 8 ulp.
+    exact = {"p": True, "m": True, "v": True}
+    worst = {"p": 0.0, "m": 0.0, "v": 0.0}
+    o = 0
+    for pr, po, gm in zip([p for m in ref_models for p in m.parameters()], own.params, gmax):
         n = pr.numel()
         st = ref.state[pr]
-        worst_m = max(worst_m, ulps(st["exp_avg"].reshape(-1), own.exp_avg[o:o + n]))
-        worst_v = max(worst_v, ulps(st["exp_avg_sq"].reshape(-1), own.exp_avg_sq[o:o + n]))
+        dp = (pr.detach() - po.detach()).abs()
+        assert bool((dp <= 2.4e-7 * pr.detach().abs() + 2e-8).all()), float(dp.max())
+        dm = (st["exp_avg"].reshape(-1) - own.exp_avg[o:o + n]).abs()
+        assert bool((dm <= 2.4e-7 * st["exp_avg"].reshape(-1).abs() + 2.4e-7 * gm).all()), (float(dm.max()), gm)
+        dv = (st["exp_avg_sq"].reshape(-1) - own.exp_avg_sq[o:o + n]).abs()
+        assert bool((dv <= 1e-6 * st["exp_avg_sq"].reshape(-1).abs() + 1e-37).all()), float(dv.max())
+        exact = {"p": exact["p"] and float(dp.max()) == 0.0, "m": exact["m"] and float(dm.max()) == 0.0, "v": exact["v"] and float(dv.max()) == 0.0}
+        worst["p"] = max(worst["p"], float((dp / (pr.detach().abs() + 1e-3)).max()))
+        worst["m"] = max(worst["m"], float(dm.max()) / gm)
+        worst["v"] = max(worst["v"], float((dv / (st["exp_avg_sq"].reshape(-1).abs() + 1e-30)).max()))
         o += n
-    moved = max(float((a - p).abs().max()) for a, p in zip(before, own.params))
+    moved = max(float((a - p.detach()).abs().max()) for a, p in zip(before, own.params))
     with capsys.disabled():
-        print(f"\n[FlatAdam vs torch.optim.Adam, 20 steps] worst parameter difference {worst:.2f} ulp, exp_avg {worst_m:.2f} ulp, "
-              f"exp_avg_sq {worst_v:.2f} ulp; parameters moved by up to {moved:.2e}; step count {int(own.state2[0])}")
+        print(f"\n[FlatAdam vs torch.optim.Adam, 20 steps] worst |dp| / (|p| + 1e-3) {worst['p']:.2e}, |d exp_avg| / max|g| {worst['m']:.2e}, "
+              f"|d exp_avg_sq| / exp_avg_sq {worst['v']:.2e}; bit-equal: {exact}; parameters moved by up to {moved:.2e}; step count {int(own.state2[0])}")
     assert int(own.state2[0]) == 20 and int(own.state2[1]) == 0
-    assert worst <= 2.0 and worst_m <= 2.0 and worst_v <= 2.0
     assert moved > 5e-3
 
 
@@ -124,7 +130,7 @@ def test_state_dict_round_trips_with_torch_adam():
     ref.load_state_dict(sd)
     run(ref, b_params, grads[3:])
     run(own, own.params, grads[3:])
-    assert max(ulps(pb.detach(), pa.detach()) for pb, pa in zip(b_params, own.params)) <= 2.0
+    assert all(bool(((pb.detach() - pa.detach()).abs() <= 2.4e-7 * pb.detach().abs() + 1e-9).all()) for pb, pa in zip(b_params, own.params))
     # and back: torch's state into a fresh FlatAdam
     c_models = models()
     with torch.no_grad():
@@ -135,7 +141,7 @@ def test_state_dict_round_trips_with_torch_adam():
     assert int(own2.state2[0]) == 6 and own2.param_groups[0]["lr"] == 5e-4
     extra = [torch.randn(p.shape, device="cuda", generator=g) * 1e-2 for p in b_params]
     run(ref, b_params, [extra]); run(own2, own2.params, [extra])
-    assert max(ulps(pb.detach(), pc.detach()) for pb, pc in zip(b_params, own2.params)) <= 2.0
+    assert all(bool(((pb.detach() - pc.detach()).abs() <= 2.4e-7 * pb.detach().abs() + 1e-9).all()) for pb, pc in zip(b_params, own2.params))
 
 
 def _batches(N):
