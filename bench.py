@@ -695,18 +695,13 @@ def self_launch(a):
     return rc
 
 
-def main():
-    global INS_NUM, MAC_PER_SAMPLE, HAVE_F16X2
-    a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(a))
-    INS_NUM = a.ins_num
-    MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)
+def init_world(a):
+    """Rank / device / process group from torchrun's environment (one process per GPU; backend "nccl" = RCCL on ROCm).
+    DMNERF_BENCH_ONE_DEVICE=1 + DMNERF_BENCH_BACKEND=gloo put every rank on the box's one GPU (the tests' dry runs)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    # (DMNERF_BENCH_ONE_DEVICE=1 + DMNERF_BENCH_BACKEND=gloo: exercise the multi-rank code path on a 1-GPU box)
     if os.environ.get("DMNERF_BENCH_ONE_DEVICE") == "1":
         local = 0
     torch.cuda.set_device(local)
@@ -714,49 +709,57 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DMNERF_BENCH_BACKEND", "nccl")                      # "nccl" is RCCL on ROCm
+        backend = os.environ.get("DMNERF_BENCH_BACKEND", "nccl")
         kw = {"device_id": dev} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     strong = a.scaling == "strong" and world > 1
     if strong and N_RAYS % world:
         raise SystemExit(f"--scaling strong needs a world size that divides {N_RAYS}")
+    return types.SimpleNamespace(world=world, rank=rank, dev=dev, strong=strong)
 
-    from dm_nerf_amd import _lib, distributed as D
-    from dm_nerf_amd.networks import helpers as H, render as R
-    HAVE_F16X2 = "dmnerf_mlp_fwd_rays_f16" in _lib.SIGNATURES
+
+def build_scene(w):
+    """Models, camera and the product's frame driver for this rank's band (rank r owns a contiguous band of rows of the frame and
+    generates its own rays -- no scatter; distributed.FrameRenderer = the body of render_frame renders it chunk by chunk into ONE
+    packed band buffer and all-gathers that buffer once per frame; a "step" is one chunk of it)."""
+    from dm_nerf_amd import distributed as D
     from dm_nerf_amd.synthetic import dmsr_intrinsics, pose_spherical
-
-    pe, ve, mc, mf = build_models(dev)
+    pe, ve, mc, mf = build_models(w.dev)
     K = dmsr_intrinsics(H_IMG, W_IMG)
     c2w = pose_spherical(30.0, -65.0, 7.0)
-    # rank r owns a contiguous band of rows of the frame and generates its own rays (no scatter): the product's frame driver
-    # (distributed.FrameRenderer = the body of render_frame) renders it chunk by chunk into ONE packed band buffer and
-    # all-gathers that buffer once per frame; a "step" is one chunk of it
-    n_step = N_RAYS // world if strong else N_RAYS             # rays THIS rank renders per step
+    n_step = N_RAYS // w.world if w.strong else N_RAYS             # rays THIS rank renders per step
     args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None)
-    fr = D.FrameRenderer(H_IMG, W_IMG, K, c2w.to(dev), (mc, mf), NEAR, FAR, args, chunk=n_step, n_samples=S_COARSE)
-    ro, rd = fr.rays_o, fr.rays_d
+    fr = D.FrameRenderer(H_IMG, W_IMG, K, c2w.to(w.dev), (mc, mf), NEAR, FAR, args, chunk=n_step, n_samples=S_COARSE)
     # the steps cycle through ALL chunks of the band, as render_frame does: at N > 1 the band (307 200 / N rays) is not a multiple
     # of 4096 and ends in a ragged chunk (tester.py:65-67) -- it is rendered like the others, so that every gathered frame is
     # complete, and `value` counts the rays each step really rendered (N = 1: 75 chunks of 4096, no ragged one)
-    n_chunks = fr.n_chunks
-    chunk_rays = [min(n_step, fr.n_local - c * n_step) for c in range(n_chunks)]
-    z = fr.z_full
-    mc.blob(); mf.blob()                                        # packed weights resident
+    chunk_rays = [min(n_step, fr.n_local - c * n_step) for c in range(fr.n_chunks)]
+    return types.SimpleNamespace(pe=pe, ve=ve, mc=mc, mf=mf, K=K, c2w=c2w, n_step=n_step, args=args, fr=fr, ro=fr.rays_o, rd=fr.rays_d,
+                                 n_chunks=fr.n_chunks, chunk_rays=chunk_rays, z=fr.z_full)
+
+
+def headline_leg(a, w, sc):
+    """The timed region of the contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides;
+    max over ranks; the dominant kernel's launches bracketed by HIP events the library records on its stream."""
+    from dm_nerf_amd.networks import render as R
+    if w.world > 1:
+        import torch.distributed as dist
+    fr, n_chunks = sc.fr, sc.n_chunks
+    sc.mc.blob(); sc.mf.blob()                                  # packed weights resident
     # setup, not a step: load the code objects (a 32-ray render) and create the RCCL communicator (one scalar all-reduce),
     # so that --warmup 0 still times K steady-state steps
     # (with a scratch HIP-event pair: the runtime sets its timestamp machinery up on the first timed event record of the process
     # -- 35-55 ms on some boxes, measured -- and that is setup, not a step)
     ev_scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     with torch.no_grad():
-        R.dm_nerf(torch.stack([ro[:32], rd[:32]]), pe, ve, mc, mf, z[:32].contiguous(), args, _events=ev_scratch)
-    if world > 1:
-        dist.all_reduce(torch.zeros(1, device=dev))
+        R.dm_nerf(torch.stack([sc.ro[:32], sc.rd[:32]]), sc.pe, sc.ve, sc.mc, sc.mf, sc.z[:32].contiguous(), sc.args, _events=ev_scratch)
+    if w.world > 1:
+        dist.all_reduce(torch.zeros(1, device=w.dev))
     torch.cuda.synchronize()
     flush_c_stdio()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    for b_, e_ in ev:                                               # create the hipEvent_t objects now (torch creates them at the first record)
+    for b_, e_ in ev:                                           # create the hipEvent_t objects now (torch creates them at the first record)
         b_.record(); e_.record()
     torch.cuda.synchronize()
     gathers = [0]
@@ -768,16 +771,17 @@ def main():
     def step(i, events=None):
         c = i % n_chunks
         rgb, ins, depth = fr.step(c, events=events)
-        if world > 1 and c == n_chunks - 1:                     # the band is complete: one all-gather per frame
+        if w.world > 1 and c == n_chunks - 1:                   # the band is complete: one all-gather per frame
             gather_frame()
         return rgb, ins
 
     def barrier():
-        if world > 1:
+        if w.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     quiesce()
+    out_rgb = None
     with torch.no_grad():
         for i in range(a.warmup):
             step(i, ev_scratch)
@@ -786,131 +790,174 @@ def main():
         host_t = []
         t0 = time.perf_counter()
         for i in range(a.steps):
-            out_rgb, out_ins = step(i, ev[i])
+            out_rgb, _ = step(i, ev[i])
             host_t.append(time.perf_counter())
-        if world > 1 and a.steps > 0 and gathers[0] == 0:
+        if w.world > 1 and a.steps > 0 and gathers[0] == 0:
             gather_frame()                                      # fewer steps than a band has chunks: the frame's gather is still timed
         barrier()
         dt = time.perf_counter() - t0
-    rays_rank = sum(chunk_rays[i % n_chunks] for i in range(a.steps))      # rays THIS rank rendered in the timed region
+    rays_rank = sum(sc.chunk_rays[i % n_chunks] for i in range(a.steps))      # rays THIS rank rendered in the timed region
     rays_total = rays_rank
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if w.world > 1:
+        tmax = torch.tensor([dt], device=w.dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        cnt = torch.tensor([rays_rank], device=dev, dtype=torch.float64)
+        cnt = torch.tensor([rays_rank], device=w.dev, dtype=torch.float64)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         rays_total = int(cnt.item())
+    return types.SimpleNamespace(dt=dt, rays_rank=rays_rank, rays_total=rays_total, ev=ev, gathers=gathers[0], host_t=host_t, t0=t0, out_rgb=out_rgb)
 
-    train_multi = None
-    if world > 1 and not a.no_train:
-        # every rank takes part; a failure here must not cost the headline line
+
+def multi_rank_legs(a, w, sc):
+    """N > 1 only, every rank takes part: the sharded training step and BASELINE config 5's manipulation frame across the ranks.
+    A failure here must not cost the headline line."""
+    from dm_nerf_amd.networks import helpers as H
+    train_multi = mani_multi = None
+    if w.world > 1 and not a.no_train:
         try:
-            n_train = N_RAYS if strong else N_RAYS * world
+            n_train = N_RAYS if w.strong else N_RAYS * w.world
             rows_t = -(-n_train // W_IMG)
-            tro, trd = H.get_rays_k(H_IMG, W_IMG, K, c2w.to(dev), row0=0, nrows=rows_t)
-            zt = H.z_val_sample(n_train, NEAR, FAR, S_COARSE, device=dev)
-            train_multi = train_leg(mc, mf, tro.reshape(-1, 3), trd.reshape(-1, 3), zt, a.train_steps, dev, world, n=n_train)
+            tro, trd = H.get_rays_k(H_IMG, W_IMG, sc.K, sc.c2w.to(w.dev), row0=0, nrows=rows_t)
+            zt = H.z_val_sample(n_train, NEAR, FAR, S_COARSE, device=w.dev)
+            train_multi = train_leg(sc.mc, sc.mf, tro.reshape(-1, 3), trd.reshape(-1, 3), zt, a.train_steps, w.dev, w.world, n=n_train)
             train_multi["scaling"] = a.scaling
         except Exception as e:                                  # noqa: BLE001
             train_multi = {"error": f"{type(e).__name__}: {e}"}
-
-    mani_multi = None
-    if world > 1 and not a.no_extras:
-        try:                                                    # BASELINE config 5's render across the ranks (never `value`)
-            mani_multi = manipulator_frame_leg(mc, mf, K, dev, world=world)
+    if w.world > 1 and not a.no_extras:
+        try:                                                    # (never `value`)
+            mani_multi = manipulator_frame_leg(sc.mc, sc.mf, sc.K, w.dev, world=w.world)
         except Exception as e:                                  # noqa: BLE001
             mani_multi = {"error": f"{type(e).__name__}: {e}"}
+    return train_multi, mani_multi
 
-    if rank == 0:
-        if world == 1:
-            # the full 10-key dict of the chunk the timed loop rendered last (the frame driver keeps rgb / ins / depth only):
-            # the same call, untimed -- what the CPU comparison and the opt-in legs are checked against
-            c_last = 0 if a.steps == 0 else (a.steps - 1) % n_chunks
-            with torch.no_grad():
-                out = R.dm_nerf(torch.stack([ro[c_last * N_RAYS:(c_last + 1) * N_RAYS], rd[c_last * N_RAYS:(c_last + 1) * N_RAYS]]), pe, ve, mc, mf, z, args)
-            torch.cuda.synchronize()
-            if a.steps:
-                assert torch.equal(out['rgb_fine'], out_rgb), "frame driver and dm_nerf disagree on the same chunk"
-        # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
-        k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else float("nan")
-        # (average over the timed launches of rank 0; with a ragged chunk among them, the average launch is that much smaller)
-        flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * (rays_rank / max(a.steps, 1))
-        achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
-        rays_per_s = rays_total / dt
-        traffic, traffic_src = pmc_traffic() if (INS_NUM == 13 and n_step == N_RAYS) else (None, None)
-        res = {
-            "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / max(a.steps, 1) * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,")
-                                   + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
-                                   f"{n_step}-ray chunk per step per GPU, det sampling, ins_num={INS_NUM}, random-init weights",
-                       "rays_per_step_per_gpu": n_step, "rays_in_timed_region": rays_total,
-                       "chunks_per_band": n_chunks, "ragged_chunk_rays": (chunk_rays[-1] if chunk_rays and chunk_rays[-1] != n_step else 0),
-                       "parallelism": f"ray-sharded x{world}" + (
-                           f" + one RCCL all-gather of the rank's band per frame ({gathers[0]} in the timed region)" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,false,false> (fine network, {n_step}x192 samples)", "kernel_ms": k_ms,
-                         "flop_per_launch": flop_per_launch},
-            "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
-        }
-        if a.steps > 1:                                             # diagnostic: how long the HOST took to enqueue each step (no sync inside the loop)
-            hd = np.diff(np.array([t0] + host_t)) * 1e3
-            res["host_enqueue_ms_per_step"] = {"median": float(np.median(hd)), "max": float(hd.max()), "first": float(hd[0])}
-        if world == 1 and not a.no_cpu_baseline:
-            c = 0 if a.steps == 0 else (a.steps - 1) % n_chunks
-            rays_cpu = torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]]).cpu()
-            base, psnr, n, want = cpu_baseline(mc, mf, rays_cpu, z.cpu(), out['rgb_fine'].cpu(), a.cpu_seconds)
-            res["cpu_baseline"] = base
-            res["psnr_vs_oracle_db"] = psnr
-            res["label_flips_vs_oracle"] = {"rays": n, "ins_fine": int((out['ins_fine'].cpu()[:n].argmax(-1) != want['ins_fine'].argmax(-1)).sum()),
-                                            "ins_coarse": int((out['ins_coarse'].cpu()[:n].argmax(-1) != want['ins_coarse'].argmax(-1)).sum())}
-            res["speedup_vs_cpu"] = rays_per_s / base["value"]
-        if world == 1 and not a.no_extras:
-            res["frame"] = frame_leg(mc, mf, K, c2w, dev)
-            res["render_fused_heads"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], fuse_heads=True)
-            res["render_split_bf16"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split=True)
-            res["frame_split_bf16"] = frame_leg(mc, mf, K, c2w, dev, mfma_split=True)
-            if HAVE_F16X2:
-                res["render_split_f16x2"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
-                res["frame_split_f16x2"] = frame_leg(mc, mf, K, c2w, dev, mfma_split="f16x2")
-            res["manipulator"] = manipulator_leg(mc, mf, K, dev)
-            res["manipulator_frame"] = manipulator_frame_leg(mc, mf, K, dev)
-            if INS_NUM != 59:                           # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
-                pe9, ve9, mc9, mf9 = build_models(dev, 59)
-                res["render_ins59"] = render_leg(pe9, ve9, mc9, mf9, ro, rd, z, a.steps, ins_num=59)
-        if world == 1 and not a.no_train:
-            tb = None
-            if not a.no_cpu_baseline:                   # (before the GPU leg: it updates the weights in place)
-                tb = cpu_train_baseline(mc, mf, torch.stack([ro[:N_RAYS], rd[:N_RAYS]]).cpu(), z.cpu(), a.cpu_seconds)
-            res["train"] = train_leg(mc, mf, ro, rd, z, a.train_steps, dev)
-            if tb is not None:
-                res["train"]["cpu_baseline"] = tb
-                res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
-            if not a.no_extras:
-                res["train_loop"] = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
-                res["train_graph"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS)
-                res["train_graph"]["note"] = "the `train` step (4096 rays) replayed from one HIP graph (GraphedTrainStep)"
-                res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS,
-                                                           t_3072_ms=res["train_loop"]["step_ms_resident_batch"])
-                if INS_NUM != 59:
-                    t9 = train_leg(mc9, mf9, ro, rd, z, a.train_steps, dev, ins_num=59)
-                    res["train_ins59"] = {k: t9[k] for k in ("rays_per_s", "ms_per_step", "tflops", "frac_of_mfma_peak", "roofline", "ins_num")}
-                tf = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, fuse_heads=True)
-                res["train_fused_heads"] = {"rays_per_s": tf["rays_per_s"], "ms_per_step": tf["ms_per_step"], "roofline": tf["roofline"],
-                                            "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
-                for key, mode in (("train_split_bf16", True),) + ((("train_split_f16x2", "f16x2"),) if HAVE_F16X2 else ()):
-                    ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=mode)
-                    res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
-                                "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
-                                "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the "
-                                        "split-operand 16-bit MFMA kernels "
-                                        f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
-                    tl = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20), mfma_split=mode)
-                    res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
-                    res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
+
+def headline_record(a, w, sc, h):
+    """The contract's JSON object from the timed region: value, roofline of the dominant kernel, config."""
+    # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
+    k_ms = float(np.mean([s.elapsed_time(e) for s, e in h.ev])) if a.steps else float("nan")
+    # (average over the timed launches of rank 0; with a ragged chunk among them, the average launch is that much smaller)
+    flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * (h.rays_rank / max(a.steps, 1))
+    achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+    rays_per_s = h.rays_total / h.dt
+    traffic, traffic_src = pmc_traffic() if (INS_NUM == 13 and sc.n_step == N_RAYS) else (None, None)
+    res = {
+        "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
+        "n_gpus": w.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": h.dt / max(a.steps, 1) * 1e3,
+        "higher_is_better": True, "scaling": "strong" if w.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,")
+                               + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
+                               f"{sc.n_step}-ray chunk per step per GPU, det sampling, ins_num={INS_NUM}, random-init weights",
+                   "rays_per_step_per_gpu": sc.n_step, "rays_in_timed_region": h.rays_total,
+                   "chunks_per_band": sc.n_chunks,
+                   "ragged_chunk_rays": (sc.chunk_rays[-1] if sc.chunk_rays and sc.chunk_rays[-1] != sc.n_step else 0),
+                   "parallelism": f"ray-sharded x{w.world}" + (
+                       f" + one RCCL all-gather of the rank's band per frame ({h.gathers} in the timed region)" if w.world > 1 else "")},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_measured_in_this_run": False if traffic is not None else None,
+                     "kernel": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,false,false> (fine network, {sc.n_step}x192 samples)", "kernel_ms": k_ms,
+                     "flop_per_launch": flop_per_launch},
+        "path_tflops": rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
+    }
+    if a.steps > 1:                                             # diagnostic: how long the HOST took to enqueue each step (no sync inside the loop)
+        hd = np.diff(np.array([h.t0] + h.host_t)) * 1e3
+        res["host_enqueue_ms_per_step"] = {"median": float(np.median(hd)), "max": float(hd.max()), "first": float(hd[0])}
+    return res
+
+
+def single_gpu_render_legs(a, w, sc, h, res):
+    """N = 1, rank 0: the full dict of the last timed chunk (checked against the frame driver), the CPU baseline on the same
+    chunk, and the secondary render legs (frame, opt-in modes, manipulator, ins-59).  Returns what the training legs reuse."""
+    from dm_nerf_amd.networks import render as R
+    pe, ve, mc, mf, ro, rd, z = sc.pe, sc.ve, sc.mc, sc.mf, sc.ro, sc.rd, sc.z
+    # the full 10-key dict of the chunk the timed loop rendered last (the frame driver keeps rgb / ins / depth only):
+    # the same call, untimed -- what the CPU comparison and the opt-in legs are checked against
+    c_last = 0 if a.steps == 0 else (a.steps - 1) % sc.n_chunks
+    with torch.no_grad():
+        out = R.dm_nerf(torch.stack([ro[c_last * N_RAYS:(c_last + 1) * N_RAYS], rd[c_last * N_RAYS:(c_last + 1) * N_RAYS]]), pe, ve, mc, mf, z, sc.args)
+    torch.cuda.synchronize()
+    if a.steps:
+        assert torch.equal(out['rgb_fine'], h.out_rgb), "frame driver and dm_nerf disagree on the same chunk"
+    if not a.no_cpu_baseline:
+        rays_cpu = torch.stack([ro[c_last * N_RAYS:(c_last + 1) * N_RAYS], rd[c_last * N_RAYS:(c_last + 1) * N_RAYS]]).cpu()
+        base, psnr, n, want = cpu_baseline(mc, mf, rays_cpu, z.cpu(), out['rgb_fine'].cpu(), a.cpu_seconds)
+        res["cpu_baseline"] = base
+        res["psnr_vs_oracle_db"] = psnr
+        res["label_flips_vs_oracle"] = {"rays": n, "ins_fine": int((out['ins_fine'].cpu()[:n].argmax(-1) != want['ins_fine'].argmax(-1)).sum()),
+                                        "ins_coarse": int((out['ins_coarse'].cpu()[:n].argmax(-1) != want['ins_coarse'].argmax(-1)).sum())}
+        res["speedup_vs_cpu"] = res["value"] / base["value"]
+    wide = None
+    if not a.no_extras:
+        res["frame"] = frame_leg(mc, mf, sc.K, sc.c2w, w.dev)
+        res["render_fused_heads"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], fuse_heads=True)
+        res["render_split_bf16"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split=True)
+        res["frame_split_bf16"] = frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split=True)
+        if HAVE_F16X2:
+            res["render_split_f16x2"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
+            res["frame_split_f16x2"] = frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split="f16x2")
+        res["manipulator"] = manipulator_leg(mc, mf, sc.K, w.dev)
+        res["manipulator_frame"] = manipulator_frame_leg(mc, mf, sc.K, w.dev)
+        if INS_NUM != 59:                               # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
+            wide = build_models(w.dev, 59)
+            res["render_ins59"] = render_leg(*wide, ro, rd, z, a.steps, ins_num=59)
+    return wide
+
+
+def single_gpu_train_legs(a, w, sc, res, wide):
+    """N = 1, rank 0: the optimisation step (`train`, with its CPU baseline), and the secondary training legs."""
+    mc, mf, ro, rd, z, dev = sc.mc, sc.mf, sc.ro, sc.rd, sc.z, w.dev
+    tb = None
+    if not a.no_cpu_baseline:                           # (before the GPU leg: it updates the weights in place)
+        tb = cpu_train_baseline(mc, mf, torch.stack([ro[:N_RAYS], rd[:N_RAYS]]).cpu(), z.cpu(), a.cpu_seconds)
+    res["train"] = train_leg(mc, mf, ro, rd, z, a.train_steps, dev)
+    if tb is not None:
+        res["train"]["cpu_baseline"] = tb
+        res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
+    if a.no_extras:
+        return
+    res["train_loop"] = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
+    res["train_graph"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS)
+    res["train_graph"]["note"] = "the `train` step (4096 rays) replayed from one HIP graph (GraphedTrainStep)"
+    if wide is not None:
+        t9 = train_leg(wide[2], wide[3], ro, rd, z, a.train_steps, dev, ins_num=59)
+        res["train_ins59"] = {k: t9[k] for k in ("rays_per_s", "ms_per_step", "tflops", "frac_of_mfma_peak", "roofline", "ins_num")}
+    tf = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, fuse_heads=True)
+    res["train_fused_heads"] = {"rays_per_s": tf["rays_per_s"], "ms_per_step": tf["ms_per_step"], "roofline": tf["roofline"],
+                                "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
+    for key, mode in (("train_split_bf16", True),) + ((("train_split_f16x2", "f16x2"),) if HAVE_F16X2 else ()):
+        ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=mode)
+        res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
+                    "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
+                    "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the "
+                            "split-operand 16-bit MFMA kernels "
+                            f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
+        tl = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20), mfma_split=mode)
+        res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
+        res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
+    # (last: the extension optimizer re-points the models' parameters at its flat vector)
+    res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS,
+                                               t_3072_ms=res["train_loop"]["step_ms_resident_batch"])
+
+
+def main():
+    global INS_NUM, MAC_PER_SAMPLE, HAVE_F16X2
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    INS_NUM = a.ins_num
+    MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)
+    w = init_world(a)
+    from dm_nerf_amd import _lib
+    HAVE_F16X2 = "dmnerf_mlp_fwd_rays_f16" in _lib.SIGNATURES
+    sc = build_scene(w)
+    h = headline_leg(a, w, sc)
+    train_multi, mani_multi = multi_rank_legs(a, w, sc)
+    if w.rank == 0:
+        res = headline_record(a, w, sc, h)
+        if w.world == 1:
+            wide = single_gpu_render_legs(a, w, sc, h, res)
+            if not a.no_train:
+                single_gpu_train_legs(a, w, sc, res, wide)
         if train_multi is not None:
             res["train"] = train_multi
         if mani_multi is not None:
@@ -922,12 +969,13 @@ def main():
             res["train_batch_rays"] = t["batch_rays"]
             res["train_roofline_frac_worst"] = None if not t.get("roofline") else t["roofline"]["frac"]
             res["train_step_frac_of_mfma_peak"] = t["frac_of_mfma_peak"]["executed"]
-    if world > 1:
+    if w.world > 1:
+        import torch.distributed as dist
         dist.barrier()                                          # nobody is still printing
     flush_c_stdio()
-    if rank == 0:
+    if w.rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if w.world > 1:
         dist.destroy_process_group()
 
 
