@@ -45,6 +45,14 @@ MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)          # 693 504
 F32_MFMA_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 B16_MFMA_PEAK_TFLOPS = 2500.0                          # same guide: dense bf16 / f16 v_mfma_f32_32x32x16_*
 HAVE_F16X2 = False                                     # set in main(): the library exports the f16x2 split kernels
+HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0      # same guide: HBM3E spec; the rate its own streaming benchmark measures
+# HBM bytes per SAMPLE of the three training kernels at ins_num 13, from the committed rocprofv3 PMC passes of the 4096-ray step
+# (profiles/r04/pmc_train_r04f.txt: separate --pmc runs, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, fine launch = 786 432 samples;
+# the f16x2 kernels move the same f32 rows: their counters agree within 1 %; bf16x3 saves the same rows, not separately measured).
+# Counters cannot be read from inside the process, so these are NOT measured in this run: they turn a kernel time measured
+# here into a GB/s figure, so that a kernel's `bound` says which roof it is actually closer to.
+TRAIN_HBM_BYTES_PER_SAMPLE = {"mlp_fwd_train": (2 * 2.9427e5 + 7.6308e6) * 1e3 / 786432, "mlp_bwd_data": (2 * 3.3843e5 + 7.1332e6) * 1e3 / 786432,
+                              "mlp_bwd_weights": (2 * 0.75 * 2 * 5.5509e6 + 0.75 * 2 * 63148) * 1e3 / 786432}
 
 
 def mac_counts(ins_num):
@@ -236,9 +244,20 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
             k_ms = float(np.mean(ms))
             tf = 2.0 * exec_mac[tag] * products * m_fine / (k_ms * 1e-3) / 1e12
             tf_ref = 2.0 * ref_mac[tag] * m_fine / (k_ms * 1e-3) / 1e12
-            kernels.append({"kernel": names[tag], "launches": len(ms), "kernel_ms": k_ms, "mac_per_sample_executed": exec_mac[tag],
-                            "mfma_products_per_mac": products, "achieved": tf, "peak": peak, "frac": tf / peak,
-                            "algorithmic_tflops": tf_ref})
+            entry = {"kernel": names[tag], "launches": len(ms), "kernel_ms": k_ms, "mac_per_sample_executed": exec_mac[tag],
+                     "mfma_products_per_mac": products, "bound": "mfma", "unit": "TFLOP/s", "achieved": tf, "peak": peak, "frac": tf / peak,
+                     "algorithmic_tflops": tf_ref}
+            if ins_num == 13:
+                # which roof is this kernel closer to?  (the opt-in f16x2 weight-gradient kernel reads the same f32 rows as the f32
+                # one in less than half the time: it sits at 0.74 of the HBM spec and 0.38 of the 16-bit MFMA roof -- HBM-bound)
+                gbs = TRAIN_HBM_BYTES_PER_SAMPLE[tag] * m_fine / (k_ms * 1e-3) / 1e9
+                entry["hbm"] = {"achieved_GBs": gbs, "frac_of_spec_8TBs": gbs / HBM_PEAK_GBS, "frac_of_guide_measured_6.29TBs": gbs / HBM_ACHIEVABLE_GBS,
+                                "bytes_per_sample": TRAIN_HBM_BYTES_PER_SAMPLE[tag], "bytes_source": "profiles/r04/pmc_train_r04f.txt",
+                                "traffic_measured_in_this_run": False}
+                if gbs / HBM_PEAK_GBS > entry["frac"]:
+                    entry.update(bound="hbm", unit="GB/s", achieved=gbs, peak=HBM_PEAK_GBS, frac=gbs / HBM_PEAK_GBS,
+                                 mfma={"achieved_tflops": tf, "peak": peak, "frac": tf / peak})
+            kernels.append(entry)
     worst = min(kernels, key=lambda k: k["frac"]) if kernels else None
     flop_exec = 2.0 * (fwd_exec + mac["dgrad"] + mac["wgrad"]) * products * (2 * S_COARSE + N_IMP) * n
     return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop_exec / dt / 1e12, "tflops_reference_flops": flop_ref / dt / 1e12,
@@ -249,13 +268,14 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
                                           "so it is not a fraction of any roof)"},
             "final_loss": float(loss.detach()),
             "batch_rays": n, "ins_num": ins_num,
-            "roofline": None if worst is None else {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "kernel": worst["kernel"],
+            "roofline": None if worst is None else {"bound": worst["bound"], "unit": worst["unit"], "peak": worst["peak"], "kernel": worst["kernel"],
                                                     "kernel_ms": worst["kernel_ms"], "achieved": worst["achieved"], "frac": worst["frac"],
                                                     "samples_per_launch": m_fine, "all": kernels,
                                                     "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; "
                                                             "`kernel` = the one furthest below "
-                                                            "the roof on EXECUTED MACs; algorithmic_tflops = the reference's FLOP count "
-                                                            "of the stage over the same time"},
+                                                            "ITS roof (each kernel's `bound` is the roof it is closer to: EXECUTED MACs against "
+                                                            "the MFMA peak, or its HBM bytes per sample -- committed PMC passes -- against 8 TB/s); "
+                                                            "algorithmic_tflops = the reference's FLOP count of the stage over the same time"},
             "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"
                     + (f"; one batch sharded over {world} ranks (sharded_train_step)" if world > 1 else "")}
 
