@@ -26,7 +26,7 @@ template <int N, class F>
 __device__ __forceinline__ void sfor(F&& f) { sf_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // SMALL = 1: v_mfma_f32_16x16x4_f32 (16 accumulators of 4 registers); 0: v_mfma_f32_32x32x2_f32 (16 accumulators of 16)
-template <int SMALL, int READS, int DMAS, int BARRIER, int VALU>
+template <int SMALL, int READS, int DMAS, int BARRIER, int VALU, int STORE = 0>
 __global__ __launch_bounds__(256) void mix(float* out, const float* src, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -43,6 +43,10 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
     const unsigned ub_lo = __builtin_amdgcn_readfirstlane((unsigned)gb), ub_hi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
     const unsigned long long ub = ((unsigned long long)ub_hi << 32) | ub_lo;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, 1 << 28, 0x00020000);
+    __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 4, 64, (1 << 23));   // stride 4 + ADD_TID_ENABLE
+    // STORE 1: the 16-sample wave's activation rows in the [32-sample block][row][32] layout the backward kernels read: lane
+    // (q = lane / 16, n = lane % 16) writes feature row 4 q + i at sample n -> four 64-byte runs per instruction, address in a VGPR
+    const int srow = ((lane >> 4) * 4) * 128 + (lane & 15) * 4 + (wu & 1) * 64;
     for (int it = 0; it < iters; ++it) {
         if (DMAS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (BARRIER) __builtin_amdgcn_s_barrier();
@@ -61,6 +65,10 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LAS void*)(lds + 16384 + wu * 256 + (M / (256 / (DMAS > 0 ? DMAS : 1))) * 1024), 16, voff,
                                                              (M / (256 / (DMAS > 0 ? DMAS : 1))) * 4096, 0, 0);
                 for (int v = 0; v < VALU; ++v) vv = fmaxf(vv * 1.0001f, 0.5f);
+                if constexpr (STORE == 1 && M % 16 == 0)        // 16 VGPR-addressed dword stores per body (64 per 256 x 256 layer)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[gl & 1][i & 7][0]), rs, srow + (M / 16) * 2048, (it & 63) * 65536 + 4194304, 0);
+                if constexpr (STORE == 2 && M % 8 == 0)         // 32 TID-addressed dword stores per body (128 per layer: the 32-sample kernel)
+                    asm volatile("buffer_store_dword %0, off, %1, %2 offset:%3" :: "v"(a[gl & 1][i & 7][0]), "s"(rst), "s"((it & 63) * 65536 + 4194304 + (M / 8) * 256), "n"(0) : "memory");
                 if constexpr (SMALL)
                     acc[i & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gl & 1][i & 7][i >> 3 & 3], b, acc[i & 15], 0, 0, 0);
                 else
@@ -76,13 +84,13 @@ __global__ __launch_bounds__(256) void mix(float* out, const float* src, int ite
 
 static double base_tf[2] = {0, 0};
 
-template <int SMALL, int READS, int DMAS, int BARRIER, int VALU>
+template <int SMALL, int READS, int DMAS, int BARRIER, int VALU, int STORE = 0>
 void run(const char* name) {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     int grid = p.multiProcessorCount, iters = SMALL ? 4000 : 2000;
     float *out, *src;
     (void)hipMalloc(&out, grid * 256 * 4); (void)hipMalloc(&src, 1 << 28); (void)hipMemset(src, 0, 1 << 20);
-    auto k = mix<SMALL, READS, DMAS, BARRIER, VALU>;
+    auto k = mix<SMALL, READS, DMAS, BARRIER, VALU, STORE>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<<<grid, 256, 147456>>>(out, src, 400);
@@ -99,7 +107,7 @@ void run(const char* name) {
     const double tf = (double)grid * 4 * iters * 256.0 * flop_per_mfma / best * 1e-9;
     const double ideal = SMALL ? 8192.0 : 16384.0;
     const double cyc = best * 1e-3 * 2.4e9 / iters;
-    if (!READS && !DMAS && !BARRIER && !VALU) base_tf[SMALL] = tf;
+    if (!READS && !DMAS && !BARRIER && !VALU && !STORE) base_tf[SMALL] = tf;
     printf("%-58s %8.3f ms %7.1f TFLOP/s = %.3f of 157.3 | %.3f of the plain stream | %6.0f cycles per 256 MFMAs at 2.4 GHz (ideal %5.0f, +%5.0f)\n",
            name, best, tf, tf / 157.3, base_tf[SMALL] > 0 ? tf / base_tf[SMALL] : 1.0, cyc, ideal, cyc - ideal);
     fflush(stdout);
@@ -118,5 +126,7 @@ int main() {
     run<1, 1, 16, 1, 0>("16x16x4  + 64 reads + 16 DMA + vmcnt + barrier");
     run<1, 1, 16, 1, 1>("16x16x4  ... + 1 VALU per gap (same epilogue work per MFMA)");
     run<1, 1, 8, 1, 0>("16x16x4  + 64 reads + 8 DMA + vmcnt + barrier");
+    run<0, 1, 16, 1, 0, 2>("32x32x2  kernel + 32 TID-addressed row stores (training forward)");
+    run<1, 1, 16, 1, 0, 1>("16x16x4  kernel + 16 VGPR-addressed row stores (training forward)");
     return 0;
 }

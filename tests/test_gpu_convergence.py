@@ -190,7 +190,41 @@ def _run_trajectory(mode, steps, eval_at, max_wgs=None):
     return torch.stack(rows).double().cpu().numpy(), evals
 
 
-PLAN_BUDGETS = (None, 224, 192, 160, 128)       # weight-gradient plans: the default (256 = one workgroup per CU) and four other splits
+def plan_budgets():
+    """Weight-gradient plans: the default (one workgroup per CU) and four other splits of the sample axis -- 7/8, 3/4, 5/8 and 1/2
+    of the CU count (224, 192, 160, 128 workgroups on the 256 CUs of an MI355X)."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    return (None,) + tuple(int(cus * f) for f in (0.875, 0.75, 0.625, 0.5))
+
+
+def _oracle_runs(golden):
+    """The ORACLE's own samples: the committed 2000-step run (train_traj.npz) and its summation-order variants
+    (train_traj_v{k}.npz: the identical training with the rays of every batch visited in another order, so that every f32 sum --
+    loss means, cost-matrix sums, the weight-gradient contractions -- is taken in another order; make_train_traj.py) ->
+    {step: [held-out PSNR of each run]}."""
+    import glob
+    base = golden("train_traj")
+    steps = [int(x) for x in base["eval_steps"]]
+    runs = {s_: [float(p)] for s_, p in zip(steps, base["eval_psnr"])}
+    names = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_traj_v*.npz")))
+    for path in names:
+        with np.load(path) as z:
+            assert [int(x) for x in z["eval_steps"]] == steps and [int(x) for x in z["config"]] == [int(x) for x in base["config"]]
+            for s_, p in zip(steps, z["eval_psnr"]):
+                runs[s_].append(float(p))
+    return runs, len(names) + 1
+
+
+def _two_sample(hip, oracle, cap):
+    """Two-sample comparison of held-out PSNRs: HIP runs (weight-gradient sums in different orders) against oracle runs (batch rows
+    in different orders).  Both sets are draws from 'a correct f32 implementation of this training, up to summation order':
+        |mean_HIP - mean_oracle| <= 2 sqrt(s2_HIP / n_HIP + s2_oracle / n_oracle)      (Welch's standard error)
+    AND <= ``cap``, an absolute ceiling that does not grow with either spread -- a path with a systematic deficit of ``cap`` or more
+    fails however noisy it is.  (Deterministic on a given GPU model: the HIP runs are, the oracle's are fixtures.)"""
+    hip, oracle = np.asarray(hip, dtype=np.float64), np.asarray(oracle, dtype=np.float64)
+    se = float(np.sqrt(hip.var(ddof=1) / len(hip) + oracle.var(ddof=1) / len(oracle)))
+    gap = abs(float(hip.mean() - oracle.mean()))
+    return gap, 2.0 * se, gap <= 2.0 * se and gap <= cap
 
 
 @pytest.mark.timeout(900)
@@ -198,16 +232,19 @@ PLAN_BUDGETS = (None, 224, 192, 160, 128)       # weight-gradient plans: the def
 def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     """300 steps x 512 rays on the batches and jitter of the oracle's run.  A training trajectory amplifies rounding differences
     (ReLU boundaries, Adam's sign-like first steps), so the losses are compared step by step where that is tight and in windows
-    afterwards, and the PSNR after the 300 steps -- still climbing ~0.03 dB per step there -- against the CHAOS FLOOR measured in
-    the same test: the identical training with the weight-gradient partial sums taken in four other orders (PLAN_BUDGETS).  The
-    HIP path may differ from the oracle by 1.5 x the spread of those HIP-vs-HIP runs (at least 0.05 dB), no more: it is then
-    indistinguishable from a re-ordering of its own sums.  Loss bounds (r03 measurements: 1.7e-4 over the first 20 steps, 4e-4 ..
-    5e-3 over the first 100, 1.2 .. 1.6 % on 20-step windows) are ~2.5-3x those figures."""
+    afterwards, and the PSNR after the 300 steps -- still climbing ~0.03 dB per step there -- as a TWO-SAMPLE comparison (VERDICT
+    r04 item 3): five HIP runs that differ only in the order of the weight-gradient partial sums (plan_budgets()) against the
+    oracle's four runs that differ only in the order the batch rows are visited (tests/golden/train_traj*.npz).  The means must
+    agree within twice the standard error of their difference AND within 0.5 dB whatever the spreads.  Loss bounds (r03
+    measurements: 1.7e-4 over the first 20 steps, 4e-4 .. 5e-3 over the first 100, 1.2 .. 1.6 % on 20-step windows) are ~2.5-3x
+    those figures."""
     g = golden("train_traj")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_train_traj as T
     assert [int(v) for v in g["config"]] == [T.INS_NUM, T.H, T.W, T.VIEWS, T.STEPS, T.BATCH]
-    runs = {b: _run_trajectory(mode, T.STEPS, (T.STEPS,), max_wgs=b) for b in PLAN_BUDGETS}
+    oracle_runs, n_or = _oracle_runs(golden)
+    assert n_or >= 4, "the oracle's summation-order variants (tests/golden/train_traj_v*.npz) are missing"
+    runs = {b: _run_trajectory(mode, T.STEPS, (T.STEPS,), max_wgs=b) for b in plan_budgets()}
     got, evals = runs[None]
     want = (g["losses"].numpy() if torch.is_tensor(g["losses"]) else np.asarray(g["losses"]))[:T.STEPS]
     (psnr0, pur0), (psnr1, pur1) = evals[0], evals[T.STEPS]
@@ -216,51 +253,51 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     relw = np.abs(win(got) - win(want)) / np.abs(win(want))
     gp, gpu_ = [float(x) for x in g["psnr"]], [float(x) for x in g["purity"]]
     psnrs = {b: r[1][T.STEPS][0] for b, r in runs.items()}
-    spread = max(psnrs.values()) - min(psnrs.values())
-    bound = max(0.05, 1.5 * spread)
-    gap = abs(psnr1 - gp[1])
+    gap, bound, ok = _two_sample(list(psnrs.values()), oracle_runs[T.STEPS], cap=0.5)
     with capsys.disabled():
         print(f"\n[trajectory vs oracle, {mode or 'default'}] total loss: max rel gap first 20 steps {rel[:20].max():.2e}, first 100 {rel[:100].max():.2e}, "
               f"all 300 {rel.max():.2e}; 20-step windows {relw.max():.2e};  purity {pur1:.4f} (oracle {gpu_[1]:.4f})")
-        print(f"  gap vs spread after {T.STEPS} steps | oracle {gp[1]:.3f} dB | HIP by wgrad plan budget: "
+        print(f"  two samples after {T.STEPS} steps | oracle runs (row orders): " + ", ".join(f"{v:.3f}" for v in oracle_runs[T.STEPS])
+              + f" -> mean {np.mean(oracle_runs[T.STEPS]):.3f}, sd {np.std(oracle_runs[T.STEPS], ddof=1):.3f} | HIP runs (wgrad plan budgets): "
               + ", ".join(f"{b or 'default'}: {v:.3f}" for b, v in psnrs.items())
-              + f" | HIP-vs-HIP spread {spread:.3f} dB | HIP(default)-vs-oracle gap {gap:.3f} dB | bound max(0.05, 1.5 x spread) = {bound:.3f} dB")
+              + f" -> mean {np.mean(list(psnrs.values())):.3f}, sd {np.std(list(psnrs.values()), ddof=1):.3f} | "
+              f"|difference of means| {gap:.3f} dB <= 2 SE = {bound:.3f} dB and <= 0.5 dB")
     assert abs(psnr0 - gp[0]) <= 0.01 and abs(pur0 - gpu_[0]) <= 0.005        # same start
     assert rel[:20].max() <= 5e-4, rel[:20].max()                       # step by step while rounding has not been amplified yet
     assert rel[:100].max() <= 1.5e-2, rel[:100].max()
     assert relw.max() <= 0.04, relw.max()                               # 20-step windows over the whole run
-    assert gap <= bound, (psnr1, gp[1], spread)                         # no further from the oracle than from a re-ordering of itself
+    assert ok, (gap, bound, psnrs, oracle_runs[T.STEPS])                # the two samples are one population; a 0.5 dB deficit fails regardless
     assert abs(pur1 - gpu_[1]) <= 0.02, (pur1, gpu_)
     assert psnr1 >= gp[0] + 8.0                                         # ... and it learned: + 9.5 dB in 300 steps
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1500)
 def test_trained_psnr_matches_the_oracle_at_the_plateau(golden, capsys):
-    """The same run continued to 2000 steps (the oracle's: ~2 h of CPU in the build container, make_train_traj.py): from ~1000
-    steps on the held-out PSNR has no steady slope left (oracle 24.79 / 26.79 / 25.14 dB at 1000 / 1500 / 2000: it wanders by a dB
-    between checkpoints), so single checkpoints say little.  Mean PSNR over steps 1000 / 1500 / 2000, default kernels against the
-    oracle, bounded by the chaos floor measured alongside (three HIP runs that differ in the summation order of the weight
-    gradients only): |gap| <= max(0.05 dB, 1.5 x HIP-vs-HIP spread)."""
+    """The same run continued to 2000 steps (the oracle's: ~1-3 h of CPU each in the build container, make_train_traj.py): from
+    ~1000 steps on the held-out PSNR has no steady slope left and wanders by a dB between checkpoints, so single checkpoints say
+    little.  Statistic per run: the MEAN PSNR over steps 1000 / 1500 / 2000.  Two samples: five HIP runs (weight-gradient sums in
+    five orders) against the oracle's four (batch rows in four orders): |difference of the sample means| <= 2 standard errors AND
+    <= 0.75 dB whatever the spreads."""
     g = golden("train_traj")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_train_traj as T
-    steps_at = [int(x) for x in g["eval_steps"]]
+    oracle_runs, n_or = _oracle_runs(golden)
+    assert n_or >= 4, "the oracle's summation-order variants (tests/golden/train_traj_v*.npz) are missing"
+    steps_at = sorted(oracle_runs)
     assert steps_at == [0] + list(T.EVAL_AT) and steps_at[-1] == T.LONG_STEPS
-    oracle = {s: float(p) for s, p in zip(steps_at, g["eval_psnr"])}
     late = [s for s in T.EVAL_AT if s >= 1000]
-    runs = {b: _run_trajectory(None, T.LONG_STEPS, T.EVAL_AT, max_wgs=b)[1] for b in (None, 192, 128)}
-    mean = lambda ev: float(np.mean([ev[s] if not isinstance(ev[s], tuple) else ev[s][0] for s in late]))
-    means = {b: mean(ev) for b, ev in runs.items()}
-    want = mean(oracle)
-    spread = max(means.values()) - min(means.values())
-    bound = max(0.05, 1.5 * spread)
-    gap = abs(means[None] - want)
+    oracle_means = [float(np.mean([oracle_runs[s][k] for s in late])) for k in range(n_or)]
+    runs = {b: _run_trajectory(None, T.LONG_STEPS, T.EVAL_AT, max_wgs=b)[1] for b in plan_budgets()}
+    means = {b: float(np.mean([ev[s][0] for s in late])) for b, ev in runs.items()}
+    gap, bound, ok = _two_sample(list(means.values()), oracle_means, cap=0.75)
     with capsys.disabled():
-        print(f"\n[plateau] held-out PSNR (dB) at steps {list(T.EVAL_AT)}: oracle " + ", ".join(f"{oracle[s]:.3f}" for s in T.EVAL_AT))
+        print(f"\n[plateau] held-out PSNR (dB) at steps {list(T.EVAL_AT)}")
+        for k in range(n_or):
+            print(f"  oracle run {k}: " + ", ".join(f"{oracle_runs[s][k]:.3f}" for s in T.EVAL_AT) + f" | mean of {late}: {oracle_means[k]:.3f}")
         for b, ev in runs.items():
             print(f"  HIP, wgrad plan budget {b or 'default'}: " + ", ".join(f"{ev[s][0]:.3f}" for s in T.EVAL_AT) + f" | mean of {late}: {means[b]:.3f}")
-        print(f"  gap vs spread | oracle mean {want:.3f} | HIP-vs-HIP spread {spread:.3f} dB | HIP(default)-vs-oracle gap {gap:.3f} dB | "
-              f"bound max(0.05, 1.5 x spread) = {bound:.3f} dB; purity at {T.LONG_STEPS}: HIP {runs[None][T.LONG_STEPS][1]:.4f}, "
-              f"oracle {float(g['eval_purity'][-1]):.4f}")
-    assert gap <= bound, (means, want)
+        print(f"  two samples | oracle mean {np.mean(oracle_means):.3f} sd {np.std(oracle_means, ddof=1):.3f} | HIP mean {np.mean(list(means.values())):.3f} "
+              f"sd {np.std(list(means.values()), ddof=1):.3f} | |difference of means| {gap:.3f} dB <= 2 SE = {bound:.3f} dB and <= 0.75 dB; "
+              f"purity at {T.LONG_STEPS}: HIP {runs[None][T.LONG_STEPS][1]:.4f}, oracle {float(g['eval_purity'][-1]):.4f}")
+    assert ok, (gap, bound, means, oracle_means)
     assert abs(runs[None][T.LONG_STEPS][1] - float(g["eval_purity"][-1])) <= 0.02
