@@ -18,7 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*flags, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.pop("DMNERF_FORCE_COLLECTIVES", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_world1.py"), *flags], capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=ROOT)
