@@ -38,6 +38,8 @@ def get_rays_k(H, W, K, c2w, row0=0, nrows=None):
     c = np.ascontiguousarray(c)
     rays_o = torch.empty(nrows, W, 3, dtype=torch.float32, device=dev)
     rays_d = torch.empty(nrows, W, 3, dtype=torch.float32, device=dev)
+    if nrows == 0:                                   # an empty band (more ranks than rows): nothing to generate
+        return rays_o, rays_d
     _lib.check(_lib.load().dmnerf_raygen(H, W, intr.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p),
                                          int(row0), nrows, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.stream()), "dmnerf_raygen")
     return rays_o, rays_d

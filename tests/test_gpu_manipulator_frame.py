@@ -112,12 +112,14 @@ def _whole_and_bands(worlds, seed=11):
 def test_frame_is_bit_identical_for_every_world_size_including_the_device_draws():
     """Default draws (the device generator; ``manipulator`` resamples with det=False at evaluation, manipulator.py:148,170,187):
     the bands of worlds 2, 7 (uneven: 2 2 2 2 2 1 1 rows) and 8 (ranks owning 1 or 2 rows of 64 rays: fractions of a 160-ray chunk)
-    concatenate to exactly the single-process frame, and every rank's generator ends where the single process's ends."""
-    r = _whole_and_bands((2, 7, 8))
-    for world in (2, 7, 8):
+    concatenate to exactly the single-process frame, and every rank's generator ends where the single process's ends; so do the
+    bands of a world with more ranks than rows (empty bands still make every chunk's draws)."""
+    r = _whole_and_bands((2, 7, 8, 16))                                         # (16 ranks for 12 rows: four ranks own NO row)
+    for world in (2, 7, 8, 16):
         for k in range(4):
             got = torch.cat([b[k] for b in r[world]], 0)
             assert torch.equal(got, r["whole"][k]), (world, k)
+    assert [b[0].shape[0] for b in r[16]] == [1] * 12 + [0] * 4
 
 
 def _worker(rank, world, port, q):
