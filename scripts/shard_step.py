@@ -1,6 +1,7 @@
 """GPU: N optimisation steps at a given batch (default: the 384-ray shard of an 8-way split), for a rocprofv3 kernel trace.
     rocprofv3 --kernel-trace --stats -d out -- python scripts/shard_step.py 384 40
-Prints the wall ms per step; ``DMNERF_OVERLAP_BWD`` = 0 / 1 selects one or two backward streams."""
+Prints the wall ms per step; ``DMNERF_OVERLAP_BWD`` = 0 / 1 selects one or two backward streams, ``DMNERF_FLAT_ADAM=1`` the extension
+optimizer instead of torch.optim.Adam."""
 import os
 import sys
 import time
@@ -26,7 +27,11 @@ def main():
     rays = torch.stack([ro.reshape(-1, 3)[:n], rd.reshape(-1, 3)[:n]])
     z = H.z_val_sample(n, B.NEAR, B.FAR, B.S_COARSE, device=dev)
     mc.train(); mf.train()
-    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
+    if os.environ.get("DMNERF_FLAT_ADAM") == "1":             # the extension optimizer (dm_nerf_amd.optim.FlatAdam): update + re-pack = 2 launches
+        from dm_nerf_amd.optim import FlatAdam
+        opt = FlatAdam((mc, mf), lr=5e-4)
+    else:
+        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
     args = types.SimpleNamespace(perturb=1.0, N_importance=B.N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05)
     g = torch.Generator(device=dev).manual_seed(0)
     target = torch.rand(n, 3, device=dev, generator=g)
