@@ -34,7 +34,7 @@ class RenderArgs(ctypes.Structure):
 class RepackModel(ctypes.Structure):
     """``dmnerf_repack_model`` (include/dmnerf_hip.h)."""
     _fields_ = [("d_params_flat", c_vp), ("ins_num", c_int), ("d_flat_copy", c_vp), ("d_idx", c_vp), ("d_blob", c_vp),
-                ("d_idx_t", c_vp), ("d_blob_t", c_vp)]
+                ("d_idx_t", c_vp), ("d_blob_t", c_vp), ("d_f_pos", c_vp)]
 
 
 c_double = ctypes.c_double

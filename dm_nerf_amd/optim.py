@@ -26,6 +26,27 @@ import torch
 from . import _lib, autograd, weights
 
 
+_f_pos_cache = {}
+
+
+def _head_positions(ins_num, n_param, device):
+    """Where the W^T blob keeps each element of the head product F (the inverse of the transposed pack index on its entries that
+    address the F block behind the parameters): int32 [32768] on ``device``, or None if an element does not occur exactly once."""
+    key = (int(ins_num), str(device))
+    if key not in _f_pos_cache:
+        import numpy as np
+        idx = weights.pack_index_t_host(ins_num)
+        where = np.nonzero(idx >= n_param)[0]
+        src = idx[where] - n_param
+        pos = None
+        if len(where) == weights.HEAD_F_FLOATS and len(np.unique(src)) == weights.HEAD_F_FLOATS:
+            inv = np.empty(weights.HEAD_F_FLOATS, dtype=np.int32)
+            inv[src] = where.astype(np.int32)
+            pos = torch.from_numpy(inv).to(device)
+        _f_pos_cache[key] = pos
+    return _f_pos_cache[key]
+
+
 class FlatAdam:
     wants_arena = True           # distributed.sharded_train_step: let the backward write into the gradient arena at world 1 too
 
@@ -67,6 +88,7 @@ class FlatAdam:
                                   weight_decay=0, amsgrad=False, maximize=False, fused=None, foreach=None, differentiable=False)]
         self._idx = [(weights.pack_index(m.ins_num, dev, False), weights.pack_index(m.ins_num, dev, True)) for m in self.models]
         self._n_blob = [(int(lib.dmnerf_blob_floats(m.ins_num)), int(lib.dmnerf_blob_t_floats(m.ins_num))) for m in self.models]
+        self._f_pos = [_head_positions(m.ins_num, size, dev) for m, size in zip(self.models, self.sizes)]
         self._persist = None
         self.repack()                                                # the models' caches now describe the flat storage
 
@@ -137,7 +159,7 @@ class FlatAdam:
             flat_copy, blob, blob_t = out[:size], out[size:size + n_blob], out[size + n_blob:]
             src = self.flat[o:o + size]
             arr[i] = _lib.RepackModel(src.data_ptr(), int(m.ins_num), flat_copy.data_ptr(), self._idx[i][0].data_ptr(), blob.data_ptr(),
-                                      self._idx[i][1].data_ptr(), blob_t.data_ptr())
+                                      self._idx[i][1].data_ptr(), blob_t.data_ptr(), None if self._f_pos[i] is None else self._f_pos[i].data_ptr())
             keep.append((m, flat_copy, blob, blob_t))
             o += size
         _lib.check(lib.dmnerf_repack_train(arr, n_models, _lib.stream()), "dmnerf_repack_train")

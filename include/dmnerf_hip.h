@@ -493,6 +493,9 @@ typedef struct dmnerf_repack_model {
     float* d_blob;
     const int32_t* d_idx_t;
     float* d_blob_t;
+    const int32_t* d_f_pos;   /* nullable; 32768 entries: position in d_blob_t of F[i][j] (i * 256 + j), i.e. the inverse of d_idx_t on
+                               * its entries >= dmnerf_param_count (each occurs once).  Given, F is formed in its natural order
+                               * (coalesced) and scattered; NULL: every blob slot that holds an F element computes it itself. */
 } dmnerf_repack_model;
 int dmnerf_adam_step(float* d_params, const float* d_grads, float* d_exp_avg, float* d_exp_avg_sq, int64_t n,
                      double lr, const float* d_lr, double beta1, double beta2, double eps, int64_t* d_state2, void* stream);
