@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned long long done = atomicAdd((unsigned long long*)&a.state[1], 1ull) + 1ull;
+        // (no fence: the ticket only orders the READS of state[0], made at the top of every workgroup, before the one write below;
+        // an agent-scope release here would write back this XCD's L2 once per workgroup -- measured: 35 us instead of 12 for the pass)
+        const unsigned long long done = __hip_atomic_fetch_add((unsigned long long*)&a.state[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
         if (done == gridDim.x) {                                    // every workgroup has read state[0] (it read it before it finished)
             a.state[1] = 0;
             a.state[0] = k.t;
