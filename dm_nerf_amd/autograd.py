@@ -350,8 +350,9 @@ class overlapped_backward:
     hooks on the parameters are the caller's responsibility (none in this package).  ``distributed.sharded_train_step`` uses it;
     plain ``loss.backward()`` of the drop-in functions stays on one stream."""
 
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, join_on_exit=True):
         self.enabled = bool(enabled)
+        self.join_on_exit = bool(join_on_exit)     # False: leave the side-stream backward in flight (the next pass / _join_side() joins it)
 
     def __enter__(self):
         self.prev = _Overlap.active
@@ -360,7 +361,8 @@ class overlapped_backward:
         return self
 
     def __exit__(self, *exc):
-        _join_side()
+        if self.join_on_exit:
+            _join_side()
         _Overlap.active = self.prev
         _Overlap.seen = set()
         return False
