@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 INS, N, N_INS = 13, 131, 70          # 131 rays -> slices of 66 + 65; the last 70 rays carry labels (ScanNet convention)
 
 
-def _two_steps():
+def _two_steps(flat_adam=False):
     from dm_nerf_amd import distributed as D
     from dm_nerf_amd.networks import dm_nerf as M
     models = []
@@ -34,7 +34,11 @@ def _two_steps():
     g = torch.Generator().manual_seed(73)
     target = torch.rand(N, 3, generator=g).cuda()
     labels = torch.randint(0, 7, (N_INS,), generator=g).cuda()
-    opt = torch.optim.SGD([p for m in models for p in m.parameters()], lr=2e-2)
+    if flat_adam:                                           # the extension optimizer: update + re-pack on the (all-reduced) arena
+        from dm_nerf_amd.optim import FlatAdam
+        opt = FlatAdam(models, lr=5e-4)
+    else:
+        opt = torch.optim.SGD([p for m in models for p in m.parameters()], lr=2e-2)
     args = types.SimpleNamespace(perturb=1.0, N_importance=128, is_train=True, N_ins=N_INS, penalize=True, tolerance=0.05, deta_w=0.05)
     torch.manual_seed(7)
     torch.cuda.manual_seed(7)                               # the jitter stream: identical on every rank
@@ -51,28 +55,29 @@ def _two_steps():
     return losses, flat, nbytes, in_place
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, flat_adam=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _two_steps())
+        q.put((rank,) + _two_steps(flat_adam))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_sharded_training_step_equals_single_process():
+@pytest.mark.parametrize("flat_adam", [False, True])
+def test_two_rank_sharded_training_step_equals_single_process(flat_adam):
     assert torch.cuda.is_available(), "GPU tests need a MI355X"
-    want_losses, want, nb0, in_place0 = _two_steps()
-    assert nb0 == 0 and in_place0 is None
+    want_losses, want, nb0, in_place0 = _two_steps(flat_adam)
+    assert nb0 == 0 and (in_place0 is None or flat_adam)            # (FlatAdam owns an arena at world 1 too; nothing is all-reduced)
     start = torch.cat([v.reshape(-1) for seed in (71, 72) for v in O.make_weights(seed, INS, gain=1.7, sigma_bias=0.3).values()]).numpy()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, flat_adam)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in range(2)]
@@ -83,8 +88,12 @@ def test_two_rank_sharded_training_step_equals_single_process():
         assert in_place is True
         assert nbytes == 4 * want.size
         assert np.allclose(losses, want_losses, rtol=2e-5), (losses, want_losses)
-        assert np.abs(flat - want).max() <= 2e-6, np.abs(flat - want).max()
-    assert np.abs(want - start).max() >= 1e-3
+        # SGD: the update is linear in the gradient (2e-6 = lr x the f32 summation-order difference); Adam's first steps are
+        # sign-like (m / sqrt(v)): a gradient element that differs in its last bits moves the parameter by up to 2 lr
+        assert np.abs(flat - want).max() <= (2e-6 if not flat_adam else 2.1e-3), np.abs(flat - want).max()
+        if flat_adam:
+            assert np.mean(np.abs(flat - want) <= 2e-6) >= 0.98
+    assert np.abs(want - start).max() >= (1e-3 if not flat_adam else 9e-4)
     assert np.array_equal(res[0][2], res[1][2])
 
 
