@@ -63,12 +63,13 @@ class FlatAdam:
         self.sizes = [int(lib.dmnerf_param_count(m.ins_num)) for m in self.models]
         n = sum(self.sizes)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.params = []
+        self.params, self._names = [], []
         o = 0
         with torch.no_grad():
-            for m, size in zip(self.models, self.sizes):
+            for mi, (m, size) in enumerate(zip(self.models, self.sizes)):
                 o_m = o
-                for _, p in m.named_parameters():
+                for pname, p in m.named_parameters():
+                    self._names.append(f"models[{mi}].{pname}")
                     if p.dtype != torch.float32 or p.device != dev:
                         raise RuntimeError("FlatAdam: f32 parameters on one GPU")
                     view = self.flat[o:o + p.numel()].view_as(p)
@@ -110,20 +111,31 @@ class FlatAdam:
             self.param_groups[0]["lr"] = float(lr)
 
     def _grads(self):
-        """The flat gradient vector: the arena when autograd installed its views (the normal case), else gathered into it."""
+        """The flat gradient vector: the arena when autograd installed its views (the normal case), else gathered into it.
+        EVERY parameter must have a gradient: ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None (no moment update, its
+        own step count), which one pass over flat vectors with one step counter cannot reproduce -- so that case raises instead of
+        silently updating with a zero or a stale gradient."""
         a = self.arena
-        first, last = self.params[0].grad, self.params[-1].grad
         base = a.flat.data_ptr()
-        if first is not None and last is not None and first.data_ptr() == base \
-                and last.data_ptr() == base + 4 * (a.flat.numel() - last.numel()):
-            return a.flat                                            # (first and last view in place: the backward installed all of them)
+        ok, o, k = True, 0, 0
+        for size, m in zip(self.sizes, self.models):                 # the backward installs a model's 30 views together:
+            n_p = sum(1 for _ in m.parameters())                     # its first and last parameter tell
+            first, last = self.params[k].grad, self.params[k + n_p - 1].grad
+            ok = ok and first is not None and last is not None and first.data_ptr() == base + 4 * o \
+                and last.data_ptr() == base + 4 * (o + size - last.numel())
+            o += size
+            k += n_p
+        if ok:
+            return a.flat
         o = 0
         with torch.no_grad():
-            for p in self.params:                                    # gradients that came another way (accumulated, user-made)
+            for name_p, p in zip(self._names, self.params):          # gradients that came another way (accumulated, user-made)
                 n = p.numel()
                 if p.grad is None:
-                    a.flat[o:o + n].zero_()
-                elif p.grad.data_ptr() != base + 4 * o:
+                    raise RuntimeError(f"FlatAdam.step: parameter {name_p} has no gradient.  torch.optim.Adam would skip it (and keep "
+                                       "a step count of its own); FlatAdam updates all parameters in one pass -- use torch.optim.Adam "
+                                       "for steps that differentiate only some of them")
+                if p.grad.data_ptr() != base + 4 * o:
                     a.flat[o:o + n].copy_(p.grad.reshape(-1))
                 o += n
         return a.flat

@@ -229,3 +229,17 @@ def test_graphed_step_with_flat_adam_equals_eager_flat_adam():
     assert all(torch.equal(a, b) for a, b in zip(e_evals, g_evals))
     assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(eager.params, opt.params))
     assert int(opt.state2[0]) == 3 and not torch.equal(e_evals[0], e_evals[1])
+
+
+def test_flat_adam_refuses_a_step_with_missing_gradients():
+    """torch.optim.Adam skips parameters whose ``.grad`` is None; one pass over flat vectors cannot -- FlatAdam raises instead of
+    updating them with a zero or stale gradient (e.g. a step that differentiated only the coarse model)."""
+    from dm_nerf_amd.optim import FlatAdam
+    ms = models()
+    own = FlatAdam(ms)
+    own.zero_grad()
+    for p in ms[0].parameters():
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(RuntimeError, match=r"models\[1\]\.mlps\.0\.weight has no gradient"):
+        own.step()
+    assert int(own.state2[0]) == 0
