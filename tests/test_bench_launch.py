@@ -20,5 +20,7 @@ def test_plain_bench_command_spawns_n_ranks_and_relays_their_failure():
                        capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert p.returncode != 0
     assert p.stdout.strip() == ""
-    assert p.stderr.count("AssertionError: bench.py needs MI355X GPUs") == 2, p.stderr[-2000:]      # one per launched rank
-    assert "local_rank: 1" in p.stderr or "rank      : 1" in p.stderr
+    # (the launcher stops the surviving rank with SIGTERM as soon as one fails: the message appears once or twice, the report
+    # names both ranks either way)
+    assert p.stderr.count("AssertionError: bench.py needs MI355X GPUs") >= 1, p.stderr[-2000:]
+    assert "local_rank: 0" in p.stderr and "local_rank: 1" in p.stderr, p.stderr[-2000:]
