@@ -42,8 +42,8 @@ struct GemmArgs {
 // AK / BK: the operand's unit-stride dimension is k (compile-time: the index arithmetic of the loader folds away)
 template <bool AK, bool BK>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
-    __shared__ float As[KC][TM + 4];
-    __shared__ float Bs[KC][TN + 4];
+    __shared__ float As[KC][TM + 1];       // (odd row length: the k-fast operand's stores -- consecutive lanes, consecutive rows -- hit 32 banks)
+    __shared__ float Bs[KC][TN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i0 = (int64_t)blockIdx.x * TM;
     const int j0 = blockIdx.y * TN;
@@ -60,28 +60,61 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     // Loader: TM x KC elements per operand and chunk, LPT per thread; the thread index runs along the operand's unit-stride
     // dimension (coalesced 4-byte loads whatever the form: NT forward, NN data gradient, TN weight gradient).  The NEXT
     // chunk is fetched into registers before the current chunk's 64 MFMAs per wave, so the global latency hides under them.
+    // Every element slot keeps a 32-bit OFFSET from the tile's (wave-uniform) base pointer -- row / column clamped once, before the
+    // loop -- and the base advances by one chunk per trip: a full chunk costs one load per element and no vector ALU (the first
+    // version re-derived row, column, both clamps and two 64-bit products per element and chunk, ~400 VALU instructions per
+    // thread against the chunk's 64 MFMAs: 0.27-0.37 of the matrix pipe).  Only a K range's partial last chunk is masked.
     constexpr bool a_kfast = AK, b_kfast = BK;
     float ra[LPT], rb[LPT];
-    auto fetch = [&](int64_t k0) {
+    int oa[LPT], ob[LPT];
+    const int64_t i_last = a.I - 1 - i0;                               // last valid row / column of this tile, tile-relative
+    const int j_last = a.J - 1 - j0;
+#pragma unroll
+    for (int e = 0; e < LPT; ++e) {
+        const int idx = e * 256 + tid;
+        const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx >> 5) : (idx & (TM - 1));
+        // rows / columns beyond the matrix are read from the clamped (valid) position: they only feed output elements the
+        // epilogue never stores
+        oa[e] = (int)(((ii < i_last ? ii : i_last) * a.sai + kk * a.sak) * 4);                  // bytes
+        const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
+        ob[e] = (int)((kb2 * a.sbk + (int64_t)(jj < j_last ? jj : j_last) * a.sbj) * 4);
+    }
+    // MUBUF loads: a descriptor on the tile's (wave-uniform) base + the element's constant 32-bit byte offset in a VGPR; the base
+    // moves by SALU arithmetic, so the offsets never leave 32 bits whatever the size of the matrices
+    const float* base_a = a.A + i0 * a.sai + kb * a.sak;
+    const float* base_b = a.B + kb * a.sbk + (int64_t)j0 * a.sbj;
+    const int64_t step_a = (int64_t)KC * a.sak, step_b = (int64_t)KC * a.sbk;
+    auto rsrc_of = [](const float* p) {
+        const unsigned long long q = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+    };
+    auto ld = [](__amdgpu_buffer_rsrc_t r, int byte_off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0)); };
+    auto fetch_full = [&]() {
+        const __amdgpu_buffer_rsrc_t r_a = rsrc_of(base_a), r_b = rsrc_of(base_b);
+#pragma unroll
+        for (int e = 0; e < LPT; ++e) {
+            ra[e] = ld(r_a, oa[e]);
+            rb[e] = ld(r_b, ob[e]);
+        }
+        base_a += step_a;
+        base_b += step_b;
+    };
+    auto fetch_tail = [&](int rem) {                                    // the K range's partial last chunk: rem < KC valid positions
+        const __amdgpu_buffer_rsrc_t r_a = rsrc_of(base_a), r_b = rsrc_of(base_b);
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
             const int idx = e * 256 + tid;
-            const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx >> 5) : (idx & (TM - 1));
-            // Branch-free and mask-free: rows / columns beyond the matrix are read from the clamped (valid) position -- they
-            // only feed output elements the epilogue never stores --, and positions beyond the K range are multiplied by 0
-            // (a float factor, not a lane mask kept alive across the MFMA loop: 32 of those spilled SGPRs).
-            const int64_t gi = i0 + ii, gk = k0 + kk;
-            const float fa = gk < ke ? 1.f : 0.f;
-            ra[e] = a.A[(gi < a.I ? gi : a.I - 1) * a.sai + (gk < ke ? gk : ke - 1) * a.sak] * fa;
-            const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
-            const int gj = j0 + jj;
-            const int64_t gk2 = k0 + kb2;
-            const float fb = gk2 < ke ? 1.f : 0.f;
-            rb[e] = a.B[(gk2 < ke ? gk2 : ke - 1) * a.sbk + (int64_t)(gj < a.J ? gj : a.J - 1) * a.sbj] * fb;
+            const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7);
+            const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7);
+            // positions beyond the K range: read the last valid one (always inside the matrix), contribute 0
+            const float va = ld(r_a, kk < rem ? oa[e] : oa[e] - (int)((kk - rem + 1) * a.sak) * 4);
+            const float vb = ld(r_b, kb2 < rem ? ob[e] : ob[e] - (int)((kb2 - rem + 1) * a.sbk) * 4);
+            ra[e] = kk < rem ? va : 0.f;
+            rb[e] = kb2 < rem ? vb : 0.f;
         }
     };
-    if (kb < ke) fetch(kb);
-    for (int64_t k0 = kb; k0 < ke; k0 += KC) {
+    auto to_lds = [&]() {
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
             const int idx = e * 256 + tid;
@@ -90,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
             const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
             Bs[kb2][jj] = rb[e];
         }
-        __syncthreads();
-        if (k0 + KC < ke) fetch(k0 + KC);
+    };
+    auto chunk_mfma = [&]() {
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
             const int kr = 2 * s + (lane >> 5), c = lane & 31;
@@ -102,6 +135,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+    };
+    const int64_t span = ke > kb ? ke - kb : 0;
+    const int64_t n_full = span / KC;
+    const int rem = (int)(span % KC);
+    if (n_full > 0) fetch_full();
+    else if (rem) fetch_tail(rem);
+    for (int64_t c = 0; c < n_full; ++c) {
+        to_lds();
+        __syncthreads();
+        if (c + 1 < n_full) fetch_full();
+        else if (rem) fetch_tail(rem);
+        chunk_mfma();
+        __syncthreads();
+    }
+    if (rem) {
+        to_lds();
+        __syncthreads();
+        chunk_mfma();
         __syncthreads();
     }
     // epilogue: lane holds column j = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32 x 32 tile
