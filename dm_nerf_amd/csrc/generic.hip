@@ -3,7 +3,7 @@
 // create_nerf (config.py:126-138) passes args.netdepth / args.netwidth / args.multires / args.multires_views through; no
 // shipped config changes them (D = 8, W = 256, multires 10 / 4 everywhere), and the register-chained kernels of
 // mlp_fwd_impl.h / mlp_bwd.hip / wgrad.hip are built around 256 = 8 accumulator blocks.  So that such a configuration
-// RUNS rather than raises, this file provides the layer-by-layer path -- slower (one pass over HBM per layer, 0.27-0.37 of
+// RUNS rather than raises, this file provides the layer-by-layer path -- slower (one pass over HBM per layer, 0.31-0.46 of
 // the matrix pipe measured), same arithmetic class (f32 MFMA, an fmaf chain over k ascending per output):
 //   gemm_kernel       C[i][j] (op)= sum_k A(i,k) B(k,j)  with arbitrary element strides for both operands, so the three
 //                     products of a linear layer are one kernel:  forward  Y = X W^T  (+ bias, ReLU),
