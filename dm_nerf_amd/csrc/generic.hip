@@ -72,11 +72,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int e = 0; e < LPT; ++e) {
         const int idx = e * 256 + tid;
-        const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx >> 5) : (idx & (TM - 1));
+        const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx / KC) : (idx & (TM - 1));
         // rows / columns beyond the matrix are read from the clamped (valid) position: they only feed output elements the
         // epilogue never stores
         oa[e] = (int)(((ii < i_last ? ii : i_last) * a.sai + kk * a.sak) * 4);                  // bytes
-        const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
+        const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx / KC) : (idx & (TN - 1));
         ob[e] = (int)((kb2 * a.sbk + (int64_t)(jj < j_last ? jj : j_last) * a.sbj) * 4);
     }
     // MUBUF loads: a descriptor on the tile's (wave-uniform) base + the element's constant 32-bit byte offset in a VGPR; the base
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < LPT; ++e) {
             const int idx = e * 256 + tid;
-            const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx >> 5) : (idx & (TM - 1));
+            const int kk = a_kfast ? (idx & (KC - 1)) : (idx >> 7), ii = a_kfast ? (idx / KC) : (idx & (TM - 1));
             As[kk][ii] = ra[e];
-            const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx >> 5) : (idx & (TN - 1));
+            const int kb2 = b_kfast ? (idx & (KC - 1)) : (idx >> 7), jj = b_kfast ? (idx / KC) : (idx & (TN - 1));
             Bs[kb2][jj] = rb[e];
         }
     };
