@@ -47,12 +47,12 @@ B16_MFMA_PEAK_TFLOPS = 2500.0                          # same guide: dense bf16 
 HAVE_F16X2 = False                                     # set in main(): the library exports the f16x2 split kernels
 HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0      # same guide: HBM3E spec; the rate its own streaming benchmark measures
 # HBM bytes per SAMPLE of the three training kernels at ins_num 13, from the committed rocprofv3 PMC passes of the 4096-ray step
-# (profiles/r04/pmc_train_r04f.txt: separate --pmc runs, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, fine launch = 786 432 samples;
+# (profiles/r05/pmc_train_r05.txt, identical to r04's: separate --pmc runs, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, fine launch = 786 432 samples;
 # the f16x2 kernels move the same f32 rows: their counters agree within 1 %; bf16x3 saves the same rows, not separately measured).
 # Counters cannot be read from inside the process, so these are NOT measured in this run: they turn a kernel time measured
 # here into a GB/s figure, so that a kernel's `bound` says which roof it is actually closer to.
-TRAIN_HBM_BYTES_PER_SAMPLE = {"mlp_fwd_train": (2 * 2.9427e5 + 7.6308e6) * 1e3 / 786432, "mlp_bwd_data": (2 * 3.3843e5 + 7.1332e6) * 1e3 / 786432,
-                              "mlp_bwd_weights": (2 * 0.75 * 2 * 5.5509e6 + 0.75 * 2 * 63148) * 1e3 / 786432}
+TRAIN_HBM_BYTES_PER_SAMPLE = {"mlp_fwd_train": (2 * 2.9427e5 + 7.6308e6) * 1e3 / 786432, "mlp_bwd_data": (2 * 3.3592e5 + 7.1332e6) * 1e3 / 786432,
+                              "mlp_bwd_weights": (2 * 0.75 * 2 * 5.5508e6 + 0.75 * 2 * 63148) * 1e3 / 786432}
 
 
 def mac_counts(ins_num):
@@ -252,7 +252,7 @@ def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, 
                 # one in less than half the time: it sits at 0.74 of the HBM spec and 0.38 of the 16-bit MFMA roof -- HBM-bound)
                 gbs = TRAIN_HBM_BYTES_PER_SAMPLE[tag] * m_fine / (k_ms * 1e-3) / 1e9
                 entry["hbm"] = {"achieved_GBs": gbs, "frac_of_spec_8TBs": gbs / HBM_PEAK_GBS, "frac_of_guide_measured_6.29TBs": gbs / HBM_ACHIEVABLE_GBS,
-                                "bytes_per_sample": TRAIN_HBM_BYTES_PER_SAMPLE[tag], "bytes_source": "profiles/r04/pmc_train_r04f.txt",
+                                "bytes_per_sample": TRAIN_HBM_BYTES_PER_SAMPLE[tag], "bytes_source": "profiles/r05/pmc_train_r05.txt",
                                 "traffic_measured_in_this_run": False}
                 if gbs / HBM_PEAK_GBS > entry["frac"]:
                     entry.update(bound="hbm", unit="GB/s", achieved=gbs, peak=HBM_PEAK_GBS, frac=gbs / HBM_PEAK_GBS,
