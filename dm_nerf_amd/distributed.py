@@ -63,6 +63,26 @@ def _active(world):
     return world > 1 or (force_collectives() and dist.is_available() and dist.is_initialized())
 
 
+# Tally of the collectives this module issued (host-side counters, no synchronisation): what a bench line reports as
+# ``collectives_per_step`` / bytes so that a multi-rank record says what crossed the links, not only how long it took.
+_tally = {"count": 0, "bytes": 0, "kinds": {}}
+
+
+def _count(kind, t):
+    _tally["count"] += 1
+    _tally["bytes"] += t.numel() * t.element_size()
+    _tally["kinds"][kind] = _tally["kinds"].get(kind, 0) + 1
+
+
+def collective_tally(reset=False):
+    """``{"count", "bytes", "kinds"}`` of the collectives issued through this module since the last reset (``bytes`` = the size of
+    each call's local send buffer; an all-gather delivers ``world`` times that to every rank)."""
+    out = {"count": _tally["count"], "bytes": _tally["bytes"], "kinds": dict(_tally["kinds"])}
+    if reset:
+        _tally.update(count=0, bytes=0, kinds={})
+    return out
+
+
 def row_band(H, rank, world):
     """Contiguous band of image rows of rank ``rank``: (row0, nrows); bands differ by at most one row."""
     base, rem = divmod(int(H), int(world))
@@ -91,9 +111,11 @@ def all_gather_cat(t, sizes=None):
         if tensor_form:
             out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(out, x)          # one RCCL all-gather
+            _count("all_gather", x)
             return out
         parts = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(parts, x)
+        _count("all_gather", x)
         return torch.cat(parts, 0)
 
     if sizes is None or len(set(sizes)) == 1:
@@ -119,6 +141,7 @@ def allreduce_grads(models, average=False, arena=None):
         return 0
     if arena is not None and arena.resident():
         dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM)
+        _count("all_reduce_grads", arena.flat)
         if average:
             arena.flat /= world
         return arena.flat.numel() * arena.flat.element_size()
@@ -142,6 +165,7 @@ def allreduce_grads(models, average=False, arena=None):
     has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=wide, device=params[0].device)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(wide) for p in params] + [has])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _count("all_reduce_grads", flat)
     n_grad = flat.numel() - len(params)
     any_rank = flat[n_grad:].tolist()
     if average:
@@ -200,6 +224,7 @@ def allreduce_sums(t):
     rank, world = world_info()
     if _active(world):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _count("all_reduce_sums", t)
     return t
 
 
