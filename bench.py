@@ -707,11 +707,11 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
     one(512)                                              # warm-up (thread pools, page faults)
     t_small, _ = one(512)                                 # calibration
     n = N_RAYS
-    est = t_small * n / 512
-    reps = int(min(3, (seconds - 2.0 * t_small) // (est * 1.03)))     # as many full-size renders (up to 3) as fit the budget
-    if reps <= 0:
+    est = t_small * n / 512 * 0.9                         # (a 512-ray render carries more fixed cost per ray than a 4096-ray one)
+    if est > seconds:                                     # a host too slow for one full-size render inside the budget: a smaller sample
         n = int(max(512, min(N_RAYS, seconds / (t_small / 512) // 512 * 512)))
-        reps = 1
+        est = t_small * n / 512
+    reps = int(max(1, min(3, (seconds - 2.0 * t_small) // est)))     # as many renders of the sample (up to 3) as fit the budget
     runs = [one(n) for _ in range(reps)]
     ts = [t for t, _ in runs]
     dt = statistics.median(ts)

@@ -237,6 +237,13 @@ class GradArena:
     def begin_step(self):
         self.free = [True] * len(self.models)
 
+    def hold(self):
+        """No slot is handed out until the next ``begin_step()``: the backward launches write scratch vectors and autograd ADDS
+        them into the installed ``p.grad`` tensors.  For steps whose gradients must ACCUMULATE into the views that are already
+        installed (``zero_grad(set_to_none=False)``, several backward passes per step): a launch that took the slot would
+        overwrite, in place, the very memory ``p.grad`` views, and AccumulateGrad would then add that memory onto itself."""
+        self.free = [False] * len(self.models)
+
     def take(self, i):
         if self.free[i]:
             self.free[i] = False
@@ -366,6 +373,13 @@ class overlapped_backward:
         _Overlap.active = self.prev
         _Overlap.seen = set()
         return False
+
+
+def join_side():
+    """Public form of ``_join_side``: anything that reads gradients on the current stream after an
+    ``overlapped_backward(join_on_exit=False)`` -- an optimizer step, a gradient all-reduce -- calls this first (no-op when nothing
+    is in flight)."""
+    _join_side()
 
 
 def _join_side():

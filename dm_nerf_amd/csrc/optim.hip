@@ -61,7 +61,10 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     __shared__ AdamScalars sk;
     if (threadIdx.x == 0) {                                         // the scalar factors once per workgroup (two double pow)
-        const long long t = a.state[0] + 1;
+        // (agent-scope atomic load: the step count is written by ONE workgroup of the previous launch on whatever XCD it ran; this
+        // read must not be served from a stale line of this XCD's L2 whatever the cache policy of the allocation -- it does not
+        // lean on the kernel-boundary write-back / invalidate.  One access per workgroup.)
+        const long long t = __hip_atomic_load(&a.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         const double lr = a.d_lr ? (double)a.d_lr[0] : a.lr;
         const double bc1 = 1.0 - pow(a.beta1, (double)t), bc2 = 1.0 - pow(a.beta2, (double)t);
         sk.neg_step = (float)(lr / bc1 * -1.0);                     // adam.py: step_size = (lr / bias_correction1) * -1
@@ -85,12 +88,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // (no fence: the ticket only orders the READS of state[0], made at the top of every workgroup, before the one write below;
-        // an agent-scope release here would write back this XCD's L2 once per workgroup -- measured: 35 us instead of 12 for the pass)
+        // (no release fence: the ticket only orders the READS of state[0], made at the top of every workgroup, before the one write
+        // below; an agent-scope release here would write back this XCD's L2 once per workgroup -- measured: 35 us instead of 12 for
+        // the pass.  This workgroup's own read has RETURNED by now: its value went through `sk` in LDS and the barrier above.
+        // All three accesses to `state` are agent-scope atomics, so none of them is a plain load / store racing across XCD L2s.)
         const unsigned long long done = __hip_atomic_fetch_add((unsigned long long*)&a.state[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
         if (done == gridDim.x) {                                    // every workgroup has read state[0] (it read it before it finished)
-            a.state[1] = 0;
-            a.state[0] = k.t;
+            __hip_atomic_store(&a.state[1], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.state[0], k.t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -139,6 +139,9 @@ def allreduce_grads(models, average=False, arena=None):
     rank, world = world_info()
     if not _active(world):
         return 0
+    if arena is not None:
+        from . import autograd
+        autograd.join_side()                             # the gradients must be complete on this stream before they are reduced
     if arena is not None and arena.resident():
         dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM)
         _count("all_reduce_grads", arena.flat)

@@ -98,11 +98,20 @@ class FlatAdam:
         if set_to_none:
             for p in self.params:
                 p.grad = None
+            self.arena.begin_step()                                  # the next backward writes the arena slots in place
+            return
+        # Keep the gradient tensors and zero them: the next backward ACCUMULATES into them.  They are (normally) views of the arena,
+        # so the arena must NOT hand its slots out again -- a backward writing a slot in place would be added onto itself by
+        # AccumulateGrad (2 g) -- the launches use scratch vectors instead and autograd adds those into the zeroed views.
+        have = False
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+                have = True
+        if have:
+            self.arena.hold()
         else:
-            for p in self.params:
-                if p.grad is not None:
-                    p.grad.zero_()
-        self.arena.begin_step()
+            self.arena.begin_step()
 
     def set_lr(self, lr):
         if self.capturable:
@@ -117,16 +126,8 @@ class FlatAdam:
         silently updating with a zero or a stale gradient."""
         a = self.arena
         base = a.flat.data_ptr()
-        ok, o, k = True, 0, 0
-        for size, m in zip(self.sizes, self.models):                 # the backward installs a model's 30 views together:
-            n_p = sum(1 for _ in m.parameters())                     # its first and last parameter tell
-            first, last = self.params[k].grad, self.params[k + n_p - 1].grad
-            ok = ok and first is not None and last is not None and first.data_ptr() == base + 4 * o \
-                and last.data_ptr() == base + 4 * (o + size - last.numel())
-            o += size
-            k += n_p
-        if ok:
-            return a.flat
+        if a.resident():                                             # ALL views checked (a frozen / replaced middle tensor must not
+            return a.flat                                            # pass for the arena: ADVICE r05), ~60 pointer compares per step
         o = 0
         with torch.no_grad():
             for name_p, p in zip(self._names, self.params):          # gradients that came another way (accumulated, user-made)
@@ -142,6 +143,7 @@ class FlatAdam:
 
     def step(self):
         lib = _lib.load()
+        autograd.join_side()                                         # a side-stream backward left in flight (join_on_exit=False) first
         g = self._grads()
         grp = self.param_groups[0]
         lr = grp["lr"]

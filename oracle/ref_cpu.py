@@ -439,45 +439,58 @@ def manipulator_nerf(rays, sd, N_samples=None, near=None, far=None, z_vals=None)
     return torch.reshape(raw, list(pts.shape[:-1]) + [raw.shape[-1]]), z_vals
 
 
-def manipulator(sd_coarse, sd_fine, ori_rays, f_tar_rays, N_samples, N_importance, near, far, target_labels, us=None):
+def manipulator(sd_coarse, sd_fine, ori_rays, f_tar_rays, N_samples, N_importance, near, far, target_labels, us=None, net=None, probe=None):
     """``manipulator`` (networks/manipulator.py:137-205).  ``us``: optional list of the ``2 + T`` uniform draws
-    [N, N_importance] in the order the reference makes them (original, each target, original again)."""
+    [N, N_importance] in the order the reference makes them (original, each target, original again).
+    Test hooks (both default to the plain restatement): ``net`` replaces ``manipulator_nerf`` (same signature: another evaluation of
+    the same network, e.g. in float64); ``probe(event, **tensors)`` is called with the inputs of every DISCRETE decision of the chain
+    -- the three-plus-T resamplings (``"resample"``: bins, weights, u) and the two exchanger rounds (``"exchange"``: the raws and
+    accumulated object maps) -- so that a test can tell which rays sit next to a threshold (oracle/manip_margins.py)."""
     us = list(us) if us is not None else None
     draw = lambda: us.pop(0) if us is not None else None
-    ori_raw, ori_z = manipulator_nerf(ori_rays, sd_coarse, N_samples, near, far)
+    net = net or manipulator_nerf
+    probe = probe or (lambda event, **kw: None)
+
+    def resample(tag, mid, w, n, u):
+        probe("resample", tag=tag, bins=mid, weights=w, u=u)
+        return sample_pdf(mid, w, n, u=u)
+    ori_raw, ori_z = net(ori_rays, sd_coarse, N_samples, near, far)
     _, ori_w, _, _ = manipulator_render(ori_raw, ori_z, ori_rays[1])
     ori_mid = .5 * (ori_z[..., 1:] + ori_z[..., :-1])
-    ori_zs = sample_pdf(ori_mid, ori_w[..., 1:-1], N_importance, u=draw())
+    ori_zs = resample("ori", ori_mid, ori_w[..., 1:-1], N_importance, draw())
     ori_z_full, _ = torch.sort(torch.cat([ori_z, ori_zs], dim=-1), dim=-1)
-    ori_raw_full, _ = manipulator_nerf(ori_rays, sd_fine, N_samples, near, far, z_vals=ori_z_full)
+    ori_raw_full, _ = net(ori_rays, sd_fine, N_samples, near, far, z_vals=ori_z_full)
     _, _, _, ori_ins_accum = manipulator_render(ori_raw_full, ori_z_full, ori_rays[1])
     tar_raws, f_tar_z, f_tar_zs, tar_ins_accums = [], [], [], []
     tar_rgb = tar_ins_accum = None
-    for tar_rays in f_tar_rays:
-        tar_raw, tar_z = manipulator_nerf(tar_rays, sd_coarse, N_samples, near, far)
+    for k, tar_rays in enumerate(f_tar_rays):
+        tar_raw, tar_z = net(tar_rays, sd_coarse, N_samples, near, far)
         tar_raws.append(tar_raw); f_tar_z.append(tar_z)
         tar_rgb, tar_w, _, _ = manipulator_render(tar_raw, tar_z, tar_rays[1])
         tar_mid = .5 * (tar_z[..., 1:] + tar_z[..., :-1])
-        tar_zs = sample_pdf(tar_mid, tar_w[..., 1:-1], N_importance, u=draw())
+        tar_zs = resample(f"tar{k}", tar_mid, tar_w[..., 1:-1], N_importance, draw())
         tar_z_full, _ = torch.sort(torch.cat([tar_z, tar_zs], dim=-1), dim=-1)
-        tar_raw_full, _ = manipulator_nerf(tar_rays, sd_fine, z_vals=tar_z_full)
+        tar_raw_full, _ = net(tar_rays, sd_fine, z_vals=tar_z_full)
         _, _, _, tar_ins_accum = manipulator_render(tar_raw_full, tar_z_full, tar_rays[1])
         f_tar_zs.append(tar_zs); tar_ins_accums.append(tar_ins_accum)
+    probe("exchange", tag="coarse", ori_raw=ori_raw, tar_raws=tar_raws, ori_acc=ori_ins_accum, tar_accs=tar_ins_accums, labels=target_labels)
     ori_raw, _, _, _ = exchanger(ori_raw, tar_raws, ori_ins_accum, tar_ins_accums, target_labels)
     _, ori_w, _, _ = manipulator_render(ori_raw, ori_z, ori_rays[1])
-    ori_zs = sample_pdf(.5 * (ori_z[..., 1:] + ori_z[..., :-1]), ori_w[..., 1:-1], N_importance, u=draw())
+    ori_zs = resample("edited", .5 * (ori_z[..., 1:] + ori_z[..., :-1]), ori_w[..., 1:-1], N_importance, draw())
     f_tar_zs = torch.cat(f_tar_zs, dim=-1)
     ori_z, _ = torch.sort(torch.cat([ori_z, ori_zs, f_tar_zs], dim=-1), dim=-1)
     for idx, tar_rays in enumerate(f_tar_rays):
-        ori_raw, ori_z = manipulator_nerf(ori_rays, sd_fine, z_vals=ori_z)
+        ori_raw, ori_z = net(ori_rays, sd_fine, z_vals=ori_z)
         tar_z, _ = torch.sort(torch.cat([f_tar_z[idx], ori_zs, f_tar_zs], dim=-1), dim=-1)
-        tar_raws[idx], _ = manipulator_nerf(tar_rays, sd_fine, z_vals=tar_z)
+        tar_raws[idx], _ = net(tar_rays, sd_fine, z_vals=tar_z)
+    probe("exchange", tag="fine", ori_raw=ori_raw, tar_raws=tar_raws, ori_acc=ori_ins_accum, tar_accs=tar_ins_accums, labels=target_labels)
     ori_raw, _, _, _ = exchanger(ori_raw, tar_raws, ori_ins_accum, tar_ins_accums, target_labels)
     final_rgb, _, _, final_ins = manipulator_render(ori_raw, ori_z, ori_rays[1])
     return final_rgb, final_ins, tar_rgb, tar_ins_accum
 
 
-def manipulate_frame(sd_coarse, sd_fine, H, W, K, ori_pose, trans, N_test, N_samples, N_importance, near, far, target_labels, us=None):
+def manipulate_frame(sd_coarse, sd_fine, H, W, K, ori_pose, trans, N_test, N_samples, N_importance, near, far, target_labels, us=None,
+                     net=None, probe=None):
     """The per-pose body of ``manipulator_eval`` (networks/manipulator.py:230-274): original rays of ``ori_pose``, target rays of
     ``trans @ ori_pose`` (:235), the chunk loop of ``N_test`` rays with its ragged last chunk (:241-244) around ``manipulator``
     (one transformation: ``tar_batch_rays[None]``, :255), the four accumulations (:260-266) and the ``[H, W, .]`` reshape
@@ -495,7 +508,7 @@ def manipulate_frame(sd_coarse, sd_fine, H, W, K, ori_pose, trans, N_test, N_sam
         ori = torch.stack([ro[step:step + n], rd[step:step + n]], dim=0)
         tar = torch.stack([to[step:step + n], td[step:step + n]], dim=0)[None, ...]
         out = manipulator(sd_coarse, sd_fine, ori, tar, N_samples, N_importance, near, far, target_labels,
-                          us=None if us is None else us[c])
+                          us=None if us is None else us[c], net=net, probe=probe)
         for col, t in zip(cols, out):
             col.append(t)
     full = [torch.cat(col, dim=0) for col in cols]

@@ -11,10 +11,10 @@ cd $ROOT
 for w in $WHAT; do
   case $w in
     bench)   # the driver's command, byte for byte; stdout and stderr kept apart, wall time taken outside
-      t0=$(date +%s.%N)
+      t0=$(python3 -c "import time; print(time.time())")
       timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_stdout.txt 2> $OUT/${TAG}_bench_stderr.txt
-      rc=$?; t1=$(date +%s.%N)
-      echo "bench rc=$rc wall_s=$(echo "$t1 - $t0" | bc) stdout_bytes=$(wc -c < $OUT/${TAG}_bench_stdout.txt) stdout_lines=$(wc -l < $OUT/${TAG}_bench_stdout.txt)" | tee $OUT/${TAG}_bench_meta.txt
+      rc=$?; t1=$(python3 -c "import time; print(time.time())")
+      echo "bench rc=$rc wall_s=$(python3 -c "print(round($t1 - $t0, 1))") stdout_bytes=$(wc -c < $OUT/${TAG}_bench_stdout.txt) stdout_lines=$(wc -l < $OUT/${TAG}_bench_stdout.txt)" | tee $OUT/${TAG}_bench_meta.txt
       cp bench_full.json $OUT/${TAG}_bench_full.json 2>/dev/null
       cat $OUT/${TAG}_bench_stdout.txt ;;
     extras)

@@ -243,3 +243,82 @@ def test_flat_adam_refuses_a_step_with_missing_gradients():
     with pytest.raises(RuntimeError, match=r"models\[1\]\.mlps\.0\.weight has no gradient"):
         own.step()
     assert int(own.state2[0]) == 0
+
+
+def _plain_loss(ms, rays, z, tgt, lab):
+    """The loss of train_dmsr.py:35-49 through the drop-in functions (every parameter of both models gets a gradient)."""
+    from dm_nerf_amd.networks import evaluator as E, render as R
+    out = R.dm_nerf(rays, None, None, ms[0], ms[1], z, ARGS)
+    return E.img2mse(out['rgb_fine'], tgt) + E.img2mse(out['rgb_coarse'], tgt) \
+        + E.ins_criterion(out['ins_fine'], lab, INS)[0] + E.ins_criterion(out['ins_coarse'], lab, INS)[0]
+
+
+def test_zero_grad_keeping_the_tensors_accumulates_once_not_twice():
+    """``zero_grad(set_to_none=False)`` keeps ``p.grad`` = views of the gradient arena and zeroes them.  Had the
+    arena then handed its slots out again, the backward would have written the new gradient INTO those views and AccumulateGrad
+    would have added the memory onto itself (2 g).  Three steps of the plain loop ``zero_grad(set_to_none=False); backward; step``
+    against torch.optim.Adam on twin models: gradients bit-equal at every step, parameters to float noise -- and a second backward
+    without zero_grad in between accumulates (g1 + g2), as it does for torch tensors."""
+    from dm_nerf_amd.networks import helpers as Hh
+    from dm_nerf_amd.optim import FlatAdam
+    N = 96
+    batches = _batches(N)
+    z = Hh.z_val_sample(N, 4.0, 15.0, 64, device="cuda")
+    r_models, o_models = models(), models()
+    r_params = [p for m in r_models for p in m.parameters()]
+    ref = torch.optim.Adam(r_params, lr=5e-4)
+    own = FlatAdam(o_models, lr=5e-4)
+    for step, (rays, tgt, lab) in enumerate(batches[:3]):
+        grads = []
+        for ms, opt in ((r_models, ref), (o_models, own)):
+            torch.cuda.manual_seed(40 + step)
+            opt.zero_grad(set_to_none=False)
+            _plain_loss(ms, rays, z, tgt, lab).backward()
+            grads.append([p.grad.clone() for m in ms for p in m.parameters()])
+            opt.step()
+        # step 0: no tensors to keep yet (the arena slots are written in place); steps 1, 2: the kept views are zeroed and ADDED into
+        worst = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in zip(*grads))
+        assert worst <= (0.0 if step == 0 else 1e-4), (step, worst)     # (later steps: the runs' parameters differ by float noise; 2 g would read 1.0)
+        assert min(float(g.abs().max()) for g in grads[1]) > 0.0
+        assert own.arena.resident()                                    # the kept tensors ARE the arena views
+    worst = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(r_params, own.params))
+    assert worst <= 2e-6, worst                                        # (2 g instead of g would not show here -- Adam is scale-invariant -- the
+    #                                                                    gradient comparison above is the check; this one says the runs stayed twins)
+    # accumulation across two backward passes: g(batch 0) + g(batch 1), in both worlds
+    sums = []
+    for ms, opt in ((r_models, ref), (o_models, own)):
+        opt.zero_grad(set_to_none=False)
+        for k in (0, 1):
+            torch.cuda.manual_seed(50 + k)
+            _plain_loss(ms, batches[k][0], z, batches[k][1], batches[k][2]).backward()
+        sums.append([p.grad.clone() for m in ms for p in m.parameters()])
+    assert all(bool(((a - b).abs() <= 1e-4 * a.abs().max() + 1e-12).all()) for a, b in zip(*sums))
+
+
+def test_a_replaced_middle_gradient_is_not_mistaken_for_the_arena():
+    """the arena check looks at ALL views.  A caller that replaces the gradient of one tensor in the MIDDLE of a model
+    out of place (clipping / scaling one layer) gets that tensor's new values in the update, not the arena's stale ones."""
+    from dm_nerf_amd import distributed as D
+    from dm_nerf_amd.networks import helpers as Hh
+    from dm_nerf_amd.optim import FlatAdam
+    N = 96
+    rays, tgt, lab = _batches(N)[0]
+    z = Hh.z_val_sample(N, 4.0, 15.0, 64, device="cuda")
+    ms = models()
+    own = FlatAdam(ms, lr=5e-4)
+
+    class NoStep:                                                    # run the step's forward / backward, keep the update for below
+        wants_arena = True
+        zero_grad = staticmethod(lambda set_to_none=True: own.zero_grad(set_to_none))
+        step = staticmethod(lambda: None)
+    torch.cuda.manual_seed(5)
+    D.sharded_train_step(rays, z, tgt, lab, ms, ARGS, NoStep, INS)
+    assert own.arena.resident()
+    mid = ms[0].mlps[3].weight                                       # neither first nor last of its model
+    before = mid.detach().clone()
+    mid.grad = mid.grad * 0.0                                        # out of place: a NEW tensor, the arena still holds the old values
+    assert not own.arena.resident()
+    own.step()
+    torch.cuda.synchronize()
+    assert torch.equal(mid.detach(), before)                         # Adam with g = 0 on fresh moments: no movement at all
+    assert not torch.equal(ms[0].mlps[2].weight.detach(), O.make_weights(61, INS, gain=1.7, sigma_bias=0.3)["mlps.2.weight"].cuda())

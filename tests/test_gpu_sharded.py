@@ -97,17 +97,22 @@ def test_two_rank_sharded_training_step_equals_single_process(flat_adam):
     assert np.array_equal(res[0][2], res[1][2])
 
 
-def _strict_line(stdout):
+def _strict_line(stdout, only_line=True):
     """The LAST stdout line, parsed strictly (no NaN / Infinity), bounded at 4096 bytes -- what the driver's reader sees -- plus the
-    full record it points at."""
+    full record it points at.  ``only_line``: stdout holds nothing else (the self-launching form filters its ranks' stdout; under a
+    bare torch.distributed.run the gloo transport of these dry runs prints its own "[Gloo] Rank ..." banners before it)."""
     import json
 
     def no_constants(name):
         raise AssertionError(f"non-strict JSON constant {name}")
     lines = [l for l in stdout.strip().split("\n") if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), lines          # stdout carries the ONE JSON line, nothing else
-    assert len(lines[0].encode()) <= 4096, len(lines[0].encode())
-    r = json.loads(lines[0], parse_constant=no_constants)
+    assert lines and lines[-1].startswith("{"), lines[-3:]              # the contract line is the LAST line
+    if only_line:
+        assert len(lines) == 1, lines                                   # ... and stdout carries nothing else
+    else:
+        assert all(l.startswith("[Gloo]") for l in lines[:-1]), lines[:-1]
+    assert len(lines[-1].encode()) <= 4096, len(lines[-1].encode())
+    r = json.loads(lines[-1], parse_constant=no_constants)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = r["full_record"] if os.path.isabs(r["full_record"]) else os.path.join(root, r["full_record"])
     with open(path) as f:
@@ -129,7 +134,7 @@ def _run_bench(world, steps, scaling, train_steps=1, timeout=800, tmp=None):
            "--train-steps", str(train_steps), "--scaling", scaling, "--full-record", os.path.join(str(tmp), "bench_full.json")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-3000:]
-    return _strict_line(p.stdout)
+    return _strict_line(p.stdout, only_line=False)
 
 
 def _run_bench_plain(world, steps, timeout=800, tmp=None):
