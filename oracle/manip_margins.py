@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE (only tests/ import this): how well-conditioned is every pixel of a manipulation frame?
+
+``manipulator`` (networks/manipulator.py:137-205) chains three inverse-CDF resamplings -- each divides by a cdf slope that may be
+as small as 1e-5 and replaces slopes below 1e-5 by 1 (helpers.py:150-151) -- with two rounds of per-sample argmax decisions.
+Float noise of the size any correct f32 implementation carries therefore moves a few samples, and on a minority of rays the edited
+pixel with them.  How far, is a property of the PIXEL (how close a draw sits to the slope threshold, how steep the field is where a
+displaced sample lands), not of the implementation -- and it can be measured without the implementation under test:
+
+* ``sens [n, 4]``: per pixel and output (final rgb, final object map, target rgb, target object map) the largest deviation from the
+  reference's recorded run among several OTHER f32-class evaluations of the same chain on the same rays and draws
+  (``variant_nets``: the oracle as this host's BLAS rounds it, the network evaluated in float64 on the same f32 inputs, the
+  K dimension of every layer summed in two halves, and in four quarters in reverse order).  A tolerance that follows it --
+  ``floor + gain * sens`` -- is tight (the floor) wherever the chain is well-conditioned and loosens only where the reference's own
+  formula amplifies rounding, by as much as it is seen to.
+* ``critical [n]``: pixels with a draw on the DISCONTINUITY -- a resampling draw whose cdf slope is within 4 ulp of the cdf (4.8e-7)
+  of the 1e-5 threshold, the criterion tests/test_gpu_manipulator.py uses for draws.  Which side such a draw falls on is decided by
+  the last bit of a 62-term sum, in the reference as much as anywhere; the jump it causes is not bounded by what the variants
+  happened to do.  Only these pixels may jump by more than ten tolerances, and their NUMBER is what a test bounds.
+
+``check_frame`` is the acceptance rule built on the two; ``tests/test_manip_conditioning.py`` shows on the CPU that it accepts an
+independent f32 evaluation (leave-one-out) and rejects a frame with mis-routed pixels."""
+import torch
+import torch.nn.functional as F
+
+from . import ref_cpu as O
+
+OUTPUTS = ("full_rgb", "full_ins", "full_tar_rgb", "full_tar_ins")
+SLOPE_THRESHOLD, SLOPE_ULPS = 1e-5, 4.8e-7          # helpers.py:150-151; 4 ulp of a cdf value near 1
+
+
+def _net_f64(rays, sd, N_samples=None, near=None, far=None, z_vals=None):
+    """``manipulator_nerf`` with the embedding and the network in float64 on the SAME f32 sample points (the points are f32 values
+    by the reference's definition: ``rays_o + rays_d * z`` in f32), result rounded to f32: the correctly rounded network."""
+    rays_o, rays_d = rays
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    if z_vals is None:
+        z_vals = O.manipulator_z(rays_d.shape[0], near, far, N_samples)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    e = torch.cat([O.embed(pts.reshape(-1, 3).double(), 10), O.embed(viewdirs[:, None].expand(pts.shape).reshape(-1, 3).double(), 4)], -1)
+    raw = O.mlp_forward({k: v.double() for k, v in sd.items()}, e).float()
+    return raw.reshape(list(pts.shape[:-1]) + [raw.shape[-1]]), z_vals
+
+
+def _split_k_net(parts, reverse):
+    """``manipulator_nerf`` with every layer's K dimension summed in ``parts`` pieces (optionally last piece first): the same f32
+    products in another order -- what a differently tiled GEMM does."""
+    def linear(x, w, b=None):
+        k = x.shape[-1]
+        cuts = [round(i * k / parts) for i in range(parts + 1)]
+        pieces = [x[..., a:e] @ w[:, a:e].T for a, e in zip(cuts[:-1], cuts[1:]) if e > a]
+        if reverse:
+            pieces = pieces[::-1]
+        acc = pieces[0]
+        for p in pieces[1:]:
+            acc = acc + p
+        return acc if b is None else acc + b
+
+    def net(rays, sd, N_samples=None, near=None, far=None, z_vals=None):
+        orig = F.linear
+        F.linear = linear
+        try:
+            return O.manipulator_nerf(rays, sd, N_samples, near, far, z_vals)
+        finally:
+            F.linear = orig
+    return net
+
+
+def variant_nets():
+    """name -> ``net`` for ``ref_cpu.manipulator(net=)``: f32-class evaluations of the same network."""
+    return {"oracle_this_host": None, "network_f64": _net_f64, "k_split_2": _split_k_net(2, False), "k_split_3_reversed": _split_k_net(3, True),
+            "k_split_4_reversed": _split_k_net(4, True), "k_split_5": _split_k_net(5, False), "k_split_8": _split_k_net(8, False)}
+
+
+def frame_inputs(g):
+    """(H, W, N_test, ins_num, label, state dicts, per-chunk draws) of the fixture tests/golden/manipulator_frame.npz."""
+    H, W, N_test = [int(v) for v in g["HWN"]]
+    ins_num, label = int(g["ins_num"]), int(g["label"])
+    sd_c, sd_f = O.make_weights(int(g["seeds"][0]), ins_num, **O.PEAKY), O.make_weights(int(g["seeds"][1]), ins_num, **O.PEAKY)
+    us = [[g[f"u{c}_{i}"] for i in range(3)] for c in range(-(-H * W // N_test))]
+    return H, W, N_test, ins_num, label, sd_c, sd_f, us
+
+
+def run_variant(g, net=None, probe=None):
+    """The oracle's frame loop on the fixture's pose, transformation and draws -> the four outputs as ``[n, width]``."""
+    H, W, N_test, ins_num, label, sd_c, sd_f, us = frame_inputs(g)
+    with torch.no_grad():
+        out = O.manipulate_frame(sd_c, sd_f, H, W, g["K"].numpy(), g["ori_pose"], g["trans"], N_test, 64, 128, 4.0, 15.0, [label],
+                                 us=us, net=net, probe=probe)
+    return [t.reshape(H * W, -1) for t in out[:4]]
+
+
+def slope_critical(g):
+    """[n] bool: the pixel has a resampling draw (any of the 2 + T of its chunk) whose cdf slope is within SLOPE_ULPS of the
+    ``denom < 1e-5 -> 1`` threshold (helpers.py:150-151), on the oracle's f32 run of the fixture's inputs; and the per-pixel
+    smallest distance to the threshold."""
+    dist = []
+
+    def probe(event, **kw):
+        if event != "resample":
+            return
+        bins, u = kw["bins"], kw["u"]
+        _, cdf, inds = O.sample_pdf(bins, kw["weights"], u.shape[-1], u=u, return_aux=True)
+        below, above = (inds - 1).clamp(min=0), inds.clamp(max=cdf.shape[-1] - 1)
+        denom = torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)
+        dist.append((kw["tag"], (denom - SLOPE_THRESHOLD).abs().amin(-1)))
+    run_variant(g, probe=probe)
+    per_call = 3                                                    # T = 1: original, target, edited original
+    chunks = [torch.stack([d for _, d in dist[i:i + per_call]], 0).amin(0) for i in range(0, len(dist), per_call)]
+    d = torch.cat(chunks)
+    return d <= SLOPE_ULPS, d
+
+
+def frame_conditioning(g, skip=()):
+    """``sens [n, 4]`` (see the module docstring; ``skip``: variant names left out), ``critical [n]``, and each variant's outputs."""
+    ref = [g[k] for k in OUTPUTS]
+    outs = {name: run_variant(g, net) for name, net in variant_nets().items() if name not in skip}
+    sens = torch.stack([torch.stack([(o[k] - ref[k]).abs().amax(-1) for o in outs.values()], 0).amax(0) for k in range(4)], 1)
+    critical, _ = slope_critical(g)
+    return sens, critical, outs
+
+
+def check_frame(got, g, sens, critical, floor=1e-4, gain=4.0, allow_frac=0.01, hard=10.0):
+    """The acceptance rule.  Per pixel ``ratio`` = the largest, over the four outputs, of |got - reference's recorded run| / tolerance
+    with tolerance = ``floor + gain * sens``.  Accepted when
+
+    * at most ``max(1, allow_frac * n)`` pixels have ratio > 1 (the deviations of this chain are heavy-tailed: a leave-one-out of
+      the variants themselves leaves the odd pixel at 1.2; tests/test_manip_conditioning.py),
+    * no pixel outside ``critical`` has ratio > ``hard`` -- only a draw ON the slope threshold can jump by more than ten tolerances --
+    * the label (argmax of the final object map) equals the reference's on every pixel within tolerance whose reference top-2 margin
+      exceeds twice its tolerance.
+
+    Returns a report dict; the caller asserts ``ok`` and bounds ``critical.mean()`` / the tolerance's looseness separately."""
+    ref = [g[k] for k in OUTPUTS]
+    n = ref[0].shape[0]
+    err = torch.stack([(got[k].reshape(n, -1) - ref[k]).abs().amax(-1) for k in range(4)], 1)
+    tol = floor + gain * sens
+    ratio = (err / tol).amax(1)
+    exceed = ratio > 1.0
+    hard_bad = (~critical) & (ratio > hard)
+    top2 = torch.topk(ref[1], 2, -1)[0]
+    decided = (~exceed) & ((top2[:, 0] - top2[:, 1]) > 2.0 * tol[:, 1])
+    flips = got[1].reshape(n, -1).argmax(-1) != ref[1].argmax(-1)
+    allowed = max(1, int(allow_frac * n))
+    rep = {"n": n, "n_critical": int(critical.sum()), "n_exceed": int(exceed.sum()), "allowed_exceed": allowed,
+           "exceeders": [(int(i), round(float(ratio[i]), 2), bool(critical[i])) for i in torch.nonzero(exceed).reshape(-1).tolist()][:20],
+           "hard_offenders": torch.nonzero(hard_bad).reshape(-1).tolist()[:20], "worst_ratio_noncritical": float(ratio[~critical].max()),
+           "max_err": {name: float(err[:, k].max()) for k, name in enumerate(OUTPUTS)},
+           "max_err_within_tolerance": {name: float(err[~exceed, k].max()) for k, name in enumerate(OUTPUTS)},
+           "frac_tol_at_floor": {name: float((tol[:, k] <= 2.0 * floor).float().mean()) for k, name in enumerate(OUTPUTS)},
+           "frac_tol_above_1e-3": {name: float((tol[:, k] > 1e-3).float().mean()) for k, name in enumerate(OUTPUTS)},
+           "flips_decided": int((flips & decided).sum()), "flips_total": int(flips.sum()), "n_decided": int(decided.sum())}
+    rep["ok"] = rep["n_exceed"] <= allowed and not rep["hard_offenders"] and rep["flips_decided"] == 0
+    return rep

@@ -665,7 +665,8 @@ def gen_manipulator_stages():
 def gen_manipulator_frame():
     """ONE pose through the reference's own ``manipulator_eval`` (networks/manipulator.py:208-270), unmodified: the function is
     CALLED (cwd = the reference, its ``./data/color_dict.json``; image / metric modules stubbed) with ``manipulator`` and
-    ``sample_pdf`` wrapped by recorders, on a small frame (8 x 10 rays, N_test = 32: chunks of 32, 32 and a ragged 16).  With
+    ``sample_pdf`` wrapped by recorders, on a small frame (16 x 20 rays, N_test = 128: chunks of 128, 128 and a ragged 64; 320 rays
+    so that the threshold-critical / ill-conditioned minority of pixels -- oracle/manip_margins.py -- is a handful, not one or two).  With
     ``gt_rgbs=None`` the function fails AFTER the pose's chunk loop (it reads ``gt_rgbs[i]`` unconditionally, :319) -- everything
     this fixture needs has been recorded by then: per chunk the original / target ray batches the loop built from
     ``get_rays_k(ori_pose)`` / ``get_rays_k(trans @ ori_pose)``, the 2 + 1 draws, and the four outputs it accumulates."""
@@ -675,7 +676,7 @@ def gen_manipulator_frame():
                 "matplotlib.cm", "h5py", "configargparse", "trimesh"):
         sys.modules.setdefault(mod, MagicMock())
     import networks.manipulator as R_mani
-    H_, W_, N_test, ins_num, label = 8, 10, 32, 7, 2
+    H_, W_, N_test, ins_num, label = 16, 20, 128, 7, 2
     sd_c, sd_f = O.make_weights(721, ins_num, **O.PEAKY), O.make_weights(722, ins_num, **O.PEAKY)
     mc, mf = ref_model(sd_c, ins_num), ref_model(sd_f, ins_num)
     pe, _ = R_model.get_embedder(10, 0); ve, _ = R_model.get_embedder(4, 0)
@@ -718,7 +719,7 @@ def gen_manipulator_frame():
     finally:
         os.chdir(cwd)
         R_mani.manipulator, R_mani.sample_pdf = orig_m, orig_pdf
-    assert failed_after_loop is not None and len(calls) == 3 and [c["ori"].shape[1] for c in calls] == [32, 32, 16], (failed_after_loop, len(calls))
+    assert failed_after_loop is not None and len(calls) == 3 and [c["ori"].shape[1] for c in calls] == [128, 128, 64], (failed_after_loop, len(calls))
     assert a.target_labels == [label] and all(len(c["us"]) == 3 and c["tar"].shape[0] == 1 for c in calls)
     full = [torch.cat([c["out"][k] for c in calls], 0) for k in range(4)]
     # the oracle's restatement of the loop reproduces the run bit for bit from the recorded draws

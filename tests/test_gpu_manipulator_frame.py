@@ -6,7 +6,7 @@ manipulate_frame; BASELINE config 5): the per-pose chunk loop of the reference's
 * the frame is bit-identical whatever the world size, INCLUDING the device generator's draws (bands of worlds 2 / 7 / 8 rendered
   by one process through ``rank=`` / ``world=``, and a real 2-rank run over gloo on the box's one GPU);
 * against the reference's own ``manipulator_eval`` run (tests/golden/manipulator_frame.npz): target pose and rays, the plain target
-  render tightly, the edited outputs as loosely as the whole chain allows (tests/test_gpu_manipulator.py explains why)."""
+  render tightly, the edited outputs per pixel as tightly as that pixel's conditioning allows (oracle/manip_margins.py)."""
 import os
 import socket
 import types
@@ -165,10 +165,21 @@ def test_two_rank_frame_over_a_real_process_group_equals_single_process():
 
 
 def test_against_the_reference_manipulator_eval_run(golden, capsys):
-    """tests/golden/manipulator_frame.npz: ONE pose through the reference's own ``manipulator_eval`` (8 x 10 rays, N_test = 32:
-    32 + 32 + a ragged 16), every chunk's ray batches, draws and outputs recorded."""
+    """tests/golden/manipulator_frame.npz: ONE pose through the reference's own ``manipulator_eval`` (16 x 20 rays, N_test = 128:
+    128 + 128 + a ragged 64), every chunk's ray batches, draws and outputs recorded.
+
+    The chain is ill-conditioned on a minority of rays (three inverse-CDF resamplings with slopes down to 1e-5 and a hard threshold
+    there, discrete label decisions), so each pixel is held to the reference's run AS TIGHTLY AS ITS OWN CONDITIONING ALLOWS
+    (oracle/manip_margins.py): tolerance = 1e-4 + 4 x the largest deviation SEVEN other f32-class evaluations
+    of the same chain show at that pixel (the oracle on this host, the network in float64, K summed in 2 / 3 / 4 / 5 / 8 pieces) --
+    1e-4 .. 2e-4 on more than 80 % of the pixels.  At most 1 % of the pixels may exceed it, only pixels with a draw ON the slope
+    threshold (about 10 % of the rays have one of their 384 draws there) by more than ten times, and the label equals the
+    reference's wherever the reference's top-2 margin exceeds twice the tolerance.  The rule's soundness (it accepts each of the
+    seven evaluations when the tolerance is measured without it) and power (it rejects a frame with 20 % or 2 % of its pixels
+    mis-routed) are shown on the CPU: tests/test_manip_conditioning.py."""
     from dm_nerf_amd import distributed as D
     from dm_nerf_amd.networks import dm_nerf as M
+    from oracle import manip_margins as MM
     g = golden("manipulator_frame")
     H_, W_, N_test = [int(v) for v in g["HWN"]]
     ins_num, label = int(g["ins_num"]), int(g["label"])
@@ -199,16 +210,22 @@ def test_against_the_reference_manipulator_eval_run(golden, capsys):
     assert torch.allclose(fr.ori[1].cpu(), g["ori_rays"][1], rtol=3e-7, atol=1e-7)
     assert torch.allclose(fr.tar[0, 1].cpu(), g["tar_rays"][1], rtol=3e-7, atol=1e-7)
     n = H_ * W_
-    err = {name: (got.reshape(n, -1) - g[name]).abs().amax(-1) for got, name in zip(frame, ("full_rgb", "full_ins", "full_tar_rgb", "full_tar_ins"))}
-    flips = int((frame[1].reshape(n, -1).argmax(-1) != g["full_ins"].argmax(-1)).sum())
+    sens, critical, _ = MM.frame_conditioning(g)                          # seven oracle evaluations of the frame on the host cores
+    rep = MM.check_frame([t.reshape(n, -1) for t in frame], g, sens, critical)
     with capsys.disabled():
-        print("\n[manipulation frame vs the reference's manipulator_eval] max |d|: " + ", ".join(f"{k_} {float(v.max()):.2e}" for k_, v in err.items())
-              + "; fraction of pixels within 5e-3: " + ", ".join(f"{k_} {float((v <= 5e-3).float().mean()):.3f}" for k_, v in err.items())
-              + f"; label flips {flips} / {n}")
-    # the plain coarse render of the target view: 3.4e-5 observed -- "trained-like" PEAKY weights (density gain 100: opaque
-    # surfaces, the compositing weights are steep in the density) and a target pose that may differ from the fixture's by the
-    # last bit of its 4 x 4 product; the mild-weight chain test (test_gpu_manipulator.py) holds the same output to 2e-5
-    assert float(err["full_tar_rgb"].max()) <= 1e-4
-    for name in ("full_rgb", "full_ins", "full_tar_ins"):
-        assert float((err[name] <= 5e-3).float().mean()) >= 0.75, (name, err[name].tolist())
-    assert flips <= n // 10
+        print(f"\n[manipulation frame vs the reference's manipulator_eval, {n} pixels] tolerance 1e-4 + 4 sens: <= 2e-4 on "
+              + ", ".join(f"{k_} {v:.3f}" for k_, v in rep["frac_tol_at_floor"].items()) + " of the pixels, > 1e-3 on "
+              + ", ".join(f"{v:.3f}" for v in rep["frac_tol_above_1e-3"].values())
+              + f"; slope-critical pixels {rep['n_critical']} ({rep['n_critical'] / n:.3f}); pixels beyond tolerance {rep['n_exceed']} (allowed "
+              f"{rep['allowed_exceed']}): {rep['exceeders']}; worst ratio on non-critical pixels {rep['worst_ratio_noncritical']:.2f}; "
+              "max |d| within tolerance: " + ", ".join(f"{k_} {v:.2e}" for k_, v in rep["max_err_within_tolerance"].items())
+              + "; max |d| overall: " + ", ".join(f"{v:.2e}" for v in rep["max_err"].values())
+              + f"; label flips {rep['flips_total']} / {n} ({rep['flips_decided']} on the {rep['n_decided']} decided pixels)")
+    assert rep["ok"], rep
+    assert critical.float().mean() <= 0.12                                 # the exempt-from-the-hard-bound set stays a small minority
+    assert min(rep["frac_tol_at_floor"].values()) >= 0.8                   # ... and the tolerance IS the floor almost everywhere
+    assert max(rep["frac_tol_above_1e-3"].values()) <= 0.05
+    # the plain coarse render of the target view has no resampling behind it: tight everywhere (3.4e-5 observed -- "trained-like"
+    # PEAKY weights, density gain 100: the compositing weights are steep in the density; and a target pose that may differ from
+    # the fixture's by the last bit of its 4 x 4 product)
+    assert rep["max_err"]["full_tar_rgb"] <= 1e-4
