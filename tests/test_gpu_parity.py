@@ -589,6 +589,9 @@ def test_split_bf16_inference_is_f32_class(A, split):
     assert float((a['rgb_fine'] - b['rgb_fine']).abs().max()) <= 2e-3       # through the ill-conditioned inverse-CDF step
 
 
+_opt_in_oracle = {}         # (ins_num, near, far) -> the oracle's dict: the three modes are checked against the same CPU render (4 s each)
+
+
 @pytest.mark.parametrize("mode", ["fuse_heads", "mfma_split", "mfma_split=f16x2"])
 @pytest.mark.parametrize("ins_num,near,far", [(13, 4.0, 15.0), (59, 0.0, 4.7), (93, 0.0, 4.7)])
 def test_opt_in_inference_modes_full_dict_vs_oracle(A, mode, ins_num, near, far, capsys):
@@ -608,8 +611,9 @@ def test_opt_in_inference_modes_full_dict_vs_oracle(A, mode, ins_num, near, far,
     args = types.SimpleNamespace(perturb=False, N_importance=128, is_train=False, N_ins=None, **{key: (val or True)})
     with torch.no_grad():
         got = {k: cpu(v) for k, v in A.R.dm_nerf(dev(rays), None, None, mc, mf, dev(z), args).items()}
-        want = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0.)
-        raw_f = None
+        if (ins_num, near, far) not in _opt_in_oracle:
+            _opt_in_oracle[(ins_num, near, far)] = O.dm_nerf(rays, sd_c, sd_f, z, perturb=0.)
+        want = _opt_in_oracle[(ins_num, near, far)]
     assert set(got) == set(want)
     for k in want:
         assert got[k].shape == want[k].shape, k
