@@ -100,6 +100,12 @@ SIGNATURES = {
     "dmnerf_colsum": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
     "dmnerf_ray_points": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "dmnerf_copy_cols": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp]),
+    "dmnerf_gemm_nt_blocks": (c_int, [c_int]),
+    "dmnerf_pack_nt": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "dmnerf_gemm_nt": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_int,
+                               c_i64, c_int, c_vp, c_i64, c_int, c_vp]),
+    "dmnerf_copy_cols_pad": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
+    "dmnerf_ray_embed": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "dmnerf_wgrad_set_trace": (c_int, [c_vp]),
     "dmnerf_blob_split_words": (c_i64, [c_int]),
     "dmnerf_build_pack_index_split": (c_int, [c_int, c_vp, c_i64]),
@@ -146,7 +152,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 6:
+    if lib.dmnerf_abi_version() != 7:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

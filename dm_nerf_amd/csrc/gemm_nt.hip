@@ -1,0 +1,388 @@
+// gemm_nt.hip -- the GEMM of the layer-by-layer DM_NeRF path (network shapes other than the shipped D = 8 / W = 256; generic.py)
+// on the machine's own terms: operands global -> LDS by LDS-DMA, ds_read_b128 operand reads, hand-scheduled MFMA stream.
+//
+//   C[m][n] = act( sum_k A[m][k] W[n][k] + bias[n] )        A: activations [M rows of samples], W: packed weights, both k-fast
+//
+// * forward of a linear layer:  A = the layer's input rows, W = nn.Linear.weight (dm_nerf.py:80-106);
+// * data gradient:              A = dL/dy rows, W = weight^T (packed transposed), epilogue . [h > 0] and optional accumulate;
+// * the cats of dm_nerf.py:87,90 ([h, pts], [rgb_feature, dirs]) are a K-OFFSET, not a copy: the A operand has up to two K ranges
+//   with their own source pointer and row stride (h | pts), matched by the column order of the packed weights.
+//
+// Tile: one workgroup = 128 samples x ALL (up to 384) outputs of the layer: wave w owns the 32 samples of A block w and every
+// B block, NBB accumulator blocks of v_mfma_f32_32x32x2_f32 (the weights are the shared operand: one copy per workgroup through
+// LDS; each activation row is read from HBM exactly once per layer).  Per 32-k chunk the tile is (4 + NBB) blocks of 32 rows x
+// 128 bytes; a block lands in LDS by four LDS-DMA wave-instructions (buffer_load ... lds, 16 B per lane: 8 rows of 128 B each) with the 16-byte units of a
+// row XOR-swizzled by (row >> 1) & 7, so that the ds_read_b128 of 32 different rows is conflict-free (the geometry of wgrad.hip's
+// ring, with row strides instead of contiguous tiles).  A D-deep ring (2 .. 4 chunks) keeps the next chunks in flight; the hand-over
+// (vmcnt + barrier) sits at the start of a chunk's last round; operand reads run one round ahead through inline asm, one per MFMA
+// gap; the refills of the released slot are spread over the last round's gaps.  Per round: 1 + NBB reads for 4 NBB MFMAs.
+// Exact f32 (the MFMA is an fmaf chain), bias as the accumulator's initial value, no vendor BLAS.
+//
+// Roofline: MFMA f32 for W >= 192 (2 N K flop per 4 (K + N) bytes of HBM per sample); for narrower layers the HBM round trip of the
+// activations between two launches is the bound.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/dmnerf_hip.h"
+#include "common.h"
+#include "mlp_common.h"
+
+using namespace dmn;
+
+namespace {
+
+constexpr int NT_RING_BYTES = 147456;     // ring budget of the CU's 160 KiB
+constexpr int NT_MAX_DEPTH = 4;
+constexpr int NT_MAX_NBB = 12;            // 384 outputs per workgroup: 192 accumulator registers
+
+struct NtArgs {
+    const float* A0; const float* A1;     // the two K ranges of the A operand (A1 null: one range)
+    int64_t lda0, lda1;                   // row strides (floats, multiples of 4: rows are 16-byte aligned)
+    int64_t a0_floats, a1_floats;         // floats from A0 / A1 to the end of their allocations
+    int nc0, nc1;                         // 32-k chunks of each range
+    const float* B; int64_t b_floats;     // packed weights [rows padded to 32 NBB x tiles][ldb], zero-filled padding
+    int ldb;                              // = 32 (nc0 + nc1)
+    const float* bias;                    // [padded rows] or null
+    float* C; int64_t ldc;                // C[m * ldc + n]
+    int n_store, n_zero;                  // columns [0, n_store) get values, [n_store, n_zero) zeros (the pad columns of a row)
+    const float* mask; int64_t ldm;       // data gradient: C = mask[m * ldm + n] > 0 ? v : 0, or null
+    int64_t M;
+    int relu, accumulate;
+};
+
+template <int NBB>
+struct NtRing {
+    static constexpr int NL = 4 + NBB;                                   // DMA pieces per wave per chunk (1 KiB each)
+    static constexpr int BUF = NL * 4096;                                // bytes per chunk
+    static constexpr int D = NT_RING_BYTES / BUF < NT_MAX_DEPTH ? NT_RING_BYTES / BUF : NT_MAX_DEPTH;
+    static_assert(D >= 2, "ring needs two slots");
+    static_assert((D - 1) * NL <= 63, "vmcnt range");
+};
+
+template <int NBB>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef NtRing<NBB> RG;
+    constexpr int NL = RG::NL, D = RG::D, BUF = RG::BUF;
+    constexpr int NR = 1 + NBB;                     // operand reads per round
+    constexpr int NGAP = 4 * NBB;                   // MFMAs per round
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = lds_addr(lds);
+    const int64_t i0 = (int64_t)blockIdx.x * 128;
+    const int j0 = blockIdx.y * (NBB * 32);         // first output (row of the packed weights) of this workgroup
+    const int nchunk = a.nc0 + a.nc1;
+
+    // ---- DMA geometry (wgrad.hip): wave w owns the 1-KiB piece w of every 32-row block (rows 8 w .. 8 w + 7); lane l lands at LDS
+    // row 8 w + (l >> 3), unit l & 7, so it must FETCH unit (l & 7) ^ ((row >> 1) & 7) of that row
+    const int drow = 8 * w + (lane >> 3);
+    const int dunit = ((lane & 7) ^ ((drow >> 1) & 7)) << 4;
+    const int voA0 = (int)(drow * a.lda0 * 4) + dunit;
+    const int voA1 = (int)(drow * a.lda1 * 4) + dunit;
+    const int voB = drow * a.ldb * 4 + dunit;
+    // descriptors: rows beyond M are beyond the A descriptors' ranges (they read as 0 and feed rows the epilogue never stores)
+    const int64_t rows_valid = a.M - i0 < 128 ? a.M - i0 : 128;
+    auto bound = [](int64_t want, int64_t have) { const int64_t b = want < have ? want : have; return b < 0x1fffffff ? b : (int64_t)0x1fffffff; };
+    const rsrc_t rsA0 = uniform_rsrc(a.A0 + i0 * a.lda0, bound(rows_valid * a.lda0, a.a0_floats - i0 * a.lda0));
+    const rsrc_t rsA1 = a.A1 ? uniform_rsrc(a.A1 + i0 * a.lda1, bound(rows_valid * a.lda1, a.a1_floats - i0 * a.lda1)) : rsA0;
+    const rsrc_t rsB = uniform_rsrc(a.B + (int64_t)j0 * a.ldb, bound((int64_t)NBB * 32 * a.ldb, a.b_floats - (int64_t)j0 * a.ldb));
+    const int blkA0 = (int)(32 * a.lda0 * 4), blkA1 = (int)(32 * a.lda1 * 4), blkB = 32 * a.ldb * 4;      // bytes per 32-row block
+
+    auto dma_chunk_piece = [&](int c, unsigned slot_byte, int i) {       // piece i of NL for chunk c (clamped) into a ring slot
+        const int cc = c < nchunk ? c : nchunk - 1;
+        float* dst = lds + (slot_byte + i * 4096 + w * 1024) / 4;
+        if (i < 4) {
+            if (cc < a.nc0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (DMN_LAS void*)dst, 16, voA0, i * blkA0 + cc * 128, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (DMN_LAS void*)dst, 16, voA1, i * blkA1 + (cc - a.nc0) * 128, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, (i - 4) * blkB + cc * 128, 0, 0);
+        }
+    };
+
+    // ---- read geometry: lane (li, half) reads row 32 blk + li, unit (2 t + half) ^ ((li >> 1) & 7) in round t
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned o = lds0 + li * 128 + ((((2 * t + half) ^ ((li >> 1) & 7))) << 4);
+        offA[t] = o + w * 4096;
+        offB[t] = o + 4 * 4096;
+    }
+
+    // ---- the bias (column n = j0 + 32 b + li is this lane's in every register of block b): loaded FIRST, so that these are the oldest
+    // VMEM operations of the wave -- vmcnt retires in order, and the ring's counting below must see DMA pieces only behind it
+    float bias_v[NBB];
+#pragma unroll
+    for (int b = 0; b < NBB; ++b) bias_v[b] = a.bias ? a.bias[j0 + 32 * b + li] : 0.f;
+    asm volatile("" ::: "memory");
+
+    f32x4 av[2][1], bv[2][NBB];
+    auto read_ops_one = [&](auto gc, int buf, unsigned addrA, unsigned addrB) {     // operand g of a round
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g == 0) lds_read16_async<0>(av[buf][0], addrA);
+        else lds_read16_async<(g - 1) * 4096>(bv[buf][g - 1], addrB);
+    };
+
+    // ---- prologue: D chunks in flight, chunk 0 landed, its round-0 operands on their way
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));     // vmcnt((D-1) NL) only
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
+    f32x16 acc[NBB];                                    // accumulators start from the bias (landed: older than chunk 0's pieces)
+#pragma unroll
+    for (int b = 0; b < NBB; ++b) {
+        acc[b] = (f32x16)(bias_v[b]);
+        if constexpr (NBB > 8) asm volatile("" : "+a"(acc[b]));    // wide tiles: the accumulators live in the AGPR half of the file
+    }
+
+    unsigned sb = 0;                                    // byte offset of the ring slot of chunk c (uniform)
+#pragma nounroll
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned nb = sb + BUF == (unsigned)(D * BUF) ? 0u : sb + BUF;
+        unsigned cA[4], cB[4];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) { cA[t] = offA[t] + sb; cB[t] = offB[t] + sb; }
+        cA[0] = offA[0] + nb; cB[0] = offB[0] + nb;     // round 0 of the NEXT chunk (read in this chunk's round 3)
+        static_for<4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            lds_wait<0>(av[r & 1]);
+#pragma unroll
+            for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
+            if constexpr (r == 3) {
+                // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NGAP>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int u = g / NBB, ib = g % NBB;
+                if constexpr (g < NR) read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
+                if constexpr (r == 3) {                                 // refill the released slot with chunk c + D
+                    constexpr int G0 = NR < NGAP ? NR : NGAP - 1;
+                    constexpr int PD = (NGAP - G0) / NL > 0 ? (NGAP - G0) / NL : 1;
+                    static_for<NL>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int at = G0 + i * PD < NGAP ? G0 + i * PD : NGAP - 1;
+                        if constexpr (at == g) dma_chunk_piece(c + D, sb, i);
+                    });
+                }
+                acc[ib] = mfma32(av[r & 1][0][u], bv[r & 1][ib][u], acc[ib]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        sb = nb;
+    }
+    // the ring's last (clamped) refills and the read-ahead of the chunk after the last one land in LDS / registers nobody uses,
+    // but they must have landed before the workgroup's LDS is handed on (the ties keep the read-ahead's registers allocated)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("" : "+" DMN_TILE_RC(av[0][0]));
+#pragma unroll
+    for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
+
+    // ---- epilogue: lane holds column n = j0 + 32 b + li, rows 32 w + (r & 3) + 8 (r >> 2) + 4 half
+    const int ncols = a.n_zero - j0 < NBB * 32 ? a.n_zero - j0 : NBB * 32;       // columns of this workgroup that exist in C
+    if (ncols <= 0 || rows_valid <= 0) return;
+    float* const Ct = a.C + i0 * a.ldc + j0;
+    const rsrc_t rsC = uniform_rsrc(Ct, (rows_valid - 1) * a.ldc + ncols);       // rows beyond M fall outside: dropped by the hardware
+    const int voC = (int)(((int64_t)(32 * w + 4 * half) * a.ldc + li) * 4);
+    const int rowB = (int)(a.ldc * 4);
+    rsrc_t rsM = rsC;
+    int voM = 0, rowM = 0;
+    if (a.mask) {
+        rsM = uniform_rsrc(a.mask + i0 * a.ldm + j0, (rows_valid - 1) * a.ldm + ncols);
+        voM = (int)(((int64_t)(32 * w + 4 * half) * a.ldm + li) * 4);
+        rowM = (int)(a.ldm * 4);
+    }
+#pragma unroll
+    for (int b = 0; b < NBB; ++b) {
+        const int col = 32 * b + li;
+        const bool in_c = col < ncols;                                           // (a column predicate: the descriptor bounds rows only)
+        const bool is_val = j0 + col < a.n_store;
+        const int vo = in_c ? voC + b * 128 : 0x7ffffff0;
+        const int vm = in_c ? voM + b * 128 : 0x7ffffff0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            float v = acc[b][r];
+            if (a.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo, ro * rowB, 0));
+            if (a.relu) v = relu1(v);
+            if (a.mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm, ro * rowM, 0)) > 0.f ? v : 0.f;
+            v = is_val ? v : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(v), rsC, vo, ro * rowB, 0);
+        }
+    }
+}
+
+// Packed weights of one layer: out[n][kk] for n < rows_pad, kk < ldb -- range 0 = source columns [c0, c0 + k0) at kk = 0 .., range 1 =
+// source columns [c1, c1 + k1) at kk = 32 ceil(k0 / 32) ..; everything else zero.  transposed: the source is read as W^T
+// (out[n][kk] = W[kk-th source ROW][n-th source COLUMN]) -- the data-gradient form.  bias_out[n] = bias[n] (zero beyond N).
+struct PackNtArgs {
+    const float* W; int64_t ldw; int N;           // source [*, ldw]; N = logical rows of the packed matrix
+    int c0, k0, c1, k1;
+    int transposed;
+    float* out; int rows_pad, ldb;
+    const float* bias; float* bias_out;
+};
+
+__global__ void pack_nt_kernel(const PackNtArgs a) {
+    const int64_t total = (int64_t)a.rows_pad * a.ldb;
+    const int kp0 = (a.k0 + 31) / 32 * 32;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / a.ldb), kk = (int)(e % a.ldb);
+        int src = -1;
+        if (kk < a.k0) src = a.c0 + kk;
+        else if (kk >= kp0 && kk - kp0 < a.k1) src = a.c1 + (kk - kp0);
+        float v = 0.f;
+        if (n < a.N && src >= 0) v = a.transposed ? a.W[(int64_t)src * a.ldw + n] : a.W[(int64_t)n * a.ldw + src];
+        a.out[e] = v;
+    }
+    if (a.bias_out)
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < a.rows_pad; n += gridDim.x * blockDim.x)
+            a.bias_out[n] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+}
+
+// pts = o + d z, viewdirs = d / |d| per sample (render.py:37,49-57) and both positional encodings (Embedder.embed, dm_nerf.py:37-38)
+// straight into row-padded buffers: x_pos [M][ldp], x_dir [M][ldv] with the pad columns zeroed -- the A operands of gemm_nt
+// (rows 16-byte aligned).  One thread per (sample, coordinate); the same shared range reduction as the fused kernels.
+__global__ void ray_embed_kernel(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ z, int64_t N, int S,
+                                 int Lp, int Lv, float* __restrict__ xp, int ldp, float* __restrict__ xv, int ldv) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = N * S;
+    if (idx >= M * 3) return;
+    const int64_t m = idx / 3;
+    const int c = (int)(idx % 3);
+    const int64_t n = m / S;
+    const float dx = rd[n * 3], dy = rd[n * 3 + 1], dz = rd[n * 3 + 2], zv = z[m];
+    const float dc = c == 0 ? dx : (c == 1 ? dy : dz);
+    const float p = ro[n * 3 + c] + dc * zv;                       // render.py:49: separate multiply and add
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);          // render.py:37
+    const float v = dc / nrm;
+    float* op = xp + m * ldp;
+    float* ov = xv + m * ldv;
+    op[c] = p;
+    ov[c] = v;
+    const double tp = dmn::rev_of(p), tv = dmn::rev_of(v);
+    for (int k = 0; k < Lp; ++k) {
+        op[3 + 6 * k + c] = dmn::sin_rev(tp, k, 0);
+        op[3 + 6 * k + 3 + c] = dmn::sin_rev(tp, k, 1);
+    }
+    for (int k = 0; k < Lv; ++k) {
+        ov[3 + 6 * k + c] = dmn::sin_rev(tv, k, 0);
+        ov[3 + 6 * k + 3 + c] = dmn::sin_rev(tv, k, 1);
+    }
+    for (int q = 3 + 6 * Lp + c; q < ldp; q += 3) op[q] = 0.f;     // pad columns
+    for (int q = 3 + 6 * Lv + c; q < ldv; q += 3) ov[q] = 0.f;
+}
+
+// dst[m][c] = src[m][c] for c < n, 0 for n <= c < n_pad: a column slice as a row-padded gemm_nt operand
+__global__ void copy_cols_pad_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t M, int n, int n_pad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * n_pad) return;
+    const int64_t m = e / n_pad;
+    const int c = (int)(e % n_pad);
+    dst[m * ldd + c] = c < n ? src[m * lds_ + c] : 0.f;
+}
+
+template <int NBB>
+int launch_nt(const NtArgs& a, int tiles_n, hipStream_t stream) {
+    constexpr int lds_bytes = NtRing<NBB>::D * NtRing<NBB>::BUF;
+    static DmnOncePerDevice once;
+    if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<NBB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+        e != hipSuccess)
+        return dmn_fail_hip(e, "gemm_nt: hipFuncSetAttribute");
+    const int64_t ti = (a.M + 127) / 128;
+    hipLaunchKernelGGL(gemm_nt_kernel<NBB>, dim3((unsigned)ti, (unsigned)tiles_n), dim3(256), lds_bytes, stream, a);
+    return dmn_check_launch("gemm_nt");
+}
+
+}  // namespace
+
+extern "C" int dmnerf_gemm_nt_blocks(int n_out) {
+    // out-blocks (32 outputs) per workgroup for a layer of n_out outputs: all of them up to NT_MAX_NBB, else even tiles
+    const int nb = (n_out + 31) / 32;
+    if (nb <= NT_MAX_NBB) return nb < 1 ? 1 : nb;
+    const int tiles = (nb + NT_MAX_NBB - 1) / NT_MAX_NBB;
+    return (nb + tiles - 1) / tiles;
+}
+
+extern "C" int dmnerf_pack_nt(const float* d_W, int64_t ldw, int n_rows, int c0, int k0, int c1, int k1, int transposed, const float* d_bias,
+                              float* d_out, int rows_pad, int ldb, float* d_bias_out, void* stream) {
+    if (n_rows < 1 || k0 < 1 || k1 < 0 || c0 < 0 || c1 < 0 || rows_pad < n_rows || rows_pad % 32)
+        return dmn_fail(DMNERF_E_ARG, "pack_nt: bad sizes rows=%d k0=%d k1=%d rows_pad=%d", n_rows, k0, k1, rows_pad);
+    if (ldb != ((k0 + 31) / 32 + (k1 + 31) / 32) * 32) return dmn_fail(DMNERF_E_ARG, "pack_nt: ldb=%d does not match the K ranges %d + %d", ldb, k0, k1);
+    if (!d_W || !d_out) return dmn_fail(DMNERF_E_ARG, "pack_nt: null pointer");
+    PackNtArgs a{d_W, ldw, n_rows, c0, k0, c1, k1, transposed, d_out, rows_pad, ldb, d_bias, d_bias_out};
+    const int64_t total = (int64_t)rows_pad * ldb;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_nt_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, a);
+    return dmn_check_launch("pack_nt");
+}
+
+extern "C" int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats, int k0, const float* d_A1, int64_t lda1, int64_t a1_floats, int k1,
+                              const float* d_B, int64_t b_floats, int ldb, const float* d_bias, float* d_C, int64_t ldc, int n_store, int n_zero,
+                              int64_t M, int relu, const float* d_mask, int64_t ldm, int accumulate, void* stream) {
+    if (M < 0 || k0 < 1 || k1 < 0 || n_store < 1 || n_zero < n_store) return dmn_fail(DMNERF_E_ARG, "gemm_nt: bad sizes M=%lld k0=%d k1=%d n=%d", (long long)M, k0, k1, n_store);
+    if (M == 0) return DMNERF_OK;
+    if (!d_A0 || !d_B || !d_C || (k1 > 0 && !d_A1)) return dmn_fail(DMNERF_E_ARG, "gemm_nt: null pointer");
+    if (lda0 % 4 || (k1 > 0 && lda1 % 4) || ((uintptr_t)d_A0 & 15) || (k1 > 0 && ((uintptr_t)d_A1 & 15)) || ((uintptr_t)d_B & 15))
+        return dmn_fail(DMNERF_E_ARG, "gemm_nt: operand rows must be 16-byte aligned (lda0=%lld lda1=%lld)", (long long)lda0, (long long)lda1);
+    if (n_zero > ldc) return dmn_fail(DMNERF_E_ARG, "gemm_nt: n_zero=%d beyond the row length %lld", n_zero, (long long)ldc);
+    const int nc0 = (k0 + 31) / 32, nc1 = (k1 + 31) / 32;
+    if (ldb != 32 * (nc0 + nc1)) return dmn_fail(DMNERF_E_ARG, "gemm_nt: ldb=%d does not match the K ranges", ldb);
+    if (lda0 * 4 * 128 > 0x3fffffffLL || lda1 * 4 * 128 > 0x3fffffffLL || ldc * 4 * 128 > 0x3fffffffLL || ldm * 4 * 128 > 0x3fffffffLL)
+        return dmn_fail(DMNERF_E_ARG, "gemm_nt: row stride too large for 32-bit tile offsets");
+    const int nbb = dmnerf_gemm_nt_blocks(n_store);
+    const int tiles = ((n_store + 31) / 32 + nbb - 1) / nbb;
+    if (b_floats < (int64_t)tiles * nbb * 32 * ldb) return dmn_fail(DMNERF_E_ARG, "gemm_nt: packed weights hold %lld floats, %lld needed", (long long)b_floats, (long long)tiles * nbb * 32 * ldb);
+    if ((M + 127) / 128 > 0x7fffffffLL) return dmn_fail(DMNERF_E_ARG, "gemm_nt: too many rows");
+    NtArgs a{};
+    a.A0 = d_A0; a.A1 = k1 > 0 ? d_A1 : nullptr; a.lda0 = lda0; a.lda1 = k1 > 0 ? lda1 : 0; a.a0_floats = a0_floats; a.a1_floats = a1_floats;
+    a.nc0 = nc0; a.nc1 = nc1; a.B = d_B; a.b_floats = b_floats; a.ldb = ldb; a.bias = d_bias; a.C = d_C; a.ldc = ldc;
+    a.n_store = n_store; a.n_zero = n_zero; a.mask = d_mask; a.ldm = ldm; a.M = M; a.relu = relu; a.accumulate = accumulate;
+    hipStream_t s = (hipStream_t)stream;
+    switch (nbb) {
+        case 1: return launch_nt<1>(a, tiles, s);
+        case 2: return launch_nt<2>(a, tiles, s);
+        case 3: return launch_nt<3>(a, tiles, s);
+        case 4: return launch_nt<4>(a, tiles, s);
+        case 5: return launch_nt<5>(a, tiles, s);
+        case 6: return launch_nt<6>(a, tiles, s);
+        case 7: return launch_nt<7>(a, tiles, s);
+        case 8: return launch_nt<8>(a, tiles, s);
+        case 9: return launch_nt<9>(a, tiles, s);
+        case 10: return launch_nt<10>(a, tiles, s);
+        case 11: return launch_nt<11>(a, tiles, s);
+        case 12: return launch_nt<12>(a, tiles, s);
+        default: return dmn_fail(DMNERF_E_ARG, "gemm_nt: unsupported block count %d", nbb);
+    }
+}
+
+extern "C" int dmnerf_copy_cols_pad(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, int n_pad, void* stream) {
+    if (M < 0 || n < 0 || n_pad < n || n_pad > ld_dst) return dmn_fail(DMNERF_E_ARG, "copy_cols_pad: bad sizes n=%d n_pad=%d ld_dst=%lld", n, n_pad, (long long)ld_dst);
+    if (M == 0 || n_pad == 0) return DMNERF_OK;
+    if (!d_src || !d_dst) return dmn_fail(DMNERF_E_ARG, "copy_cols_pad: null pointer");
+    const int64_t total = M * n_pad;
+    if ((total + 255) / 256 > 0x7fffffffLL) return dmn_fail(DMNERF_E_ARG, "copy_cols_pad: too many elements");
+    hipLaunchKernelGGL(copy_cols_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src, ld_src, d_dst, ld_dst, M, n, n_pad);
+    return dmn_check_launch("copy_cols_pad");
+}
+
+extern "C" int dmnerf_ray_embed(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, int Lp, int Lv,
+                                float* d_x_pos, int ldp, float* d_x_dir, int ldv, void* stream) {
+    if (N < 0 || S < 1 || Lp < 0 || Lv < 0 || Lp > 30 || Lv > 30 || ldp < 3 + 6 * Lp || ldv < 3 + 6 * Lv)
+        return dmn_fail(DMNERF_E_ARG, "ray_embed: bad sizes N=%lld S=%d Lp=%d Lv=%d ldp=%d ldv=%d", (long long)N, S, Lp, Lv, ldp, ldv);
+    if (N == 0) return DMNERF_OK;
+    if (!d_rays_o || !d_rays_d || !d_z || !d_x_pos || !d_x_dir) return dmn_fail(DMNERF_E_ARG, "ray_embed: null pointer");
+    const int64_t total = N * S * 3;
+    if ((total + 255) / 256 > 0x7fffffffLL) return dmn_fail(DMNERF_E_ARG, "ray_embed: too many samples");
+    hipLaunchKernelGGL(ray_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rays_o, d_rays_d, d_z, N, S, Lp, Lv,
+                       d_x_pos, ldp, d_x_dir, ldv);
+    return dmn_check_launch("ray_embed");
+}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 6
+#define DMNERF_ABI_VERSION 7
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -466,6 +466,32 @@ int dmnerf_colsum(const float* d_X, int64_t ldx, int64_t M, int J, float* d_out,
 int dmnerf_ray_points(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, float* d_pts,
                       float* d_dirs, void* stream);
 int dmnerf_copy_cols(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, void* stream);
+
+/* The same path's forward and data-gradient products on the machine's own terms (csrc/gemm_nt.hip, ABI 7): both operands k-fast,
+ * global -> LDS by LDS-DMA into a swizzled ring, ds_read_b128 operand reads, one workgroup = 128 samples x all outputs of the layer.
+ *   dmnerf_pack_nt: the layer's weight matrix in the kernel's form -- d_out [rows_pad][ldb], rows_pad = 32 x dmnerf_gemm_nt_blocks(n)
+ *     x tiles, ldb = 32 (ceil(k0 / 32) + ceil(k1 / 32)), zero-filled padding: row n = source row n, columns [c0, c0 + k0) then (from
+ *     column 32 ceil(k0 / 32)) [c1, c1 + k1) -- the two K ranges of a layer whose input is a cat (dm_nerf.py:87 [h, pts], :90
+ *     [rgb_feature, dirs]); transposed != 0: the source is read as W^T (row n = source COLUMN n, column k = source ROW c + k): the
+ *     data-gradient form.  d_bias_out [rows_pad] (nullable) = the bias, zero beyond n_rows.
+ *   dmnerf_gemm_nt: C[m*ldc + n] = act(sum_k A(m, k) Wp[n][k] + bias[n]) for m < M, n < n_store, zeros in columns [n_store, n_zero)
+ *     (the pad columns that keep the NEXT layer's operand rows 16-byte aligned); A(m, k) = A0[m*lda0 + k] for k < k0, then
+ *     A1[m*lda1 + (k - k0)] (k1 = 0: one range); lda0 / lda1 multiples of 4, base pointers 16-byte aligned, a*_floats = floats from the
+ *     pointer to the end of its allocation (the kernel's descriptor bound: a row's tail may be read past k0 into the next row -- those
+ *     products meet zero weights -- but never past the allocation).  relu; d_mask (nullable): C = mask[m*ldm + n] > 0 ? v : 0 (the
+ *     ReLU derivative of the data gradient); accumulate: C += before relu / mask.  Bias is the accumulator's initial value.
+ *   dmnerf_ray_embed: pts = o + d z, viewdirs = d / |d| per sample (render.py:37,49-57) and Embedder.embed of both (dm_nerf.py:37-38)
+ *     into row-padded buffers x_pos [N*S][ldp], x_dir [N*S][ldv], pad columns zeroed.
+ *   dmnerf_copy_cols_pad: dst[m*ld_dst + c] = c < n ? src[m*ld_src + c] : 0 for c < n_pad -- a column slice as such an operand.      */
+int dmnerf_gemm_nt_blocks(int n_out);
+int dmnerf_pack_nt(const float* d_W, int64_t ldw, int n_rows, int c0, int k0, int c1, int k1, int transposed, const float* d_bias,
+                   float* d_out, int rows_pad, int ldb, float* d_bias_out, void* stream);
+int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats, int k0, const float* d_A1, int64_t lda1, int64_t a1_floats, int k1,
+                   const float* d_B, int64_t b_floats, int ldb, const float* d_bias, float* d_C, int64_t ldc, int n_store, int n_zero,
+                   int64_t M, int relu, const float* d_mask, int64_t ldm, int accumulate, void* stream);
+int dmnerf_copy_cols_pad(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, int n_pad, void* stream);
+int dmnerf_ray_embed(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, int Lp, int Lv,
+                     float* d_x_pos, int ldp, float* d_x_dir, int ldv, void* stream);
 
 /* ---- EXTENSION: the optimizer update and the weight re-packing of a training step as two launches (csrc/optim.hip).
  * The reference steps torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr, betas=(0.9, 0.999))

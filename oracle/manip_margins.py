@@ -81,12 +81,22 @@ def frame_inputs(g):
 
 
 def run_variant(g, net=None, probe=None):
-    """The oracle's frame loop on the fixture's pose, transformation and draws -> the four outputs as ``[n, width]``."""
+    """The chunk loop of ``manipulator_eval`` (networks/manipulator.py:241-270) through the oracle's ``manipulator`` on the fixture's
+    RECORDED ray batches and draws -> the four outputs as ``[n, width]``.  (The rays themselves are not recomputed here: the 4 x 4
+    product ``trans @ ori_pose`` and ``get_rays_k`` round in their last bit as the host's BLAS / vector math library does, and a
+    1-ulp change of a ray direction moves a third of the edited pixels by more than 1e-4 -- measured on the GPU box's host,
+    scripts/diag_manip_conditioning.py.  Ray generation has its own tests; this is about the chain behind it.)"""
     H, W, N_test, ins_num, label, sd_c, sd_f, us = frame_inputs(g)
+    cols = [[], [], [], []]
     with torch.no_grad():
-        out = O.manipulate_frame(sd_c, sd_f, H, W, g["K"].numpy(), g["ori_pose"], g["trans"], N_test, 64, 128, 4.0, 15.0, [label],
-                                 us=us, net=net, probe=probe)
-    return [t.reshape(H * W, -1) for t in out[:4]]
+        for c, s0 in enumerate(range(0, H * W, N_test)):
+            e = min(s0 + N_test, H * W)
+            ori = g["ori_rays"][:, s0:e].contiguous()
+            tar = g["tar_rays"][:, s0:e].contiguous()[None]
+            out = O.manipulator(sd_c, sd_f, ori, tar, 64, 128, 4.0, 15.0, [label], us=us[c], net=net, probe=probe)
+            for col, t in zip(cols, out):
+                col.append(t)
+    return [torch.cat(col, 0) for col in cols]
 
 
 def slope_critical(g):
@@ -113,7 +123,12 @@ def slope_critical(g):
 def frame_conditioning(g, skip=()):
     """``sens [n, 4]`` (see the module docstring; ``skip``: variant names left out), ``critical [n]``, and each variant's outputs."""
     ref = [g[k] for k in OUTPUTS]
-    outs = {name: run_variant(g, net) for name, net in variant_nets().items() if name not in skip}
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, n_threads))        # (layer-sized GEMMs on 128 threads: 134 s for the seven frames instead of 28)
+    try:
+        outs = {name: run_variant(g, net) for name, net in variant_nets().items() if name not in skip}
+    finally:
+        torch.set_num_threads(n_threads)
     sens = torch.stack([torch.stack([(o[k] - ref[k]).abs().amax(-1) for o in outs.values()], 0).amax(0) for k in range(4)], 1)
     critical, _ = slope_critical(g)
     return sens, critical, outs

@@ -1,4 +1,5 @@
-import sys, time, types, torch
+import sys, time, types, warnings, torch
+warnings.filterwarnings('ignore')
 sys.path.insert(0, '.')
 from dm_nerf_amd import config as Cfg
 from dm_nerf_amd.networks import helpers as H, render as R
@@ -22,4 +23,6 @@ for D, W in ((8, 256), (8, 192), (6, 128), (10, 320)):
     for _ in range(2):
         out = R.dm_nerf(torch.stack([ro, rd]), pe, ve, mc, mf, z, ta); (out['rgb_fine'].sum() + out['rgb_coarse'].sum() + out['ins_fine'].sum()).backward()
     torch.cuda.synchronize(); dtt = (time.perf_counter() - t0) / 2
-    print(f"D={D} W={W} fused={mc._fused_ok()}: render {dt*1e3:.1f} ms/4096 rays = {N/dt/1e3:.0f} k rays/s ({2*mac*256*N/dt/1e12:.1f} TFLOP/s); fwd+bwd {dtt*1e3:.1f} ms = {N/dtt/1e3:.0f} k rays/s")
+    tf = 2 * mac * 256 * N / dt / 1e12
+    print(f"D={D} W={W} fused={mc._fused_ok()}: render {dt*1e3:.1f} ms/4096 rays = {N/dt/1e3:.0f} k rays/s ({tf:.1f} TFLOP/s = {tf/157.3:.2f} of the f32 MFMA roof); "
+          f"fwd+bwd {dtt*1e3:.1f} ms = {N/dtt/1e3:.0f} k rays/s ({3*tf*dt/dtt:.1f} TFLOP/s on 3x the forward MACs)", flush=True)

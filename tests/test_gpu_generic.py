@@ -59,6 +59,39 @@ def test_strided_gemm_three_forms(A):
     assert A.G._splits(N, K, 10 ** 6) > 1
 
 
+@pytest.mark.parametrize("M_,K0,K1,N", [(1000, 167, 0, 130), (257, 63, 0, 128), (4097, 320, 63, 320), (300, 192, 27, 96), (129, 96, 0, 18),
+                                         (1000, 1, 0, 320), (513, 384, 0, 400)])
+def test_gemm_nt_forward_and_data_gradient_forms(A, M_, K0, K1, N):
+    """csrc/gemm_nt.hip (the LDS-DMA / ds_read_b128 GEMM of the generic path) against float64: forward relu(X W^T + b) with a cat
+    input as two K ranges, output into a column slice of a wider buffer with its pad columns zeroed; the data-gradient form
+    (W^T packed transposed, ReLU-derivative mask, accumulate); ragged M, K not a multiple of 32, N of 1 .. 13 out-blocks (two tiles)."""
+    G = A.G
+    g = torch.Generator().manual_seed(M_ + N)
+    x0 = G._Act.empty(M_, K0, "cuda"); x0.buf.copy_(torch.randn(M_, x0.ld, generator=g)); x0.buf[:, K0:] = 0
+    x1 = None
+    if K1:
+        x1 = G._Act.empty(M_, K1, "cuda"); x1.buf.copy_(torch.randn(M_, x1.ld, generator=g)); x1.buf[:, K1:] = 0
+    Wt = (torch.randn(N, K0 + K1, generator=g) / (K0 + K1) ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    pk = G._Packed(Wt, b, [(0, K0), (K0, K1)] if K1 else [(0, K0)])
+    ldc = G._ld(N) + 8
+    Y = torch.full((M_, ldc), 7.0, device="cuda")
+    G._linear_nt(x0, pk, G._col(Y, 4), ldc, N, G._ld(N), M_, a1=x1, relu=True)
+    X = torch.cat([x0.buf[:, :K0]] + ([x1.buf[:, :K1]] if K1 else []), 1).double()
+    want = torch.relu(X @ Wt.double().t() + b.double())
+    assert float((Y[:, 4:4 + N].double() - want).abs().max()) <= 2e-5
+    assert bool((Y[:, 4 + N:4 + G._ld(N)] == 0).all()) and bool((Y[:, :4] == 7.0).all()) and bool((Y[:, 4 + G._ld(N):] == 7.0).all())
+    # data gradient through the same layer: dX[:, :K0] = ((dY W)[:, :K0] + 0.5) . [H > 0]
+    dY = G._Act.empty(M_, N, "cuda"); dY.buf.copy_(torch.randn(M_, dY.ld, generator=g)); dY.buf[:, N:] = 0
+    H = torch.randn(M_, G._ld(K0), generator=g).cuda()
+    pt = G._Packed(Wt, None, [(0, N)], n_rows=K0, transposed=True)
+    dX = G._Act.empty(M_, K0, "cuda"); dX.buf.fill_(0.5)
+    G._linear_nt(dY, pt, dX.buf, dX.ld, K0, dX.ld, M_, mask=H, ldm=H.shape[1], accumulate=True)
+    want = (dY.buf[:, :N].double() @ Wt.double()[:, :K0] + 0.5) * (H[:, :K0] > 0)
+    assert float((dX.buf[:, :K0].double() - want).abs().max()) <= 2e-5
+    assert bool((dX.buf[:, K0:] == 0).all())
+
+
 @pytest.mark.parametrize("cfg", SHAPES)
 def test_model_forward_and_gradients_other_shapes(A, cfg):
     D, W, ins_num = cfg["D"], cfg["W"], cfg["ins_num"]
