@@ -34,6 +34,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import bench_extras as X        # noqa: E402  (the --extras legs)
 
 INS_NUM = 13                 # DM-SR 'study' (data/color_dict.json: 13 labels)
 N_RAYS = 4096                # N_test of every shipped config (configs/dmsr/train/study.txt)
@@ -463,30 +464,6 @@ def train_loop_leg(mc, mf, dev, steps, mfma_split=False):
                     "resident dataset) + full optimisation step"}
 
 
-def frame_leg(mc, mf, K, c2w, dev, mfma_split=False):
-    """One complete 640x480 pose through the frame driver (distributed.render_path: raygen of the band, 75 chunks of
-    N_test = 4096 rays, preallocated frame buffers, device-side label / confidence of ins_eval) -- what render_test does
-    per pose (networks/tester.py:58-85) minus file output and CPU metrics."""
-    quiesce()
-    from dm_nerf_amd import distributed as D
-    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, N_test=N_RAYS, N_samples=S_COARSE, near=NEAR, far=FAR,
-                                 mfma_split=mfma_split)
-    with torch.no_grad():
-        D.render_path(c2w[None].to(dev), (H_IMG, W_IMG, K), (mc, mf), args, labels_only=True)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            out = D.render_path(c2w[None].to(dev), (H_IMG, W_IMG, K), (mc, mf), args, labels_only=True)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-    dt = min(ts)
-    return {"frames_per_s": 1.0 / dt, "seconds_per_frame": dt, "rays_per_s": H_IMG * W_IMG / dt,
-            "labels_in_frame": int(len(torch.unique(out["label"]))),
-            "note": "render_path, one 640x480 pose: raygen + 75 x dm_nerf(4096 rays) + label/conf kernel, labels_only"
-                    + ("; opt-in split-bf16 MFMA (args.mfma_split)" if mfma_split else "")}
-
-
 def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
     """the same optimisation step on the oracle (CPU port: PyTorch autograd, scipy assignment, torch
     Adam), N = 1024 rays of the same chunk, penalize on; median of up to 3 timed steps after a warm-up, anomaly detection
@@ -539,155 +516,6 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
         res["anomaly_on"] = {"value": n / dt_on, "seconds": dt_on,
                              "note": "one step with torch.autograd.set_detect_anomaly(True), as the reference ships (dm_nerf.py:5)"}
     return res
-
-
-def render_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref=None, fuse_heads=False, mfma_split=False, ins_num=None):
-    """Not the headline: the same render step (dm_nerf on 4096-ray chunks of the band) in another configuration.
-    fuse_heads: the activation-free rgb_feature_linear / ins_feature_linear folded into the hidden layers (SURVEY 8(f)-4;
-    562 432 instead of 693 504 MAC per sample at ins_num 13, results equal up to f32 re-association).  mfma_split: additionally the
-    GEMMs on the 16-bit MFMA with every f32 operand split into planes -- True / "bf16x3": three bf16 planes, six products;
-    "f16x2": two f16 planes, three products (f32-class accuracy either way; csrc/mlp_split_impl.h, csrc/mlp_f16_impl.h).
-    ins_num: the models' object-code width (BASELINE config 3: Replica office_0 = 59).  Roofline of the fine-network launch from
-    HIP events around it: executed MACs x 16-bit products against the peak of the MFMA type used."""
-    quiesce()
-    from dm_nerf_amd.networks import render as R
-    ins_num = INS_NUM if ins_num is None else ins_num
-    fused = bool(fuse_heads or mfma_split)
-    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None, fuse_heads=fused, mfma_split=mfma_split)
-    n_chunks = ro.shape[0] // N_RAYS
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    with torch.no_grad():
-        for i in range(2):
-            out = R.dm_nerf(torch.stack([ro[:N_RAYS], rd[:N_RAYS]]), pe, ve, mc, mf, z, args)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            c = i % n_chunks
-            out = R.dm_nerf(torch.stack([ro[c * N_RAYS:(c + 1) * N_RAYS], rd[c * N_RAYS:(c + 1) * N_RAYS]]), pe, ve, mc, mf, z, args, _events=ev[i])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-    mac = mac_counts(ins_num)
-    exec_mac = mac["fwd_fused"] if fused else mac["fwd"]
-    products = split_products(mfma_split)
-    peak = B16_MFMA_PEAK_TFLOPS if mfma_split else F32_MFMA_PEAK_TFLOPS
-    k_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))
-    tf = 2.0 * exec_mac * products * N_RAYS * (S_COARSE + N_IMP) / (k_ms * 1e-3) / 1e12
-    res = {"rays_per_s": N_RAYS / dt, "ms_per_step": dt * 1e3, "ins_num": ins_num, "mac_per_sample": exec_mac,
-           "roofline": {"bound": "mfma", "unit": "TFLOP/s", "kernel_ms": k_ms, "achieved": tf, "peak": peak, "frac": tf / peak,
-                        "mfma_products_per_mac": products, "note": "fine-network MLP launch, HIP events; executed MACs x 16-bit products per MAC"},
-           "note": ("opt-in (args.mfma_split = %r): fused heads + split-operand 16-bit MFMA" % (mfma_split,) if mfma_split
-                    else "opt-in (args.fuse_heads)" if fuse_heads else "default f32 path") + ", not the headline metric"}
-    if rgb_ref is not None:                                      # same last chunk as the headline loop
-        res["max_abs_rgb_diff_vs_layerwise"] = float((out['rgb_fine'] - rgb_ref).abs().max())
-    return res
-
-
-def manipulator_leg(mc, mf, K, dev, steps=3):
-    """BASELINE config 5's render: ``manipulator`` (networks/manipulator.py:137-205) on one 4096-ray chunk with T = 1 and T = 2
-    moved objects -- per call 1 + T coarse and 1 + T fine network passes of 64 / 192 samples per ray plus 2 T passes on the merged
-    64 + 128 + 128 T depths (T = 1: 1152 network samples per ray = 4.5 x a dm_nerf render), three resamplings with random u
-    (sample_pdf(det=False) even at evaluation), two exchanger
-    rounds, the final composite.  Rays: the bench camera for the original view; each target view is the same camera
-    moved by a rigid transform (what manipulator_demo does with the edited object's pose, :346-371)."""
-    quiesce()
-    from dm_nerf_amd.networks import helpers as H, manipulator as MA
-    from dm_nerf_amd.synthetic import pose_spherical
-    c2w = pose_spherical(30.0, -65.0, 7.0).to(dev)
-    ro, rd = H.get_rays_k(H_IMG, W_IMG, K, c2w)
-    ori = torch.stack([ro.reshape(-1, 3)[:N_RAYS], rd.reshape(-1, 3)[:N_RAYS]])
-    tars = []
-    for k in range(2):
-        c2 = pose_spherical(30.0 + 4.0 * (k + 1), -65.0, 7.0 + 0.1 * (k + 1)).to(dev)
-        to, td = H.get_rays_k(H_IMG, W_IMG, K, c2)
-        tars.append(torch.stack([to.reshape(-1, 3)[:N_RAYS], td.reshape(-1, 3)[:N_RAYS]]))
-    out = {}
-    for T in (1, 2):
-        args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, target_labels=list(range(1, T + 1)))
-        torch.manual_seed(0); torch.cuda.manual_seed(0)
-        with torch.no_grad():
-            MA.manipulator(None, None, mc, mf, ori, tars[:T], args)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                rgb, ins, _, _ = MA.manipulator(None, None, mc, mf, ori, tars[:T], args)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-        samples = (1 + T) * (2 * S_COARSE + N_IMP) + 2 * T * (S_COARSE + N_IMP + N_IMP * T)   # network evaluations per ray
-        mac = mac_counts(INS_NUM)["fwd"]
-        out[f"T{T}"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "network_samples_per_ray": samples,
-                        "tflops": 2.0 * mac * samples * N_RAYS / dt / 1e12,
-                        "frac_of_f32_mfma_peak": 2.0 * mac * samples * N_RAYS / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                        "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all())}
-    if HAVE_F16X2:                                       # opt-in (args.mfma_split = "f16x2"), T = 1; not an MFMA-roof fraction: three products per MAC
-        args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, target_labels=[1], mfma_split="f16x2")
-        torch.manual_seed(0); torch.cuda.manual_seed(0)
-        with torch.no_grad():
-            MA.manipulator(None, None, mc, mf, ori, tars[:1], args)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                rgb, ins, _, _ = MA.manipulator(None, None, mc, mf, ori, tars[:1], args)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-        out["T1_split_f16x2"] = {"rays_per_s": N_RAYS / dt, "ms_per_call": dt * 1e3, "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all()),
-                                 "note": "opt-in split-f16 network kernels (f32-class, not bitwise the default); not part of the T1 / T2 numbers"}
-    out["note"] = ("manipulator() on one 4096-ray chunk, 64 + 128 samples, T moved objects (default f32 kernels); network_samples_per_ray = "
-                   "(1+T)(64+192) + 2T(192+128T) -- the reference re-evaluates the original rays once per target (:190-193); "
-                   "frac = whole call (incl. resampling, exchanger, composites) against the f32 MFMA roof")
-    return out
-
-
-def manipulator_frame_leg(mc, mf, K, dev, world=1):
-    """BASELINE config 5's manipulation render as a FRAME: one whole 640 x 480 pose through the product's sharded frame driver
-    (distributed.manipulate_frame = the per-pose chunk loop of manipulator_eval, networks/manipulator.py:232-270; T = 1 as the
-    reference evaluates it), 75 chunks of N_test = 4096 rays, target view = ``trans @ pose``, the 2 + T draws per chunk from the
-    device generator, ONE all-gather of the packed band per frame at N > 1.  At N = 1 also the time of ONE band of an 8-way split
-    (``rank=0, world=8``: 38 400 rays) -- what one of 8 GPUs would take for its share of the same frame."""
-    quiesce()
-    from dm_nerf_amd import distributed as D
-    from dm_nerf_amd.synthetic import pose_spherical
-    pose = pose_spherical(30.0, -65.0, 7.0)
-    ang = 0.15
-    trans = torch.tensor([[np.cos(ang), -np.sin(ang), 0., 0.3], [np.sin(ang), np.cos(ang), 0., -0.2], [0., 0., 1., 0.1], [0., 0., 0., 1.]],
-                         dtype=torch.float32)
-    args = types.SimpleNamespace(N_samples=S_COARSE, N_importance=N_IMP, near=NEAR, far=FAR, N_test=N_RAYS, target_label=1)
-    T = 1
-    samples = (1 + T) * (2 * S_COARSE + N_IMP) + 2 * T * (S_COARSE + N_IMP + N_IMP * T)
-    mac = mac_counts(INS_NUM)["fwd"]
-
-    def timed(**kw):
-        torch.manual_seed(0); torch.cuda.manual_seed(0)
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            frame = D.manipulate_frame(H_IMG, W_IMG, K, pose.to(dev), [trans], (mc, mf), args, **kw)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, frame
-    with torch.no_grad():                                      # warm-up: the first rows of the frame as one chunk
-        D.manipulate_frame(8, W_IMG, K, pose.to(dev), [trans], (mc, mf), args, rank=0, world=1)
-    dt, frame = timed()
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    n = H_IMG * W_IMG
-    out = {"rays_per_s": n / dt, "s_per_frame": dt, "n_gpus": world, "T": T, "chunks": -(-n // N_RAYS), "network_samples_per_ray": samples,
-           "tflops": 2.0 * mac * samples * n / dt / 1e12,
-           "frac_of_f32_mfma_peak": 2.0 * mac * samples * n / dt / 1e12 / (F32_MFMA_PEAK_TFLOPS * world),
-           "finite": bool(all(torch.isfinite(t).all() for t in frame)), "labels_in_frame": int(len(torch.unique(frame[1].argmax(-1)))),
-           "note": "one whole 640x480 pose through distributed.manipulate_frame (manipulator_eval's chunk loop: 75 x 4096 rays, T = 1, "
-                   "default f32 kernels); the whole frame incl. raygen of both views, resampling, exchanger, composites and the band "
-                   "gather against the f32 MFMA roof of the GPUs used"}
-    if world == 1:
-        dt8, _ = timed(rank=0, world=8)
-        out["band_of_8"] = {"rays": n // 8, "s": dt8, "predicted_8gpu_rays_per_s": n / dt8, "predicted_efficiency_before_gather": dt / 8 / dt8}
-    return out
 
 
 def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
@@ -930,7 +758,7 @@ def multi_rank_legs(a, w, sc):
             train_multi = {"error": f"{type(e).__name__}: {e}"}
     if w.world > 1 and a.extras:
         try:                                                    # (never `value`)
-            mani_multi = manipulator_frame_leg(sc.mc, sc.mf, sc.K, w.dev, world=w.world)
+            mani_multi = X.manipulator_frame_leg(sc.mc, sc.mf, sc.K, w.dev, world=w.world)
         except Exception as e:                                  # noqa: BLE001
             mani_multi = {"error": f"{type(e).__name__}: {e}"}
     return train_multi, mani_multi
@@ -997,18 +825,18 @@ def single_gpu_render_legs(a, w, sc, h, res):
         res["speedup_vs_cpu"] = None if res["value"] is None else res["value"] / base["value"]
     wide = None
     if a.extras:
-        res["frame"] = frame_leg(mc, mf, sc.K, sc.c2w, w.dev)
-        res["render_fused_heads"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], fuse_heads=True)
-        res["render_split_bf16"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split=True)
-        res["frame_split_bf16"] = frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split=True)
+        res["frame"] = X.frame_leg(mc, mf, sc.K, sc.c2w, w.dev)
+        res["render_fused_heads"] = X.render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], fuse_heads=True)
+        res["render_split_bf16"] = X.render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split=True)
+        res["frame_split_bf16"] = X.frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split=True)
         if HAVE_F16X2:
-            res["render_split_f16x2"] = render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
-            res["frame_split_f16x2"] = frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split="f16x2")
-        res["manipulator"] = manipulator_leg(mc, mf, sc.K, w.dev)
-        res["manipulator_frame"] = manipulator_frame_leg(mc, mf, sc.K, w.dev)
+            res["render_split_f16x2"] = X.render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
+            res["frame_split_f16x2"] = X.frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split="f16x2")
+        res["manipulator"] = X.manipulator_leg(mc, mf, sc.K, w.dev)
+        res["manipulator_frame"] = X.manipulator_frame_leg(mc, mf, sc.K, w.dev)
         if INS_NUM != 59:                               # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
             wide = build_models(w.dev, 59)
-            res["render_ins59"] = render_leg(*wide, ro, rd, z, a.steps, ins_num=59)
+            res["render_ins59"] = X.render_leg(*wide, ro, rd, z, a.steps, ins_num=59)
     return wide
 
 
@@ -1175,6 +1003,7 @@ def write_full_record(res, path):
 
 def main():
     global INS_NUM, MAC_PER_SAMPLE, HAVE_F16X2
+    X.bind(sys.modules[__name__])
     a = parse()
     t_wall = time.perf_counter()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -32,9 +32,16 @@ using namespace dmn;
 
 namespace {
 
-constexpr int NT_RING_BYTES = 147456;     // ring budget of the CU's 160 KiB
+constexpr int NT_RING_BYTES = 147456;     // ring budget of the CU's 160 KiB when ONE workgroup owns the CU
+constexpr int NT_RING_BYTES_2 = 81920;    // ... and when TWO share it (narrow layers: see nt_occupancy)
 constexpr int NT_MAX_DEPTH = 4;
 constexpr int NT_MAX_NBB = 12;            // 384 outputs per workgroup: 192 accumulator registers
+
+// Workgroups per CU.  A tile's fixed cost -- launch, the first chunk's DMA latency, the epilogue's stores draining -- is ~10 us
+// (measured: a 63 -> 192 layer, 2 chunks, took 15 us per tile for 5 us of MFMA work); with one workgroup per CU nothing runs under
+// it.  Up to 6 out-blocks a wave needs < 256 registers and the ring fits 80 KiB at depth 2, so two workgroups share a CU and one's
+// prologue / epilogue hides under the other's MFMA stream; wider tiles (longer K loops, relatively smaller fixed cost) keep the CU.
+constexpr int nt_occupancy(int nbb) { return nbb <= 6 ? 2 : 1; }
 
 struct NtArgs {
     const float* A0; const float* A1;     // the two K ranges of the A operand (A1 null: one range)
@@ -55,13 +62,14 @@ template <int NBB>
 struct NtRing {
     static constexpr int NL = 4 + NBB;                                   // DMA pieces per wave per chunk (1 KiB each)
     static constexpr int BUF = NL * 4096;                                // bytes per chunk
-    static constexpr int D = NT_RING_BYTES / BUF < NT_MAX_DEPTH ? NT_RING_BYTES / BUF : NT_MAX_DEPTH;
+    static constexpr int BUDGET = nt_occupancy(NBB) == 2 ? NT_RING_BYTES_2 : NT_RING_BYTES;
+    static constexpr int D = BUDGET / BUF < NT_MAX_DEPTH ? BUDGET / BUF : NT_MAX_DEPTH;
     static_assert(D >= 2, "ring needs two slots");
     static_assert((D - 1) * NL <= 63, "vmcnt range");
 };
 
 template <int NBB>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
+__global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef NtRing<NBB> RG;
     constexpr int NL = RG::NL, D = RG::D, BUF = RG::BUF;
@@ -90,8 +98,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
     const rsrc_t rsB = uniform_rsrc(a.B + (int64_t)j0 * a.ldb, bound((int64_t)NBB * 32 * a.ldb, a.b_floats - (int64_t)j0 * a.ldb));
     const int blkA0 = (int)(32 * a.lda0 * 4), blkA1 = (int)(32 * a.lda1 * 4), blkB = 32 * a.ldb * 4;      // bytes per 32-row block
 
-    auto dma_chunk_piece = [&](int c, unsigned slot_byte, int i) {       // piece i of NL for chunk c (clamped) into a ring slot
-        const int cc = c < nchunk ? c : nchunk - 1;
+    auto dma_chunk_piece = [&](int cc, unsigned slot_byte, int i) {      // piece i of NL of chunk cc (< nchunk) into a ring slot
         float* dst = lds + (slot_byte + i * 4096 + w * 1024) / 4;
         if (i < 4) {
             if (cc < a.nc0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (DMN_LAS void*)dst, 16, voA0, i * blkA0 + cc * 128, 0, 0);
@@ -124,12 +131,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
         else lds_read16_async<(g - 1) * 4096>(bv[buf][g - 1], addrB);
     };
 
-    // ---- prologue: D chunks in flight, chunk 0 landed, its round-0 operands on their way
+    // ---- prologue: the first D chunks in flight (those that exist), chunk 0 landed, its round-0 operands on their way
 #pragma unroll
     for (int sl = 0; sl < D; ++sl)
+        if (sl < nchunk) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));     // vmcnt((D-1) NL) only
+            for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
+        }
+    if (nchunk >= D) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));     // vmcnt((D-1) NL) only
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                         // a short K: everything
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
@@ -154,8 +164,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
 #pragma unroll
             for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
             if constexpr (r == 3) {
-                // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
+                // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released.  In flight behind
+                // chunk c + 1 are the D - 2 chunks after it -- or fewer at the end of the K range (no refill is issued for chunks that
+                // do not exist), where waiting for everything is exact enough
+                if (c + D - 1 < nchunk) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
@@ -164,13 +177,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
                 constexpr int g = decltype(gc)::value;
                 constexpr int u = g / NBB, ib = g % NBB;
                 if constexpr (g < NR) read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
-                if constexpr (r == 3) {                                 // refill the released slot with chunk c + D
+                if constexpr (r == 3) {                                 // refill the released slot with chunk c + D (if there is one)
                     constexpr int G0 = NR < NGAP ? NR : NGAP - 1;
                     constexpr int PD = (NGAP - G0) / NL > 0 ? (NGAP - G0) / NL : 1;
                     static_for<NL>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         constexpr int at = G0 + i * PD < NGAP ? G0 + i * PD : NGAP - 1;
-                        if constexpr (at == g) dma_chunk_piece(c + D, sb, i);
+                        if constexpr (at == g) {
+                            if (c + D < nchunk) dma_chunk_piece(c + D, sb, i);
+                        }
                     });
                 }
                 acc[ib] = mfma32(av[r & 1][0][u], bv[r & 1][ib][u], acc[ib]);
@@ -179,8 +194,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
         });
         sb = nb;
     }
-    // the ring's last (clamped) refills and the read-ahead of the chunk after the last one land in LDS / registers nobody uses,
-    // but they must have landed before the workgroup's LDS is handed on (the ties keep the read-ahead's registers allocated)
+    // the read-ahead of the chunk after the last one lands in registers nobody uses, but it must have landed before the
+    // workgroup's LDS is handed on (the ties keep its registers allocated)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("" : "+" DMN_TILE_RC(av[0][0]));
 #pragma unroll

@@ -209,7 +209,8 @@ def forward_layers(net, x_pos, x_dir, save):
         else:
             _linear_nt(h, pk[f"mlps.{i}"], out.buf, out.ld, W, out.ld, M, a1=x_pos if net.after_skip(i) else None, relu=True)
         h = out
-        hs.append(h)
+        if save is not None:                                 # (inference keeps only the current layer's input alive)
+            hs.append(h)
     xr = _Act.empty(M, W, dev)                               # rgb_feature (no activation, :89); cat[., dirs] (:90) = the next layer's 2nd range
     _linear_nt(h, pk["rf"], xr.buf, xr.ld, W, xr.ld, M)
     g1 = _Act.empty(M, HW, dev)
@@ -324,7 +325,13 @@ def _run(model, x_pos, x_dir, train):
     params = [p for _, p in model.named_parameters()]
     if train:
         return GenericMLPFunction.apply(model, x_pos, x_dir, *params)
-    return forward_layers(_Net(model, [p.detach() for p in params]), x_pos, x_dir, None)
+    # inference: the packed weights are kept with the model until a parameter changes (the key DM_NeRF.blob() uses)
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cached = getattr(model, "_generic_net", None)
+    if cached is None or cached[0] != key:
+        cached = (key, _Net(model, [p.detach() for p in params]))
+        model._generic_net = cached
+    return forward_layers(cached[1], x_pos, x_dir, None)
 
 
 def run_network(model, rays_o, rays_d, z, train=False):

@@ -1,9 +1,11 @@
 import sys, time, types, warnings, torch
 warnings.filterwarnings('ignore')
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dm_nerf_amd import config as Cfg
 from dm_nerf_amd.networks import helpers as H, render as R
-for D, W in ((8, 256), (8, 192), (6, 128), (10, 320)):
+SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(8, 256), (8, 192), (6, 128), (10, 320)]
+for D, W in SHAPES:
     args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=D, netwidth=W, ins_num=13, device=torch.device("cuda:0"))
     pe, ve, mc, mf, _ = Cfg.create_nerf(args)
     N = 4096

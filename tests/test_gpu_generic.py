@@ -79,7 +79,7 @@ def test_gemm_nt_forward_and_data_gradient_forms(A, M_, K0, K1, N):
     G._linear_nt(x0, pk, G._col(Y, 4), ldc, N, G._ld(N), M_, a1=x1, relu=True)
     X = torch.cat([x0.buf[:, :K0]] + ([x1.buf[:, :K1]] if K1 else []), 1).double()
     want = torch.relu(X @ Wt.double().t() + b.double())
-    assert float((Y[:, 4:4 + N].double() - want).abs().max()) <= 2e-5
+    assert float((Y[:, 4:4 + N].double() - want).abs().max()) <= 2e-6 * max(10.0, float(want.abs().max()))
     assert bool((Y[:, 4 + N:4 + G._ld(N)] == 0).all()) and bool((Y[:, :4] == 7.0).all()) and bool((Y[:, 4 + G._ld(N):] == 7.0).all())
     # data gradient through the same layer: dX[:, :K0] = ((dY W)[:, :K0] + 0.5) . [H > 0]
     dY = G._Act.empty(M_, N, "cuda"); dY.buf.copy_(torch.randn(M_, dY.ld, generator=g)); dY.buf[:, N:] = 0
@@ -88,7 +88,7 @@ def test_gemm_nt_forward_and_data_gradient_forms(A, M_, K0, K1, N):
     dX = G._Act.empty(M_, K0, "cuda"); dX.buf.fill_(0.5)
     G._linear_nt(dY, pt, dX.buf, dX.ld, K0, dX.ld, M_, mask=H, ldm=H.shape[1], accumulate=True)
     want = (dY.buf[:, :N].double() @ Wt.double()[:, :K0] + 0.5) * (H[:, :K0] > 0)
-    assert float((dX.buf[:, :K0].double() - want).abs().max()) <= 2e-5
+    assert float((dX.buf[:, :K0].double() - want).abs().max()) <= 2e-6 * max(10.0, float(want.abs().max()))     # (sums of N terms: up to ~25)
     assert bool((dX.buf[:, K0:] == 0).all())
 
 
