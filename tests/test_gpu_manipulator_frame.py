@@ -173,7 +173,7 @@ def test_against_the_reference_manipulator_eval_run(golden, capsys):
     (oracle/manip_margins.py): tolerance = 1e-4 + 4 x the largest deviation SEVEN other f32-class evaluations
     of the same chain show at that pixel (the oracle on this host, the network in float64, K summed in 2 / 3 / 4 / 5 / 8 pieces) --
     1e-4 .. 2e-4 on more than 80 % of the pixels.  At most 1 % of the pixels may exceed it, only pixels with a draw ON the slope
-    threshold (about 10 % of the rays have one of their 384 draws there) by more than ten times, and the label equals the
+    threshold (about 10 % of the rays have one of their 384 draws there) by more than fifty times, and the label equals the
     reference's wherever the reference's top-2 margin exceeds twice the tolerance.  The rule's soundness (it accepts each of the
     seven evaluations when the tolerance is measured without it) and power (it rejects a frame with 20 % or 2 % of its pixels
     mis-routed) are shown on the CPU: tests/test_manip_conditioning.py."""
