@@ -12,7 +12,10 @@ every rank renders the chunks of its own band of image rows (``--scaling weak``,
 step; ``--scaling strong``: the 4096-ray step is split over the ranks) and the finished band is all-gathered ONCE PER
 FRAME over RCCL (what distributed.render_frame does).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`; secondary objects
+The LAST stdout line of rank 0 is the bounded contract line (<= 4096 bytes, strict JSON: the task statement's fields with `roofline`
+and `cpu_baseline`, plus scalars of the training legs and, at N > 1, what the process group was -- `rccl`); the FULL record (every leg,
+per-kernel tables, notes) goes to bench_full.json beside this file and, as one prefixed line, to stderr.  Modules: bench_common.py
+(constants, MAC counts, peaks), bench_train.py (training legs), bench_extras.py (the `--extras` legs).  Secondary objects
 (never part of `value`): `frame` (one complete 640x480 pose through the frame driver), `train` (one optimisation step,
 its own per-kernel roofline and CPU baseline), `train_loop` (the shipped N_train = 3072 loop incl. batch selection),
 `render_fused_heads`, `render_split_bf16`, `frame_split_bf16`, `train_fused_heads`, `train_split_bf16` (opt-in modes),
@@ -34,60 +37,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import bench_common as C        # noqa: E402  (constants, MAC counts, peaks)
 import bench_extras as X        # noqa: E402  (the --extras legs)
-
-INS_NUM = 13                 # DM-SR 'study' (data/color_dict.json: 13 labels)
-N_RAYS = 4096                # N_test of every shipped config (configs/dmsr/train/study.txt)
-N_TRAIN_SHIPPED = 3072       # N_train of the shipped train configs (configs/dmsr/train/study.txt)
-S_COARSE, N_IMP = 64, 128
-H_IMG, W_IMG = 480, 640
-NEAR, FAR = 4.0, 15.0
-MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)          # 693 504
-F32_MFMA_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-B16_MFMA_PEAK_TFLOPS = 2500.0                          # same guide: dense bf16 / f16 v_mfma_f32_32x32x16_*
-HAVE_F16X2 = False                                     # set in main(): the library exports the f16x2 split kernels
-HBM_PEAK_GBS, HBM_ACHIEVABLE_GBS = 8000.0, 6290.0      # same guide: HBM3E spec; the rate its own streaming benchmark measures
-# HBM bytes per SAMPLE of the three training kernels at ins_num 13, from the committed rocprofv3 PMC passes of the 4096-ray step
-# (profiles/r05/pmc_train_r05.txt, identical to r04's: separate --pmc runs, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, fine launch = 786 432 samples;
-# the f16x2 kernels move the same f32 rows: their counters agree within 1 %; bf16x3 saves the same rows, not separately measured).
-# Counters cannot be read from inside the process, so these are NOT measured in this run: they turn a kernel time measured
-# here into a GB/s figure, so that a kernel's `bound` says which roof it is actually closer to.
-TRAIN_HBM_BYTES_PER_SAMPLE = {"mlp_fwd_train": (2 * 2.9427e5 + 7.6308e6) * 1e3 / 786432, "mlp_bwd_data": (2 * 3.3592e5 + 7.1332e6) * 1e3 / 786432,
-                              "mlp_bwd_weights": (2 * 0.75 * 2 * 5.5508e6 + 0.75 * 2 * 63148) * 1e3 / 786432}
-TRAIN_HBM_BYTES_SOURCE = "profiles/r05/pmc_train_r05.txt"
-# The three kernels those byte counts were measured on.  If a kernel of that family is renamed or re-templated the counts are stale:
-# train_hbm_bytes_per_sample() then returns None (no HBM view is reported) instead of pricing a new kernel with an old kernel's bytes.
-TRAIN_HBM_KERNELS = ("mlp_fwd_kernel<1, false, true, false>", "mlp_bwd_kernel<1>", "wgrad_kernel")
-
-
-def train_hbm_bytes_per_sample():
-    """TRAIN_HBM_BYTES_PER_SAMPLE, but only while the committed PMC file still names the kernels this build launches:
-    every name of TRAIN_HBM_KERNELS must appear in the profile; cached."""
-    if "v" not in _hbm_cache:
-        ok = False
-        try:
-            with open(os.path.join(ROOT, TRAIN_HBM_BYTES_SOURCE)) as f:
-                txt = f.read().replace(" ", "")
-            ok = all(k.replace(" ", "") in txt for k in TRAIN_HBM_KERNELS)
-        except OSError:
-            pass
-        _hbm_cache["v"] = TRAIN_HBM_BYTES_PER_SAMPLE if ok else None
-    return _hbm_cache["v"]
-
-
-_hbm_cache = {}
-
-
-def mac_counts(ins_num):
-    """MACs per sample.  ``reference_*``: the reference's formulation (forward = wgrad = 691 712 + 128 C,
-    dgrad = that - 101 248).  ``fwd`` / ``fwd_fused`` / ``dgrad`` / ``wgrad``: what this library's kernels EXECUTE after the head
-    re-association (useful MACs, zero padding not counted): the fused-heads / split forward and the
-    weight-gradient kernel lose the two activation-free 256 x 256 products (-131 072); the data-gradient kernel runs
-    mlps.7^T .. mlps.1^T (7 x 65 536), F^T (32 768), ins_linear^T (128 C) and the two VALU heads (384 + 256)."""
-    C = ins_num + 1
-    ref = 691712 + 128 * C
-    return {"reference_fwd": ref, "reference_dgrad": ref - 101248, "reference_wgrad": ref,
-            "fwd": ref, "fwd_fused": ref - 131072, "dgrad": 7 * 65536 + 32768 + 128 * C + 384 + 256, "wgrad": ref - 131072}
+import bench_train as T         # noqa: E402  (the training legs)
+# (the experiment scripts under scripts/ read the workload and the legs through this module)
+from bench_common import (FAR, H_IMG, INS_NUM, N_IMP, N_RAYS, N_TRAIN_SHIPPED, NEAR, S_COARSE, W_IMG, build_models, mac_counts,   # noqa: E402,F401
+                          quiesce, warm_up)
+from bench_train import graph_train_leg, train_leg, train_loop_leg         # noqa: E402,F401
 
 
 def parse():
@@ -111,357 +67,9 @@ def parse():
                         "as fit -- one, on the GPU box's host -- so that the default bench stays near a minute; on a slow host the sample shrinks")
     p.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"),
                    help="where rank 0 writes the FULL record (every leg, per-kernel tables, notes); the stdout line is the bounded contract line")
-    p.add_argument("--ins-num", type=int, default=INS_NUM,
+    p.add_argument("--ins-num", type=int, default=C.INS_NUM,
                    help="object-code width: 13 = DM-SR 'study' (the headline config); 59 / 93 = Replica office_0 / room_0 (BASELINE config 2)")
     return p.parse_args()
-
-
-def quiesce():
-    """At the START of a measurement leg, before its warm-up steps: run the cyclic garbage collector now.  A full (generation-2)
-    collection of a process holding a few hundred thousand Python objects pauses the host for 50-80 ms; landing inside a 20-step
-    timed loop it drains the launch queue and reads as +2 .. 4 ms per step (seen on `train_loop` when an unrelated change moved the
-    pause; scripts/diag_train_loop.py: the same loop is within 1 % of the resident-batch step).  A long training run pays such a
-    pause once per many thousand steps.  Not placed between warm-up and timing: the GPU would sit idle for the length of the
-    collection and start the timed steps from a lower clock (measured: +2 .. 5 % on the training kernels)."""
-    import gc
-    gc.collect()
-
-
-def warm_up(one, min_steps=2, seconds=0.4):
-    """Untimed warm-up of a leg: at least ``min_steps`` calls and ``seconds`` of back-to-back GPU work.  The training legs follow
-    CPU baselines that leave the GPU idle for tens of seconds; the first ~100 ms of kernels after an idle period run 2-5 % slower
-    (clock ramp), which two 27 ms steps do not cover."""
-    t0 = time.perf_counter()
-    k = 0
-    while k < min_steps or time.perf_counter() - t0 < seconds:
-        one()
-        torch.cuda.synchronize()
-        k += 1
-
-
-def flush_c_stdio():
-    """RCCL prints its version banner with printf (NCCL_DEBUG=VERSION on this pool); on a pipe that sits in the C
-    buffer until exit and would land BEHIND the JSON line.  Push it out early instead."""
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:                                           # noqa: BLE001
-        pass
-
-
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command (counters need
-    their own ``--pmc`` runs, they cannot be read from inside the process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE,
-    profiles/pmc_traffic.json -> (bytes, provenance) or (None, None)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            d = json.load(f)
-        return d["traffic_bytes_per_launch"], d.get("source", "profiles/pmc_traffic.json")
-    except Exception:                                           # noqa: BLE001
-        return None, None
-
-
-def host_info():
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except Exception:                                           # noqa: BLE001
-        pass
-    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
-
-
-def build_models(device, ins_num=None):
-    from dm_nerf_amd import config as Cfg
-    torch.manual_seed(0)
-    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=8, netwidth=256,
-                                 ins_num=INS_NUM if ins_num is None else ins_num, device=device)
-    pe, ve, mc, mf, _ = Cfg.create_nerf(args)
-    with torch.no_grad():                       # "trained-like": give the density head surfaces (SURVEY 8d)
-        mc.density_linear.bias.add_(0.3)
-        mf.density_linear.bias.add_(0.3)
-    return pe, ve, mc.eval(), mf.eval()
-
-
-def train_flop_per_ray(ins_num=None):
-    m = mac_counts(INS_NUM if ins_num is None else ins_num)
-    return 2.0 * (m["reference_fwd"] + m["reference_wgrad"] + m["reference_dgrad"]) * (2 * S_COARSE + N_IMP)
-
-
-def train_leg(mc, mf, ro, rd, z, steps, dev, world=1, n=None, fuse_heads=False, mfma_split=False, ins_num=None, flat_adam=False):
-    """Secondary measurement: rays/s of one full optimisation step on ONE batch of ``n`` rays (default 4096 per GPU;
-    64+128 samples, perturb=1), the sequence of train_dmsr.py:32-64: dm_nerf forward with saved activations, img2mse on both
-    levels, the emptiness penalizer on both levels (fused HIP kernels, tolerance / deta_w of
-    configs/dmsr/train/study.txt), the Hungarian-matched object-code loss ins_criterion on both levels (device
-    kernels: the reference solves the assignment with scipy on the host), backward (composite_bwd,
-    dgrad, wgrad kernels), Adam(lr 5e-4).  Labels: a synthetic 9-object segmentation of the batch.
-    world > 1: the batch is sharded over the ranks by dm_nerf_amd.distributed.sharded_train_step -- batch-global losses on
-    all-gathered rgb / ins, penalizer sums and the 5.57 MB gradient arena all-reduced in place over RCCL; ``ro`` / ``rd``
-    must then hold the same rays on every rank.  Also returns the per-kernel roofline of the three MFMA kernels of the
-    fine-network pass, timed with HIP events on their stream (autograd.KERNEL_EVENTS): ``frac`` divides the MACs the kernel
-    EXECUTES (mac_counts) by the peak of the MFMA type it runs on; ``algorithmic_tflops`` is the reference's FLOP count of
-    the stage over the same time -- larger than ``achieved`` where the head re-association removed work."""
-    quiesce()
-    from dm_nerf_amd import autograd as G, distributed as D
-    ins_num = INS_NUM if ins_num is None else ins_num
-    mc.train(); mf.train()
-    params = list(mc.parameters()) + list(mf.parameters())
-    if flat_adam:                                       # extension (dm_nerf_amd.optim.FlatAdam): update + re-pack as two launches
-        from dm_nerf_amd.optim import FlatAdam
-        opt = FlatAdam((mc, mf), lr=5e-4, betas=(0.9, 0.999))
-    else:                                               # the reference's optimizer (train_dmsr.py:124-125)
-        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
-    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
-                                 fuse_heads=fuse_heads, mfma_split=mfma_split)
-    n = N_RAYS * world if n is None else n
-    g = torch.Generator(device=dev).manual_seed(0)
-    target = torch.rand(n, 3, device=dev, generator=g)
-    labels = torch.randint(0, 9, (n,), device=dev, generator=g)
-    rays = torch.stack([ro[:n], rd[:n]])
-    z = z[:n].contiguous()
-    assert rays.shape[1] == n and z.shape[0] == n
-    torch.manual_seed(0)                                # identical jitter streams on every rank
-    torch.cuda.manual_seed(0)
-
-    nbytes_seen = [0]
-
-    def one():
-        loss, nbytes_seen[0] = D.sharded_train_step(rays, z, target, labels, (mc, mf), args, opt, ins_num)
-        return loss
-
-    def fence():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-    warm_up(one, seconds=0.4 if world == 1 else 0.0)           # (N > 1: a fixed count -- every step contains collectives)
-    fence()
-    G.KERNEL_EVENTS = []
-    D.collective_tally(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = one()
-    tally = D.collective_tally()                        # (before the fence: its barrier is not part of the step)
-    fence()
-    dt = (time.perf_counter() - t0) / steps
-    events, G.KERNEL_EVENTS = G.KERNEL_EVENTS, None
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    mc.eval(); mf.eval()
-    mac = mac_counts(ins_num)
-    flop_ref = train_flop_per_ray(ins_num) * n
-    # per-kernel roofline of the fine-network launches (the dominant ones: 192 of the 256 samples per ray)
-    n_local = D.ray_slice(n, D.world_info()[0], world)[1]
-    m_fine = n_local * (S_COARSE + N_IMP)
-    obi = (ins_num + 32) // 32
-    fwd_exec = mac["fwd_fused"] if (mfma_split or fuse_heads) else mac["fwd"]
-    products = split_products(mfma_split)               # 16-bit MFMA products per f32 product (1 on the f32 MFMA)
-    peak = B16_MFMA_PEAK_TFLOPS if mfma_split else F32_MFMA_PEAK_TFLOPS
-    exec_mac = {"mlp_fwd_train": fwd_exec, "mlp_bwd_data": mac["dgrad"], "mlp_bwd_weights": mac["wgrad"]}
-    ref_mac = {"mlp_fwd_train": mac["reference_fwd"], "mlp_bwd_data": mac["reference_dgrad"], "mlp_bwd_weights": mac["reference_wgrad"]}
-    names = {"mlp_fwd_train": f"mlp_fwd_kernel<{obi},false,true,false>", "mlp_bwd_data": f"mlp_bwd_kernel<{obi}>",
-             "mlp_bwd_weights": "wgrad_kernel + wgrad_reduce_kernel + head_unfuse_kernel"}
-    if mfma_split:
-        names.update(split_kernel_names(mfma_split, obi))
-    elif fuse_heads:
-        names.update(mlp_fwd_train=f"mlp_fwd_kernel<{obi},true,true,false>")
-    kernels = []
-    for tag in ("mlp_fwd_train", "mlp_bwd_data", "mlp_bwd_weights"):
-        ms = [b.elapsed_time(e) for t, M, b, e in events if t == tag and M == m_fine]
-        if ms:
-            k_ms = float(np.mean(ms))
-            tf = 2.0 * exec_mac[tag] * products * m_fine / (k_ms * 1e-3) / 1e12
-            tf_ref = 2.0 * ref_mac[tag] * m_fine / (k_ms * 1e-3) / 1e12
-            entry = {"kernel": names[tag], "launches": len(ms), "kernel_ms": k_ms, "mac_per_sample_executed": exec_mac[tag],
-                     "mfma_products_per_mac": products, "bound": "mfma", "unit": "TFLOP/s", "achieved": tf, "peak": peak, "frac": tf / peak,
-                     "algorithmic_tflops": tf_ref}
-            entry["frac_best_roof"], entry["bound_best_roof"] = entry["frac"], "mfma"
-            hbm_bytes = train_hbm_bytes_per_sample() if ins_num == 13 else None
-            if hbm_bytes is not None:
-                # which roof is this kernel closer to?  (the opt-in f16x2 weight-gradient kernel reads the same f32 rows as the f32
-                # one in less than half the time: it sits at 0.74 of the HBM spec and 0.38 of the 16-bit MFMA roof -- HBM-bound.)
-                # `frac` stays the MFMA fraction (the definition of rounds 1-4, comparable across rounds); the HBM view rides beside it
-                # and `frac_best_roof` = max of the two
-                gbs = hbm_bytes[tag] * m_fine / (k_ms * 1e-3) / 1e9
-                entry["hbm"] = {"achieved_GBs": gbs, "frac_of_spec_8TBs": gbs / HBM_PEAK_GBS, "frac_of_guide_measured_6.29TBs": gbs / HBM_ACHIEVABLE_GBS,
-                                "bytes_per_sample": hbm_bytes[tag], "bytes_source": TRAIN_HBM_BYTES_SOURCE,
-                                "traffic_measured_in_this_run": False}
-                if gbs / HBM_PEAK_GBS > entry["frac"]:
-                    entry.update(frac_best_roof=gbs / HBM_PEAK_GBS, bound_best_roof="hbm")
-            kernels.append(entry)
-    worst = min(kernels, key=lambda k: k["frac"]) if kernels else None
-    flop_exec = 2.0 * (fwd_exec + mac["dgrad"] + mac["wgrad"]) * products * (2 * S_COARSE + N_IMP) * n
-    return {"rays_per_s": n / dt, "ms_per_step": dt * 1e3, "tflops": flop_exec / dt / 1e12, "tflops_reference_flops": flop_ref / dt / 1e12,
-            "frac_of_mfma_peak": {"executed": flop_exec / dt / 1e12 / (peak * world), "peak": peak,
-                                  "note": "whole step incl. losses, compositing, Adam, on the MFMA work the three MLP kernels issue (mac_counts); "
-                                          "`tflops_reference_flops` = the same time against SURVEY 8(d)'s 1013 MFLOP/ray "
-                                          "(the head re-association removed work, "
-                                          "so it is not a fraction of any roof)"},
-            "final_loss": float(loss.detach()),
-            "batch_rays": n, "ins_num": ins_num, "rays_this_rank": n_local,
-            "allreduce_bytes_per_step": int(nbytes_seen[0]), "collectives_per_step": tally["count"] / max(steps, 1),
-            "collective_kinds_per_step": {k: v / max(steps, 1) for k, v in tally["kinds"].items()},
-            "collective_send_bytes_per_step": tally["bytes"] / max(steps, 1),
-            "roofline": None if worst is None else {"bound": worst["bound"], "unit": worst["unit"], "peak": worst["peak"], "kernel": worst["kernel"],
-                                                    "kernel_ms": worst["kernel_ms"], "achieved": worst["achieved"], "frac": worst["frac"],
-                                                    "frac_best_roof_worst": min(k["frac_best_roof"] for k in kernels),
-                                                    "samples_per_launch": m_fine, "all": kernels,
-                                                    "note": "fine-network launches (192 samples/ray), HIP events on the launch stream; "
-                                                            "`kernel` = the one furthest below the MFMA roof on EXECUTED MACs (`frac`, the "
-                                                            "definition of every round); each kernel also carries `hbm` (its HBM bytes per sample "
-                                                            "from committed PMC passes against 8 TB/s) and `frac_best_roof` = the larger of the two; "
-                                                            "algorithmic_tflops = the reference's FLOP count of the stage over the same time"},
-            "note": "fwd + img2mse + Hungarian-matched object-code loss (device) + fused emptiness penalizer + bwd + Adam, perturb=1"
-                    + (f"; one batch sharded over {world} ranks (sharded_train_step)" if world > 1 else "")}
-
-
-def split_products(mode):
-    """16-bit MFMA products per f32 product of an ``args.mfma_split`` mode (False: the f32 MFMA, one)."""
-    if not mode:
-        return 1
-    return 3 if str(mode) == "f16x2" else 6
-
-
-def split_kernel_names(mode, obi):
-    obx = 4 if obi == 3 else obi
-    if str(mode) == "f16x2":
-        return {"mlp_fwd_train": f"mlp_f16_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_f16_kernel<{obi}>",
-                "mlp_bwd_weights": "wgrad_f16_kernel + reduce + unfuse"}
-    return {"mlp_fwd_train": f"mlp_split_kernel<{obx},true>", "mlp_bwd_data": f"mlp_bwd_split_kernel<{obi}>",
-            "mlp_bwd_weights": "wgrad_split_kernel + reduce + unfuse"}
-
-
-def graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, mfma_split=False, ins_num=None, flat_adam=False):
-    """The same optimisation step as `train_leg` replayed from ONE HIP graph (dm_nerf_amd.graphed.GraphedTrainStep: forward,
-    losses, every backward kernel, Adam, weight re-packing in a single launch; bit-equal to the eager step,
-    tests/test_gpu_driver.py) on a batch of ``n`` rays: ms per step and the eager figure next to it."""
-    quiesce()
-    from dm_nerf_amd.graphed import GraphedTrainStep
-    ins_num = INS_NUM if ins_num is None else ins_num
-    mc.train(); mf.train()
-    if flat_adam:
-        from dm_nerf_amd.optim import FlatAdam
-        opt = FlatAdam((mc, mf), lr=5e-4, betas=(0.9, 0.999), capturable=True)
-    else:
-        opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=torch.tensor(5e-4, device=dev), betas=(0.9, 0.999), capturable=True)
-    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
-                                 mfma_split=mfma_split)
-    g = torch.Generator(device=dev).manual_seed(0)
-    target = torch.rand(n, 3, device=dev, generator=g)
-    labels = torch.randint(0, 9, (n,), device=dev, generator=g)
-    rays = torch.stack([ro[:n], rd[:n]])
-    zz = z[:n].contiguous()
-    torch.manual_seed(0); torch.cuda.manual_seed(0)
-    gs = GraphedTrainStep((mc, mf), opt, args, ins_num, rays, zz, target, labels)
-    warm_up(gs.step)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = gs.step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    mc.eval(); mf.eval()
-    return {"ms_per_step": dt * 1e3, "rays_per_s": n / dt, "batch_rays": n, "final_loss": float(loss)}
-
-
-def shard_proxy_leg(mc, mf, ro, rd, z, steps, dev, t_full_ms, n_full, t_3072_ms=None):
-    """What ONE GPU can say about the 8-GPU strong-scaling run (SURVEY 8(e) caveat): the complete optimisation step at the
-    per-rank shard of an 8-way split of the shipped batch sizes -- 384 rays (N_train 3072 / 8) and 512 rays (4096 / 8) -- eager
-    and as one HIP graph (graph_train_leg).  predicted_strong_efficiency_8 = (t_full / 8) / t_shard: the fixed per-step cost
-    (launch overheads, the loss / Adam kernels that do not shrink with the batch) is what keeps it below 1; the exchange itself
-    (0.2 MB gather + one 5.57 MB all-reduce) is not in it.  The step is the product's default: fused loss tail, and at 384 rays the
-    two levels' network backwards on two streams (distributed.overlap_enabled: it removes the partial round there)."""
-    out = {}
-    for n in (384, 512):
-        r = train_leg(mc, mf, ro, rd, z, steps, dev, n=n)
-        gr = graph_train_leg(mc, mf, ro, rd, z, steps, dev, n)
-        rf = train_leg(mc, mf, ro, rd, z, steps, dev, n=n, flat_adam=True)
-        gf = graph_train_leg(mc, mf, ro, rd, z, steps, dev, n, flat_adam=True)
-        out[f"n{n}"] = {"ms_per_step": r["ms_per_step"], "rays_per_s": r["rays_per_s"], "graph_ms_per_step": gr["ms_per_step"],
-                        "flat_adam_ms_per_step": rf["ms_per_step"], "flat_adam_graph_ms_per_step": gf["ms_per_step"],
-                        "kernel_ms": {k["kernel"].split("<")[0].split(" ")[0]: k["kernel_ms"] for k in (r["roofline"] or {}).get("all", [])}}
-    out["full_batch_rays"] = n_full
-    out["full_batch_ms"] = t_full_ms
-    full = t_full_ms * (4096.0 / n_full)
-    out["predicted_strong_efficiency_8"] = {"eager_n512_of_4096": (full / 8.0) / out["n512"]["ms_per_step"],
-                                            "graph_n512_of_4096": (full / 8.0) / out["n512"]["graph_ms_per_step"]}
-    if t_3072_ms:                                            # the shipped N_train: 3072 rays over 8 ranks = 384 each
-        out["full_3072_ms"] = t_3072_ms
-        out["predicted_strong_efficiency_8"]["eager_n384_of_3072"] = (t_3072_ms / 8.0) / out["n384"]["ms_per_step"]
-        best = min(out["n384"][k] for k in ("ms_per_step", "graph_ms_per_step", "flat_adam_ms_per_step", "flat_adam_graph_ms_per_step"))
-        out["predicted_strong_efficiency_8"]["best_n384_of_3072"] = (t_3072_ms / 8.0) / best
-    out["note"] = ("full optimisation step (same recipe as `train`) at the per-rank shard of an 8-way strong split, eager and as one HIP graph; "
-                   "flat_adam_* = the same step with the extension optimizer dm_nerf_amd.optim.FlatAdam (torch.optim.Adam's update + the weight "
-                   "re-packing as two launches) instead of the reference's torch.optim.Adam; "
-                   "efficiency = (t_full / 8) / t_shard with t_full = the eager step with torch.optim.Adam")
-    return out
-
-
-def train_loop_leg(mc, mf, dev, steps, mfma_split=False):
-    """The training LOOP as shipped (configs/dmsr/train/study.txt: N_train 3072; train_dmsr.py:24-64): per iteration the
-    batch selection on the reference's numpy stream -- drawn ahead by dm_nerf_amd.prefetch.TrainBatchPrefetcher on a side
-    thread, dataset resident in HBM, indices through pinned memory -- then the same optimisation step as `train`.
-    Reports loop ms per iteration next to the step alone on a resident batch: the difference is the host-side overhead the
-    prefetcher has to hide (< 3 % is the bar).  `inline_selection_ms` = the same loop with the drop-in
-    get_select_full on the critical path (what the reference's loop structure costs here)."""
-    quiesce()
-    from dm_nerf_amd import distributed as D
-    from dm_nerf_amd.networks import helpers as H
-    from dm_nerf_amd.prefetch import TrainBatchPrefetcher
-    from dm_nerf_amd.synthetic import dmsr_intrinsics, pose_spherical
-    n_img, N = 4, N_TRAIN_SHIPPED
-    g = torch.Generator().manual_seed(1)
-    images = torch.rand(n_img, H_IMG, W_IMG, 3, generator=g)
-    labels = torch.randint(0, 9, (n_img, H_IMG, W_IMG), generator=g).to(torch.int16)
-    poses = torch.stack([pose_spherical(30.0 + 40.0 * k, -65.0, 7.0) for k in range(n_img)])
-    K = dmsr_intrinsics(H_IMG, W_IMG)
-    mc.train(); mf.train()
-    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4, betas=(0.9, 0.999))
-    args = types.SimpleNamespace(perturb=1.0, N_importance=N_IMP, is_train=True, N_ins=None, penalize=True, tolerance=0.05, deta_w=0.05,
-                                 mfma_split=mfma_split)
-    z = H.z_val_sample(N, NEAR, FAR, S_COARSE, device=dev)
-    torch.manual_seed(0); torch.cuda.manual_seed(0)
-
-    def step(b):
-        return D.sharded_train_step(b.rays, z, b.target_c, b.target_i, (mc, mf), args, opt, INS_NUM)[0]
-
-    pf = TrainBatchPrefetcher(images, labels, poses, K, np.arange(n_img), N, dev, seed=0, depth=3, max_steps=steps + 3)
-    it = iter(pf)
-    first = next(it)
-    step(first); step(next(it)); step(next(it))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in it:
-        loss = step(b)
-    torch.cuda.synchronize()
-    loop_ms = (time.perf_counter() - t0) / steps * 1e3
-    pf.close()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(first)
-    torch.cuda.synchronize()
-    step_ms = (time.perf_counter() - t0) / steps * 1e3
-    # the reference's loop structure on the drop-in functions: selection + uploads on the critical path
-    di, dl, dp = images.to(dev), labels.to(dev), poses.to(dev)
-    np.random.seed(0)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        img_i = np.random.choice(n_img)
-        tc, ti, rays = H.get_select_full(di[img_i], dp[img_i, :3, :4], K, dl[img_i], N)
-        D.sharded_train_step(rays, z, tc, ti, (mc, mf), args, opt, INS_NUM)
-    torch.cuda.synchronize()
-    inline_ms = (time.perf_counter() - t0) / steps * 1e3
-    mc.eval(); mf.eval()
-    return {"rays_per_s": N / (loop_ms * 1e-3), "batch_rays": N, "loop_ms": loop_ms, "step_ms_resident_batch": step_ms,
-            "overhead_ms": loop_ms - step_ms, "overhead_frac": (loop_ms - step_ms) / step_ms, "inline_selection_ms": inline_ms,
-            "final_loss": float(loss.detach()), "steps": steps,
-            "note": "shipped N_train=3072: prefetched batch selection (reference numpy stream, side thread, pinned index upload, "
-                    "resident dataset) + full optimisation step"}
 
 
 def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
@@ -474,15 +82,15 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
     sdf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mf.state_dict().items()}
     opt = torch.optim.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4, betas=(0.9, 0.999))
     g = torch.Generator().manual_seed(0)
-    target = torch.rand(N_RAYS, 3, generator=g)
-    labels = torch.randint(0, 9, (N_RAYS,), generator=g)
+    target = torch.rand(C.N_RAYS, 3, generator=g)
+    labels = torch.randint(0, 9, (C.N_RAYS,), generator=g)
 
     def one(n):
         t0 = time.perf_counter()
         rays = rays_cpu[:, :n]
         o = O.dm_nerf(rays, sdc, sdf, z_cpu[:n], perturb=1.)
         loss = ((o['rgb_fine'] - target[:n]) ** 2).mean() + ((o['rgb_coarse'] - target[:n]) ** 2).mean() \
-            + O.ins_criterion(o['ins_fine'], labels[:n], INS_NUM)[0].sum() + O.ins_criterion(o['ins_coarse'], labels[:n], INS_NUM)[0].sum() \
+            + O.ins_criterion(o['ins_fine'], labels[:n], C.INS_NUM)[0].sum() + O.ins_criterion(o['ins_coarse'], labels[:n], C.INS_NUM)[0].sum() \
             + O.ins_penalizer(o['raw_fine'], o['z_vals_fine'], o['depth_fine'], rays[1], 0.05, 0.05).sum() \
             + O.ins_penalizer(o['raw_coarse'], o['z_vals_coarse'], o['depth_coarse'], rays[1], 0.05, 0.05).sum()
         opt.zero_grad(); loss.backward(); opt.step()
@@ -506,7 +114,7 @@ def cpu_train_baseline(mc, mf, rays_cpu, z_cpu, seconds):
     res = {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"optimisation step on N={n} rays of the same chunk (64+128 samples, perturb=1, penalize on), oracle/ref_cpu + torch autograd + "
                      f"scipy assignment + Adam; median of {reps} after warm-up: {dt:.2f} s (all: {[round(t, 2) for t in ts]}), anomaly detection off",
-           "host": host_info()}
+           "host": C.host_info()}
     if 1.15 * max(ts) <= left():                          # budget left (--cpu-seconds 80): one step "as shipped"
         torch.autograd.set_detect_anomaly(True)
         try:
@@ -534,10 +142,10 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
 
     one(512)                                              # warm-up (thread pools, page faults)
     t_small, _ = one(512)                                 # calibration
-    n = N_RAYS
+    n = C.N_RAYS
     est = t_small * n / 512 * 0.9                         # (a 512-ray render carries more fixed cost per ray than a 4096-ray one)
     if est > seconds:                                     # a host too slow for one full-size render inside the budget: a smaller sample
-        n = int(max(512, min(N_RAYS, seconds / (t_small / 512) // 512 * 512)))
+        n = int(max(512, min(C.N_RAYS, seconds / (t_small / 512) // 512 * 512)))
         est = t_small * n / 512
     reps = int(max(1, min(3, (seconds - 2.0 * t_small) // est)))     # as many renders of the sample (up to 3) as fit the budget
     runs = [one(n) for _ in range(reps)]
@@ -549,7 +157,7 @@ def cpu_baseline(mc, mf, rays_cpu, z_cpu, got_rgb, seconds):
     return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"N={n} rays = the same 4096-ray chunk (64+128 samples, det), oracle/ref_cpu.dm_nerf; median of {reps} after warm-up: "
                       f"{dt:.2f} s (all: {[round(t, 2) for t in ts]})",
-            "host": host_info()}, psnr, n, want
+            "host": C.host_info()}, psnr, n, want
 
 
 def self_launch(a):
@@ -610,8 +218,8 @@ def init_world(a):
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     strong = a.scaling == "strong" and world > 1
-    if strong and N_RAYS % world:
-        raise SystemExit(f"--scaling strong needs a world size that divides {N_RAYS}")
+    if strong and C.N_RAYS % world:
+        raise SystemExit(f"--scaling strong needs a world size that divides {C.N_RAYS}")
     return types.SimpleNamespace(world=world, rank=rank, dev=dev, strong=strong, one_device=one_device)
 
 
@@ -621,12 +229,12 @@ def build_scene(w):
     packed band buffer and all-gathers that buffer once per frame; a "step" is one chunk of it)."""
     from dm_nerf_amd import distributed as D
     from dm_nerf_amd.synthetic import dmsr_intrinsics, pose_spherical
-    pe, ve, mc, mf = build_models(w.dev)
-    K = dmsr_intrinsics(H_IMG, W_IMG)
+    pe, ve, mc, mf = C.build_models(w.dev)
+    K = dmsr_intrinsics(C.H_IMG, C.W_IMG)
     c2w = pose_spherical(30.0, -65.0, 7.0)
-    n_step = N_RAYS // w.world if w.strong else N_RAYS             # rays THIS rank renders per step
-    args = types.SimpleNamespace(perturb=False, N_importance=N_IMP, is_train=False, N_ins=None)
-    fr = D.FrameRenderer(H_IMG, W_IMG, K, c2w.to(w.dev), (mc, mf), NEAR, FAR, args, chunk=n_step, n_samples=S_COARSE)
+    n_step = C.N_RAYS // w.world if w.strong else C.N_RAYS             # rays THIS rank renders per step
+    args = types.SimpleNamespace(perturb=False, N_importance=C.N_IMP, is_train=False, N_ins=None)
+    fr = D.FrameRenderer(C.H_IMG, C.W_IMG, K, c2w.to(w.dev), (mc, mf), C.NEAR, C.FAR, args, chunk=n_step, n_samples=C.S_COARSE)
     # the steps cycle through ALL chunks of the band, as render_frame does: at N > 1 the band (307 200 / N rays) is not a multiple
     # of 4096 and ends in a ragged chunk (tester.py:65-67) -- it is rendered like the others, so that every gathered frame is
     # complete, and `value` counts the rays each step really rendered (N = 1: 75 chunks of 4096, no ragged one)
@@ -653,7 +261,7 @@ def headline_leg(a, w, sc):
     if w.world > 1:
         dist.all_reduce(torch.zeros(1, device=w.dev))
     torch.cuda.synchronize()
-    flush_c_stdio()
+    C.flush_c_stdio()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     for b_, e_ in ev:                                           # create the hipEvent_t objects now (torch creates them at the first record)
         b_.record(); e_.record()
@@ -676,7 +284,7 @@ def headline_leg(a, w, sc):
             dist.barrier()
         torch.cuda.synchronize()
 
-    quiesce()
+    C.quiesce()
     out_rgb = None
     with torch.no_grad():
         for i in range(a.warmup):
@@ -748,11 +356,11 @@ def multi_rank_legs(a, w, sc):
     train_multi = mani_multi = None
     if w.world > 1 and not a.no_train:
         try:
-            n_train = N_RAYS if w.strong else N_RAYS * w.world
-            rows_t = -(-n_train // W_IMG)
-            tro, trd = H.get_rays_k(H_IMG, W_IMG, sc.K, sc.c2w.to(w.dev), row0=0, nrows=rows_t)
-            zt = H.z_val_sample(n_train, NEAR, FAR, S_COARSE, device=w.dev)
-            train_multi = train_leg(sc.mc, sc.mf, tro.reshape(-1, 3), trd.reshape(-1, 3), zt, a.train_steps, w.dev, w.world, n=n_train)
+            n_train = C.N_RAYS if w.strong else C.N_RAYS * w.world
+            rows_t = -(-n_train // C.W_IMG)
+            tro, trd = H.get_rays_k(C.H_IMG, C.W_IMG, sc.K, sc.c2w.to(w.dev), row0=0, nrows=rows_t)
+            zt = H.z_val_sample(n_train, C.NEAR, C.FAR, C.S_COARSE, device=w.dev)
+            train_multi = T.train_leg(sc.mc, sc.mf, tro.reshape(-1, 3), trd.reshape(-1, 3), zt, a.train_steps, w.dev, w.world, n=n_train)
             train_multi["scaling"] = a.scaling
         except Exception as e:                                  # noqa: BLE001
             train_multi = {"error": f"{type(e).__name__}: {e}"}
@@ -769,28 +377,28 @@ def headline_record(a, w, sc, h, rccl=None):
     # dominant kernel = the fine-network fused PE+MLP launch (192 samples/ray): HIP events on its stream
     k_ms = float(np.mean([s.elapsed_time(e) for s, e in h.ev])) if a.steps else None       # (--steps 0: null, never NaN)
     # (average over the timed launches of rank 0; with a ragged chunk among them, the average launch is that much smaller)
-    flop_per_launch = 2.0 * MAC_PER_SAMPLE * (S_COARSE + N_IMP) * (h.rays_rank / max(a.steps, 1))
+    flop_per_launch = 2.0 * C.MAC_PER_SAMPLE * (C.S_COARSE + C.N_IMP) * (h.rays_rank / max(a.steps, 1))
     achieved = None if not k_ms else flop_per_launch / (k_ms * 1e-3) / 1e12
     rays_per_s = h.rays_total / h.dt if a.steps else None
-    traffic, traffic_src = pmc_traffic() if (INS_NUM == 13 and sc.n_step == N_RAYS) else (None, None)
+    traffic, traffic_src = C.pmc_traffic() if (C.INS_NUM == 13 and sc.n_step == C.N_RAYS) else (None, None)
     res = {
         "metric": "rays/sec (render) at 640x480, 64+128 samples", "value": rays_per_s, "unit": "rays/s",
         "n_gpus": w.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": (h.dt / a.steps * 1e3) if a.steps else None,
         "higher_is_better": True, "scaling": "strong" if w.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("DM-SR 'study'" if INS_NUM == 13 else "Replica-width object head,")
+        "config": {"workload": ("DM-SR 'study'" if C.INS_NUM == 13 else "Replica-width object head,")
                                + " 640x480 synthetic camera, dm_nerf render, 64 coarse + 128 fine samples, "
-                               f"{sc.n_step}-ray chunk per step per GPU, det sampling, ins_num={INS_NUM}, random-init weights",
+                               f"{sc.n_step}-ray chunk per step per GPU, det sampling, ins_num={C.INS_NUM}, random-init weights",
                    "rays_per_step_per_gpu": sc.n_step, "rays_in_timed_region": h.rays_total,
                    "chunks_per_band": sc.n_chunks,
                    "ragged_chunk_rays": (sc.chunk_rays[-1] if sc.chunk_rays and sc.chunk_rays[-1] != sc.n_step else 0),
                    "parallelism": f"ray-sharded x{w.world}" + (
                        f" + one RCCL all-gather of the rank's band per frame ({h.gathers} in the timed region)" if w.world > 1 else "")},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": None if achieved is None else achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": C.F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": None if achieved is None else achieved / C.F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_measured_in_this_run": False if traffic is not None else None,
-                     "kernel": f"mlp_fwd_kernel<{(INS_NUM + 32) // 32},false,false,false> (fine network, {sc.n_step}x192 samples)", "kernel_ms": k_ms,
+                     "kernel": f"mlp_fwd_kernel<{(C.INS_NUM + 32) // 32},false,false,false> (fine network, {sc.n_step}x192 samples)", "kernel_ms": k_ms,
                      "flop_per_launch": flop_per_launch},
-        "path_tflops": None if rays_per_s is None else rays_per_s * 2.0 * MAC_PER_SAMPLE * (2 * S_COARSE + N_IMP) / 1e12,
+        "path_tflops": None if rays_per_s is None else rays_per_s * 2.0 * C.MAC_PER_SAMPLE * (2 * C.S_COARSE + C.N_IMP) / 1e12,
     }
     if rccl is not None:
         res["rccl"] = rccl
@@ -811,12 +419,12 @@ def single_gpu_render_legs(a, w, sc, h, res):
     # the same call, untimed -- what the CPU comparison and the opt-in legs are checked against
     c_last = 0 if a.steps == 0 else (a.steps - 1) % sc.n_chunks
     with torch.no_grad():
-        out = R.dm_nerf(torch.stack([ro[c_last * N_RAYS:(c_last + 1) * N_RAYS], rd[c_last * N_RAYS:(c_last + 1) * N_RAYS]]), pe, ve, mc, mf, z, sc.args)
+        out = R.dm_nerf(torch.stack([ro[c_last * C.N_RAYS:(c_last + 1) * C.N_RAYS], rd[c_last * C.N_RAYS:(c_last + 1) * C.N_RAYS]]), pe, ve, mc, mf, z, sc.args)
     torch.cuda.synchronize()
     if a.steps:
         assert torch.equal(out['rgb_fine'], h.out_rgb), "frame driver and dm_nerf disagree on the same chunk"
     if not a.no_cpu_baseline:
-        rays_cpu = torch.stack([ro[c_last * N_RAYS:(c_last + 1) * N_RAYS], rd[c_last * N_RAYS:(c_last + 1) * N_RAYS]]).cpu()
+        rays_cpu = torch.stack([ro[c_last * C.N_RAYS:(c_last + 1) * C.N_RAYS], rd[c_last * C.N_RAYS:(c_last + 1) * C.N_RAYS]]).cpu()
         base, psnr, n, want = cpu_baseline(mc, mf, rays_cpu, z.cpu(), out['rgb_fine'].cpu(), a.cpu_seconds)
         res["cpu_baseline"] = base
         res["psnr_vs_oracle_db"] = psnr
@@ -829,13 +437,13 @@ def single_gpu_render_legs(a, w, sc, h, res):
         res["render_fused_heads"] = X.render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], fuse_heads=True)
         res["render_split_bf16"] = X.render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split=True)
         res["frame_split_bf16"] = X.frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split=True)
-        if HAVE_F16X2:
+        if C.HAVE_F16X2:
             res["render_split_f16x2"] = X.render_leg(pe, ve, mc, mf, ro, rd, z, a.steps, out['rgb_fine'], mfma_split="f16x2")
             res["frame_split_f16x2"] = X.frame_leg(mc, mf, sc.K, sc.c2w, w.dev, mfma_split="f16x2")
         res["manipulator"] = X.manipulator_leg(mc, mf, sc.K, w.dev)
         res["manipulator_frame"] = X.manipulator_frame_leg(mc, mf, sc.K, w.dev)
-        if INS_NUM != 59:                               # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
-            wide = build_models(w.dev, 59)
+        if C.INS_NUM != 59:                               # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
+            wide = C.build_models(w.dev, 59)
             res["render_ins59"] = X.render_leg(*wide, ro, rd, z, a.steps, ins_num=59)
     return wide
 
@@ -845,33 +453,33 @@ def single_gpu_train_legs(a, w, sc, res, wide):
     mc, mf, ro, rd, z, dev = sc.mc, sc.mf, sc.ro, sc.rd, sc.z, w.dev
     tb = None
     if not a.no_cpu_baseline:                           # (before the GPU leg: it updates the weights in place)
-        tb = cpu_train_baseline(mc, mf, torch.stack([ro[:N_RAYS], rd[:N_RAYS]]).cpu(), z.cpu(), a.cpu_seconds)
-    res["train"] = train_leg(mc, mf, ro, rd, z, a.train_steps, dev)
+        tb = cpu_train_baseline(mc, mf, torch.stack([ro[:C.N_RAYS], rd[:C.N_RAYS]]).cpu(), z.cpu(), a.cpu_seconds)
+    res["train"] = T.train_leg(mc, mf, ro, rd, z, a.train_steps, dev)
     if tb is not None:
         res["train"]["cpu_baseline"] = tb
         res["train"]["speedup_vs_cpu"] = res["train"]["rays_per_s"] / tb["value"]
-    res["train_loop"] = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
+    res["train_loop"] = T.train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20))
     if a.extras:
-        res["train_graph"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS)
+        res["train_graph"] = T.graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, C.N_RAYS)
         res["train_graph"]["note"] = "the `train` step (4096 rays) replayed from one HIP graph (GraphedTrainStep)"
         if wide is not None:
-            t9 = train_leg(wide[2], wide[3], ro, rd, z, a.train_steps, dev, ins_num=59)
+            t9 = T.train_leg(wide[2], wide[3], ro, rd, z, a.train_steps, dev, ins_num=59)
             res["train_ins59"] = {k: t9[k] for k in ("rays_per_s", "ms_per_step", "tflops", "frac_of_mfma_peak", "roofline", "ins_num")}
-        tf = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, fuse_heads=True)
+        tf = T.train_leg(mc, mf, ro, rd, z, a.train_steps, dev, fuse_heads=True)
         res["train_fused_heads"] = {"rays_per_s": tf["rays_per_s"], "ms_per_step": tf["ms_per_step"], "roofline": tf["roofline"],
                                     "note": "opt-in (args.fuse_heads in training): forward on the fused-heads blob, same backward; not part of `train`"}
-        for key, mode in (("train_split_bf16", True),) + ((("train_split_f16x2", "f16x2"),) if HAVE_F16X2 else ()):
-            ts = train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=mode)
+        for key, mode in (("train_split_bf16", True),) + ((("train_split_f16x2", "f16x2"),) if C.HAVE_F16X2 else ()):
+            ts = T.train_leg(mc, mf, ro, rd, z, a.train_steps, dev, mfma_split=mode)
             res[key] = {"rays_per_s": ts["rays_per_s"], "ms_per_step": ts["ms_per_step"],
                         "frac_of_mfma_peak": ts["frac_of_mfma_peak"], "roofline": ts["roofline"],
                         "note": "opt-in (args.mfma_split in training): forward, data gradients and weight gradients on the "
                                 "split-operand 16-bit MFMA kernels "
-                                f"(f32-class values: {split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
-            tl = train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20), mfma_split=mode)
+                                f"(f32-class values: {C.split_products(mode)} products per f32 product, f32 accumulation); not part of `train`"}
+            tl = T.train_loop_leg(mc, mf, dev, max(a.train_steps * 4, 20), mfma_split=mode)
             res[key]["train_loop"] = {k: tl[k] for k in ("rays_per_s", "batch_rays", "loop_ms", "step_ms_resident_batch", "overhead_frac")}
-            res[key]["graph_ms_per_step"] = graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, N_RAYS, mfma_split=mode)["ms_per_step"]
+            res[key]["graph_ms_per_step"] = T.graph_train_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, C.N_RAYS, mfma_split=mode)["ms_per_step"]
     # (last: the extension optimizer re-points the models' parameters at its flat vector)
-    res["train_shard_proxy"] = shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], N_RAYS,
+    res["train_shard_proxy"] = T.shard_proxy_leg(mc, mf, ro, rd, z, max(a.train_steps, 10), dev, res["train"]["ms_per_step"], C.N_RAYS,
                                                t_3072_ms=res["train_loop"]["step_ms_resident_batch"])
 
 
@@ -1002,17 +610,15 @@ def write_full_record(res, path):
 
 
 def main():
-    global INS_NUM, MAC_PER_SAMPLE, HAVE_F16X2
-    X.bind(sys.modules[__name__])
     a = parse()
     t_wall = time.perf_counter()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
-    INS_NUM = a.ins_num
-    MAC_PER_SAMPLE = 691712 + 128 * (INS_NUM + 1)
+    C.INS_NUM = a.ins_num
+    C.MAC_PER_SAMPLE = 691712 + 128 * (C.INS_NUM + 1)
     w = init_world(a)
     from dm_nerf_amd import _lib
-    HAVE_F16X2 = "dmnerf_mlp_fwd_rays_f16" in _lib.SIGNATURES
+    C.HAVE_F16X2 = "dmnerf_mlp_fwd_rays_f16" in _lib.SIGNATURES
     sc = build_scene(w)
     h = headline_leg(a, w, sc)
     rccl = rccl_evidence(w, sc, h) if w.world > 1 else None
@@ -1032,7 +638,7 @@ def main():
     if w.world > 1:
         import torch.distributed as dist
         dist.barrier()                                          # nobody is still printing
-    flush_c_stdio()
+    C.flush_c_stdio()
     if w.rank == 0:
         path = write_full_record(res, a.full_record)
         rel = None if path is None else (os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)

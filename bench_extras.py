@@ -3,41 +3,35 @@
 `frame` (one complete 640x480 pose through the frame driver), the opt-in inference modes (`render_fused_heads`, `render_split_*`,
 `frame_split_*`), `render_ins59` (BASELINE config 3's object-head width), `manipulator` / `manipulator_frame` (BASELINE config 5's
 manipulation render, per chunk and as a whole sharded frame).  They live here so that bench.py stays the contract: headline, CPU
-baseline, the training step and its proxies.  ``bind(bench_module)`` hands over the running bench module (its constants follow
-``--ins-num``; importing ``bench`` from here would make a second copy of them)."""
+baseline, the training step and its proxies."""
 import time
 import types
 
 import numpy as np
 import torch
 
-B = None        # the running bench module (bind)
-
-
-def bind(bench_module):
-    global B
-    B = bench_module
+import bench_common as C
 
 
 def frame_leg(mc, mf, K, c2w, dev, mfma_split=False):
     """One complete 640x480 pose through the frame driver (distributed.render_path: raygen of the band, 75 chunks of
     N_test = 4096 rays, preallocated frame buffers, device-side label / confidence of ins_eval) -- what render_test does
     per pose (networks/tester.py:58-85) minus file output and CPU metrics."""
-    B.quiesce()
+    C.quiesce()
     from dm_nerf_amd import distributed as D
-    args = types.SimpleNamespace(perturb=False, N_importance=B.N_IMP, is_train=False, N_ins=None, N_test=B.N_RAYS, N_samples=B.S_COARSE, near=B.NEAR, far=B.FAR,
+    args = types.SimpleNamespace(perturb=False, N_importance=C.N_IMP, is_train=False, N_ins=None, N_test=C.N_RAYS, N_samples=C.S_COARSE, near=C.NEAR, far=C.FAR,
                                  mfma_split=mfma_split)
     with torch.no_grad():
-        D.render_path(c2w[None].to(dev), (B.H_IMG, B.W_IMG, K), (mc, mf), args, labels_only=True)
+        D.render_path(c2w[None].to(dev), (C.H_IMG, C.W_IMG, K), (mc, mf), args, labels_only=True)
         torch.cuda.synchronize()
         ts = []
         for _ in range(2):
             t0 = time.perf_counter()
-            out = D.render_path(c2w[None].to(dev), (B.H_IMG, B.W_IMG, K), (mc, mf), args, labels_only=True)
+            out = D.render_path(c2w[None].to(dev), (C.H_IMG, C.W_IMG, K), (mc, mf), args, labels_only=True)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
     dt = min(ts)
-    return {"frames_per_s": 1.0 / dt, "seconds_per_frame": dt, "rays_per_s": B.H_IMG * B.W_IMG / dt,
+    return {"frames_per_s": 1.0 / dt, "seconds_per_frame": dt, "rays_per_s": C.H_IMG * C.W_IMG / dt,
             "labels_in_frame": int(len(torch.unique(out["label"]))),
             "note": "render_path, one 640x480 pose: raygen + 75 x dm_nerf(4096 rays) + label/conf kernel, labels_only"
                     + ("; opt-in split-bf16 MFMA (args.mfma_split)" if mfma_split else "")}
@@ -51,30 +45,30 @@ def render_leg(pe, ve, mc, mf, ro, rd, z, steps, rgb_ref=None, fuse_heads=False,
     "f16x2": two f16 planes, three products (f32-class accuracy either way; csrc/mlp_split_impl.h, csrc/mlp_f16_impl.h).
     ins_num: the models' object-code width (BASELINE config 3: Replica office_0 = 59).  Roofline of the fine-network launch from
     HIP events around it: executed MACs x 16-bit products against the peak of the MFMA type used."""
-    B.quiesce()
+    C.quiesce()
     from dm_nerf_amd.networks import render as R
-    ins_num = B.INS_NUM if ins_num is None else ins_num
+    ins_num = C.INS_NUM if ins_num is None else ins_num
     fused = bool(fuse_heads or mfma_split)
-    args = types.SimpleNamespace(perturb=False, N_importance=B.N_IMP, is_train=False, N_ins=None, fuse_heads=fused, mfma_split=mfma_split)
-    n_chunks = ro.shape[0] // B.N_RAYS
+    args = types.SimpleNamespace(perturb=False, N_importance=C.N_IMP, is_train=False, N_ins=None, fuse_heads=fused, mfma_split=mfma_split)
+    n_chunks = ro.shape[0] // C.N_RAYS
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     with torch.no_grad():
         for i in range(2):
-            out = R.dm_nerf(torch.stack([ro[:B.N_RAYS], rd[:B.N_RAYS]]), pe, ve, mc, mf, z, args)
+            out = R.dm_nerf(torch.stack([ro[:C.N_RAYS], rd[:C.N_RAYS]]), pe, ve, mc, mf, z, args)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             c = i % n_chunks
-            out = R.dm_nerf(torch.stack([ro[c * B.N_RAYS:(c + 1) * B.N_RAYS], rd[c * B.N_RAYS:(c + 1) * B.N_RAYS]]), pe, ve, mc, mf, z, args, _events=ev[i])
+            out = R.dm_nerf(torch.stack([ro[c * C.N_RAYS:(c + 1) * C.N_RAYS], rd[c * C.N_RAYS:(c + 1) * C.N_RAYS]]), pe, ve, mc, mf, z, args, _events=ev[i])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-    mac = B.mac_counts(ins_num)
+    mac = C.mac_counts(ins_num)
     exec_mac = mac["fwd_fused"] if fused else mac["fwd"]
-    products = B.split_products(mfma_split)
-    peak = B.B16_MFMA_PEAK_TFLOPS if mfma_split else B.F32_MFMA_PEAK_TFLOPS
+    products = C.split_products(mfma_split)
+    peak = C.B16_MFMA_PEAK_TFLOPS if mfma_split else C.F32_MFMA_PEAK_TFLOPS
     k_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))
-    tf = 2.0 * exec_mac * products * B.N_RAYS * (B.S_COARSE + B.N_IMP) / (k_ms * 1e-3) / 1e12
-    res = {"rays_per_s": B.N_RAYS / dt, "ms_per_step": dt * 1e3, "ins_num": ins_num, "mac_per_sample": exec_mac,
+    tf = 2.0 * exec_mac * products * C.N_RAYS * (C.S_COARSE + C.N_IMP) / (k_ms * 1e-3) / 1e12
+    res = {"rays_per_s": C.N_RAYS / dt, "ms_per_step": dt * 1e3, "ins_num": ins_num, "mac_per_sample": exec_mac,
            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "kernel_ms": k_ms, "achieved": tf, "peak": peak, "frac": tf / peak,
                         "mfma_products_per_mac": products, "note": "fine-network MLP launch, HIP events; executed MACs x 16-bit products per MAC"},
            "note": ("opt-in (args.mfma_split = %r): fused heads + split-operand 16-bit MFMA" % (mfma_split,) if mfma_split
@@ -91,20 +85,20 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
     (sample_pdf(det=False) even at evaluation), two exchanger
     rounds, the final composite.  Rays: the bench camera for the original view; each target view is the same camera
     moved by a rigid transform (what manipulator_demo does with the edited object's pose, :346-371)."""
-    B.quiesce()
+    C.quiesce()
     from dm_nerf_amd.networks import helpers as H, manipulator as MA
     from dm_nerf_amd.synthetic import pose_spherical
     c2w = pose_spherical(30.0, -65.0, 7.0).to(dev)
-    ro, rd = H.get_rays_k(B.H_IMG, B.W_IMG, K, c2w)
-    ori = torch.stack([ro.reshape(-1, 3)[:B.N_RAYS], rd.reshape(-1, 3)[:B.N_RAYS]])
+    ro, rd = H.get_rays_k(C.H_IMG, C.W_IMG, K, c2w)
+    ori = torch.stack([ro.reshape(-1, 3)[:C.N_RAYS], rd.reshape(-1, 3)[:C.N_RAYS]])
     tars = []
     for k in range(2):
         c2 = pose_spherical(30.0 + 4.0 * (k + 1), -65.0, 7.0 + 0.1 * (k + 1)).to(dev)
-        to, td = H.get_rays_k(B.H_IMG, B.W_IMG, K, c2)
-        tars.append(torch.stack([to.reshape(-1, 3)[:B.N_RAYS], td.reshape(-1, 3)[:B.N_RAYS]]))
+        to, td = H.get_rays_k(C.H_IMG, C.W_IMG, K, c2)
+        tars.append(torch.stack([to.reshape(-1, 3)[:C.N_RAYS], td.reshape(-1, 3)[:C.N_RAYS]]))
     out = {}
     for T in (1, 2):
-        args = types.SimpleNamespace(N_samples=B.S_COARSE, N_importance=B.N_IMP, near=B.NEAR, far=B.FAR, target_labels=list(range(1, T + 1)))
+        args = types.SimpleNamespace(N_samples=C.S_COARSE, N_importance=C.N_IMP, near=C.NEAR, far=C.FAR, target_labels=list(range(1, T + 1)))
         torch.manual_seed(0); torch.cuda.manual_seed(0)
         with torch.no_grad():
             MA.manipulator(None, None, mc, mf, ori, tars[:T], args)
@@ -114,14 +108,14 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
                 rgb, ins, _, _ = MA.manipulator(None, None, mc, mf, ori, tars[:T], args)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
-        samples = (1 + T) * (2 * B.S_COARSE + B.N_IMP) + 2 * T * (B.S_COARSE + B.N_IMP + B.N_IMP * T)   # network evaluations per ray
-        mac = B.mac_counts(B.INS_NUM)["fwd"]
-        out[f"T{T}"] = {"rays_per_s": B.N_RAYS / dt, "ms_per_call": dt * 1e3, "network_samples_per_ray": samples,
-                        "tflops": 2.0 * mac * samples * B.N_RAYS / dt / 1e12,
-                        "frac_of_f32_mfma_peak": 2.0 * mac * samples * B.N_RAYS / dt / 1e12 / B.F32_MFMA_PEAK_TFLOPS,
+        samples = (1 + T) * (2 * C.S_COARSE + C.N_IMP) + 2 * T * (C.S_COARSE + C.N_IMP + C.N_IMP * T)   # network evaluations per ray
+        mac = C.mac_counts(C.INS_NUM)["fwd"]
+        out[f"T{T}"] = {"rays_per_s": C.N_RAYS / dt, "ms_per_call": dt * 1e3, "network_samples_per_ray": samples,
+                        "tflops": 2.0 * mac * samples * C.N_RAYS / dt / 1e12,
+                        "frac_of_f32_mfma_peak": 2.0 * mac * samples * C.N_RAYS / dt / 1e12 / C.F32_MFMA_PEAK_TFLOPS,
                         "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all())}
-    if B.HAVE_F16X2:                                       # opt-in (args.mfma_split = "f16x2"), T = 1; not an MFMA-roof fraction: three products per MAC
-        args = types.SimpleNamespace(N_samples=B.S_COARSE, N_importance=B.N_IMP, near=B.NEAR, far=B.FAR, target_labels=[1], mfma_split="f16x2")
+    if C.HAVE_F16X2:                                       # opt-in (args.mfma_split = "f16x2"), T = 1; not an MFMA-roof fraction: three products per MAC
+        args = types.SimpleNamespace(N_samples=C.S_COARSE, N_importance=C.N_IMP, near=C.NEAR, far=C.FAR, target_labels=[1], mfma_split="f16x2")
         torch.manual_seed(0); torch.cuda.manual_seed(0)
         with torch.no_grad():
             MA.manipulator(None, None, mc, mf, ori, tars[:1], args)
@@ -131,7 +125,7 @@ def manipulator_leg(mc, mf, K, dev, steps=3):
                 rgb, ins, _, _ = MA.manipulator(None, None, mc, mf, ori, tars[:1], args)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
-        out["T1_split_f16x2"] = {"rays_per_s": B.N_RAYS / dt, "ms_per_call": dt * 1e3, "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all()),
+        out["T1_split_f16x2"] = {"rays_per_s": C.N_RAYS / dt, "ms_per_call": dt * 1e3, "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(ins).all()),
                                  "note": "opt-in split-f16 network kernels (f32-class, not bitwise the default); not part of the T1 / T2 numbers"}
     out["note"] = ("manipulator() on one 4096-ray chunk, 64 + 128 samples, T moved objects (default f32 kernels); network_samples_per_ray = "
                    "(1+T)(64+192) + 2T(192+128T) -- the reference re-evaluates the original rays once per target (:190-193); "
@@ -145,17 +139,17 @@ def manipulator_frame_leg(mc, mf, K, dev, world=1):
     reference evaluates it), 75 chunks of N_test = 4096 rays, target view = ``trans @ pose``, the 2 + T draws per chunk from the
     device generator, ONE all-gather of the packed band per frame at N > 1.  At N = 1 also the time of ONE band of an 8-way split
     (``rank=0, world=8``: 38 400 rays) -- what one of 8 GPUs would take for its share of the same frame."""
-    B.quiesce()
+    C.quiesce()
     from dm_nerf_amd import distributed as D
     from dm_nerf_amd.synthetic import pose_spherical
     pose = pose_spherical(30.0, -65.0, 7.0)
     ang = 0.15
     trans = torch.tensor([[np.cos(ang), -np.sin(ang), 0., 0.3], [np.sin(ang), np.cos(ang), 0., -0.2], [0., 0., 1., 0.1], [0., 0., 0., 1.]],
                          dtype=torch.float32)
-    args = types.SimpleNamespace(N_samples=B.S_COARSE, N_importance=B.N_IMP, near=B.NEAR, far=B.FAR, N_test=B.N_RAYS, target_label=1)
+    args = types.SimpleNamespace(N_samples=C.S_COARSE, N_importance=C.N_IMP, near=C.NEAR, far=C.FAR, N_test=C.N_RAYS, target_label=1)
     T = 1
-    samples = (1 + T) * (2 * B.S_COARSE + B.N_IMP) + 2 * T * (B.S_COARSE + B.N_IMP + B.N_IMP * T)
-    mac = B.mac_counts(B.INS_NUM)["fwd"]
+    samples = (1 + T) * (2 * C.S_COARSE + C.N_IMP) + 2 * T * (C.S_COARSE + C.N_IMP + C.N_IMP * T)
+    mac = C.mac_counts(C.INS_NUM)["fwd"]
 
     def timed(**kw):
         torch.manual_seed(0); torch.cuda.manual_seed(0)
@@ -165,23 +159,23 @@ def manipulator_frame_leg(mc, mf, K, dev, world=1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
-            frame = D.manipulate_frame(B.H_IMG, B.W_IMG, K, pose.to(dev), [trans], (mc, mf), args, **kw)
+            frame = D.manipulate_frame(C.H_IMG, C.W_IMG, K, pose.to(dev), [trans], (mc, mf), args, **kw)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0, frame
     with torch.no_grad():                                      # warm-up: the first rows of the frame as one chunk
-        D.manipulate_frame(8, B.W_IMG, K, pose.to(dev), [trans], (mc, mf), args, rank=0, world=1)
+        D.manipulate_frame(8, C.W_IMG, K, pose.to(dev), [trans], (mc, mf), args, rank=0, world=1)
     dt, frame = timed()
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    n = B.H_IMG * B.W_IMG
-    out = {"rays_per_s": n / dt, "s_per_frame": dt, "n_gpus": world, "T": T, "chunks": -(-n // B.N_RAYS), "network_samples_per_ray": samples,
+    n = C.H_IMG * C.W_IMG
+    out = {"rays_per_s": n / dt, "s_per_frame": dt, "n_gpus": world, "T": T, "chunks": -(-n // C.N_RAYS), "network_samples_per_ray": samples,
            "tflops": 2.0 * mac * samples * n / dt / 1e12,
-           "frac_of_f32_mfma_peak": 2.0 * mac * samples * n / dt / 1e12 / (B.F32_MFMA_PEAK_TFLOPS * world),
+           "frac_of_f32_mfma_peak": 2.0 * mac * samples * n / dt / 1e12 / (C.F32_MFMA_PEAK_TFLOPS * world),
            "finite": bool(all(torch.isfinite(t).all() for t in frame)), "labels_in_frame": int(len(torch.unique(frame[1].argmax(-1)))),
            "note": "one whole 640x480 pose through distributed.manipulate_frame (manipulator_eval's chunk loop: 75 x 4096 rays, T = 1, "
                    "default f32 kernels); the whole frame incl. raygen of both views, resampling, exchanger, composites and the band "
