@@ -79,9 +79,13 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     const int lane = tid & 63, half = lane >> 5, li = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = lds_addr(lds);
-    const int64_t i0 = (int64_t)blockIdx.x * 128;
     const int j0 = blockIdx.y * (NBB * 32);         // first output (row of the packed weights) of this workgroup
     const int nchunk = a.nc0 + a.nc1;
+    // PERSISTENT: the grid is (at most) one workgroup per CU slot and a workgroup walks the sample tiles blockIdx.x, + gridDim.x, ...
+    // A tile's fixed cost (workgroup launch, the first chunks' DMA latency, the stores draining: ~10 us measured against 5 .. 40 us of
+    // MFMA work) shrinks to what cannot overlap: the next tile's first chunks are requested BEFORE this tile's epilogue issues its stores.
+    const int64_t ntiles = (a.M + 127) / 128;
+    int64_t tile = blockIdx.x;
 
     // ---- DMA geometry (wgrad.hip): wave w owns the 1-KiB piece w of every 32-row block (rows 8 w .. 8 w + 7); lane l lands at LDS
     // row 8 w + (l >> 3), unit l & 7, so it must FETCH unit (l & 7) ^ ((row >> 1) & 7) of that row
@@ -90,22 +94,43 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     const int voA0 = (int)(drow * a.lda0 * 4) + dunit;
     const int voA1 = (int)(drow * a.lda1 * 4) + dunit;
     const int voB = drow * a.ldb * 4 + dunit;
-    // descriptors: rows beyond M are beyond the A descriptors' ranges (they read as 0 and feed rows the epilogue never stores)
-    const int64_t rows_valid = a.M - i0 < 128 ? a.M - i0 : 128;
     auto bound = [](int64_t want, int64_t have) { const int64_t b = want < have ? want : have; return b < 0x1fffffff ? b : (int64_t)0x1fffffff; };
-    const rsrc_t rsA0 = uniform_rsrc(a.A0 + i0 * a.lda0, bound(rows_valid * a.lda0, a.a0_floats - i0 * a.lda0));
-    const rsrc_t rsA1 = a.A1 ? uniform_rsrc(a.A1 + i0 * a.lda1, bound(rows_valid * a.lda1, a.a1_floats - i0 * a.lda1)) : rsA0;
     const rsrc_t rsB = uniform_rsrc(a.B + (int64_t)j0 * a.ldb, bound((int64_t)NBB * 32 * a.ldb, a.b_floats - (int64_t)j0 * a.ldb));
     const int blkA0 = (int)(32 * a.lda0 * 4), blkA1 = (int)(32 * a.lda1 * 4), blkB = 32 * a.ldb * 4;      // bytes per 32-row block
+    // `args()`: the kernel arguments re-read from the kernarg segment where a tile's set-up / epilogue needs them.  Read once at the
+    // top they are ~60 SGPRs held across the whole tile loop (the compiler hoists the loads), and the loop's own state spilled.
+    typedef const NtArgs __attribute__((address_space(4))) KArgs;         // (the kernel's one argument sits at the start of the segment)
+    auto args = [&]() -> KArgs* { KArgs* p = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
+    // per-tile state: rows beyond M are beyond the A descriptors' ranges (they read as 0 and feed rows the epilogue never stores)
+    int64_t i0 = 0, rows_valid = 0;
+    rsrc_t rsA0, rsA1;
+    auto set_tile = [&](int64_t t) __attribute__((always_inline)) {
+        KArgs* q = args();
+        i0 = t * 128;
+        rows_valid = q->M - i0 < 128 ? q->M - i0 : 128;
+        rsA0 = uniform_rsrc(q->A0 + i0 * q->lda0, bound(rows_valid * q->lda0, q->a0_floats - i0 * q->lda0));
+        rsA1 = q->A1 ? uniform_rsrc(q->A1 + i0 * q->lda1, bound(rows_valid * q->lda1, q->a1_floats - i0 * q->lda1)) : rsA0;
+    };
 
-    auto dma_chunk_piece = [&](int cc, unsigned slot_byte, int i) {      // piece i of NL of chunk cc (< nchunk) into a ring slot
-        float* dst = lds + (slot_byte + i * 4096 + w * 1024) / 4;
+    // (`fresh_s`: the block strides are re-read where they are used -- as loop invariants of the tile loop the 4 + NBB piece offsets,
+    // times two call sites, were a hundred SGPRs held across the whole kernel and spilled)
+    auto fresh_s = [](int x) -> int { asm volatile("" : "+s"(x)); return x; };
+    auto dma_chunk_piece = [&](int cc, unsigned slot_byte, int i) __attribute__((always_inline)) {      // piece i of NL of chunk cc (< nchunk) into a ring slot
+        float* dst = lds + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;       // (likewise: the LDS addresses of the first chunks' pieces)
         if (i < 4) {
-            if (cc < a.nc0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (DMN_LAS void*)dst, 16, voA0, i * blkA0 + cc * 128, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (DMN_LAS void*)dst, 16, voA1, i * blkA1 + (cc - a.nc0) * 128, 0, 0);
+            if (cc < a.nc0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (DMN_LAS void*)dst, 16, voA0, i * fresh_s(blkA0) + cc * 128, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (DMN_LAS void*)dst, 16, voA1, i * fresh_s(blkA1) + (cc - a.nc0) * 128, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, (i - 4) * blkB + cc * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, (i - 4) * fresh_s(blkB) + cc * 128, 0, 0);
         }
+    };
+    auto issue_first_chunks = [&]() __attribute__((always_inline)) {                   // the current tile's first D chunks (those that exist) into slots 0 .. D - 1
+#pragma unroll
+        for (int sl = 0; sl < D; ++sl)
+            if (sl < nchunk) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
+            }
     };
 
     // ---- read geometry: lane (li, half) reads row 32 blk + li, unit (2 t + half) ^ ((li >> 1) & 7) in round t
@@ -117,11 +142,13 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
         offB[t] = o + 4 * 4096;
     }
 
-    // ---- the bias (column n = j0 + 32 b + li is this lane's in every register of block b): loaded FIRST, so that these are the oldest
-    // VMEM operations of the wave -- vmcnt retires in order, and the ring's counting below must see DMA pieces only behind it
+    // ---- the bias (column n = j0 + 32 b + li is this lane's in every register of block b), once for all tiles
     float bias_v[NBB];
 #pragma unroll
-    for (int b = 0; b < NBB; ++b) bias_v[b] = a.bias ? a.bias[j0 + 32 * b + li] : 0.f;
+    for (int b = 0; b < NBB; ++b) {
+        bias_v[b] = a.bias ? a.bias[j0 + 32 * b + li] : 0.f;
+        if constexpr (NBB > 6) asm volatile("" : "+a"(bias_v[b]));          // (parked in the AGPR half next to the accumulators)
+    }
     asm volatile("" ::: "memory");
 
     f32x4 av[2][1], bv[2][NBB];
@@ -131,107 +158,128 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
         else lds_read16_async<(g - 1) * 4096>(bv[buf][g - 1], addrB);
     };
 
-    // ---- prologue: the first D chunks in flight (those that exist), chunk 0 landed, its round-0 operands on their way
-#pragma unroll
-    for (int sl = 0; sl < D; ++sl)
-        if (sl < nchunk) {
-#pragma unroll
-            for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
-        }
-    if (nchunk >= D) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));     // vmcnt((D-1) NL) only
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                         // a short K: everything
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
-    f32x16 acc[NBB];                                    // accumulators start from the bias (landed: older than chunk 0's pieces)
-#pragma unroll
-    for (int b = 0; b < NBB; ++b) {
-        acc[b] = (f32x16)(bias_v[b]);
-        if constexpr (NBB > 8) asm volatile("" : "+a"(acc[b]));    // wide tiles: the accumulators live in the AGPR half of the file
-    }
-
-    unsigned sb = 0;                                    // byte offset of the ring slot of chunk c (uniform)
+    set_tile(tile);
+    issue_first_chunks();
+    f32x16 acc[NBB];
 #pragma nounroll
-    for (int c = 0; c < nchunk; ++c) {
-        const unsigned nb = sb + BUF == (unsigned)(D * BUF) ? 0u : sb + BUF;
-        unsigned cA[4], cB[4];
+    for (;;) {
+        // ---- the tile's first chunks have landed (everything older too: the bias, the previous tile's stores), round-0 operands on
+        // their way.  (vmcnt(0): behind the first chunk's pieces sit the other D - 1 chunks AND, from the second tile on, up to 16 NBB
+        // stores -- more than the counter can express; they were all issued within a microsecond of each other.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
 #pragma unroll
-        for (int t = 1; t < 4; ++t) { cA[t] = offA[t] + sb; cB[t] = offB[t] + sb; }
-        cA[0] = offA[0] + nb; cB[0] = offB[0] + nb;     // round 0 of the NEXT chunk (read in this chunk's round 3)
-        static_for<4>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            lds_wait<0>(av[r & 1]);
-#pragma unroll
-            for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
-            if constexpr (r == 3) {
-                // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released.  In flight behind
-                // chunk c + 1 are the D - 2 chunks after it -- or fewer at the end of the K range (no refill is issued for chunks that
-                // do not exist), where waiting for everything is exact enough
-                if (c + D - 1 < nchunk) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
-                else __builtin_amdgcn_s_waitcnt(0x0F70);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<NGAP>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                constexpr int u = g / NBB, ib = g % NBB;
-                if constexpr (g < NR) read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
-                if constexpr (r == 3) {                                 // refill the released slot with chunk c + D (if there is one)
-                    constexpr int G0 = NR < NGAP ? NR : NGAP - 1;
-                    constexpr int PD = (NGAP - G0) / NL > 0 ? (NGAP - G0) / NL : 1;
-                    static_for<NL>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        constexpr int at = G0 + i * PD < NGAP ? G0 + i * PD : NGAP - 1;
-                        if constexpr (at == g) {
-                            if (c + D < nchunk) dma_chunk_piece(c + D, sb, i);
-                        }
-                    });
-                }
-                acc[ib] = mfma32(av[r & 1][0][u], bv[r & 1][ib][u], acc[ib]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        sb = nb;
-    }
-    // the read-ahead of the chunk after the last one lands in registers nobody uses, but it must have landed before the
-    // workgroup's LDS is handed on (the ties keep its registers allocated)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    asm volatile("" : "+" DMN_TILE_RC(av[0][0]));
-#pragma unroll
-    for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
-
-    // ---- epilogue: lane holds column n = j0 + 32 b + li, rows 32 w + (r & 3) + 8 (r >> 2) + 4 half
-    const int ncols = a.n_zero - j0 < NBB * 32 ? a.n_zero - j0 : NBB * 32;       // columns of this workgroup that exist in C
-    if (ncols <= 0 || rows_valid <= 0) return;
-    float* const Ct = a.C + i0 * a.ldc + j0;
-    const rsrc_t rsC = uniform_rsrc(Ct, (rows_valid - 1) * a.ldc + ncols);       // rows beyond M fall outside: dropped by the hardware
-    const int voC = (int)(((int64_t)(32 * w + 4 * half) * a.ldc + li) * 4);
-    const int rowB = (int)(a.ldc * 4);
-    rsrc_t rsM = rsC;
-    int voM = 0, rowM = 0;
-    if (a.mask) {
-        rsM = uniform_rsrc(a.mask + i0 * a.ldm + j0, (rows_valid - 1) * a.ldm + ncols);
-        voM = (int)(((int64_t)(32 * w + 4 * half) * a.ldm + li) * 4);
-        rowM = (int)(a.ldm * 4);
-    }
-#pragma unroll
-    for (int b = 0; b < NBB; ++b) {
-        const int col = 32 * b + li;
-        const bool in_c = col < ncols;                                           // (a column predicate: the descriptor bounds rows only)
-        const bool is_val = j0 + col < a.n_store;
-        const int vo = in_c ? voC + b * 128 : 0x7ffffff0;
-        const int vm = in_c ? voM + b * 128 : 0x7ffffff0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ro = (r & 3) + 8 * (r >> 2);
-            float v = acc[b][r];
-            if (a.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo, ro * rowB, 0));
-            if (a.relu) v = relu1(v);
-            if (a.mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm, ro * rowM, 0)) > 0.f ? v : 0.f;
-            v = is_val ? v : 0.f;
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(v), rsC, vo, ro * rowB, 0);
+        for (int b = 0; b < NBB; ++b) {                 // accumulators start from the bias
+            float bb = bias_v[b];
+            asm volatile("" : "+v"(bb));                // (opaque per trip: the 16-wide splats are loop invariants otherwise -- 16 NBB registers
+            acc[b] = (f32x16)(bb);                      //  held across the tile loop next to the accumulators themselves)
+            if constexpr (NBB > 6) asm volatile("" : "+a"(acc[b]));    // one workgroup per CU: the accumulators live in the AGPR half of the file
         }
+
+        unsigned sb = 0;                                // byte offset of the ring slot of chunk c (uniform)
+#pragma nounroll
+        for (int c = 0; c < nchunk; ++c) {
+            const unsigned nb = sb + BUF == (unsigned)(D * BUF) ? 0u : sb + BUF;
+            unsigned cA[4], cB[4];
+#pragma unroll
+            for (int t = 1; t < 4; ++t) { cA[t] = offA[t] + sb; cB[t] = offB[t] + sb; }
+            cA[0] = offA[0] + nb; cB[0] = offB[0] + nb; // round 0 of the NEXT chunk (read in this chunk's round 3)
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                lds_wait<0>(av[r & 1]);
+#pragma unroll
+                for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
+                if constexpr (r == 3) {
+                    // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released.  In flight
+                    // behind chunk c + 1 are the D - 2 chunks after it -- or fewer at the end of the K range (no refill is issued for
+                    // chunks that do not exist), where waiting for everything is exact enough
+                    if (c + D - 1 < nchunk) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<NGAP>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    constexpr int u = g / NBB, ib = g % NBB;
+                    if constexpr (g < NR) read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
+                    if constexpr (r == 3) {                             // refill the released slot with chunk c + D (if there is one)
+                        constexpr int G0 = NR < NGAP ? NR : NGAP - 1;
+                        constexpr int PD = (NGAP - G0) / NL > 0 ? (NGAP - G0) / NL : 1;
+                        static_for<NL>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            constexpr int at = G0 + i * PD < NGAP ? G0 + i * PD : NGAP - 1;
+                            if constexpr (at == g) {
+                                if (c + D < nchunk) dma_chunk_piece(c + D, sb, i);
+                            }
+                        });
+                    }
+                    acc[ib] = mfma32(av[r & 1][0][u], bv[r & 1][ib][u], acc[ib]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            sb = nb;
+        }
+        // the read-ahead of the chunk after the last one lands in registers nobody uses, but it must have landed before the ring is
+        // refilled (the ties keep its registers allocated); the barrier: EVERY wave is done reading this tile's chunks
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+" DMN_TILE_RC(av[0][0]));
+#pragma unroll
+        for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // ---- the NEXT tile's first chunks go out now, under this tile's epilogue
+        const int64_t i0_done = i0, rows_done = rows_valid;
+        const int64_t next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        if (more) {
+            set_tile(next);
+            issue_first_chunks();
+        }
+
+        // ---- epilogue: lane holds column n = j0 + 32 b + li, rows 32 w + (r & 3) + 8 (r >> 2) + 4 half
+        // (`fresh` hides a value's origin: what is derived from it is computed HERE, in every trip, instead of being hoisted out of the
+        // tile loop -- 16 NBB store offsets as loop invariants were 130 spilled SGPRs)
+        auto fresh_v = [](int x) -> int { asm volatile("" : "+v"(x)); return x; };
+        KArgs* q = args();
+        const int ncols = q->n_zero - j0 < NBB * 32 ? q->n_zero - j0 : NBB * 32;       // columns of this workgroup that exist in C
+        float* const Ct = q->C + i0_done * q->ldc + j0;
+        const rsrc_t rsC = uniform_rsrc(Ct, (rows_done - 1) * q->ldc + ncols);    // rows beyond M fall outside: dropped by the hardware
+        const int lane_e = fresh_v(lane);
+        const int half_e = lane_e >> 5, li_e = lane_e & 31;
+        const int voC = (int)(((int64_t)(32 * w + 4 * half_e) * q->ldc + li_e) * 4);
+        const int rowB = fresh_v((int)(q->ldc * 4));                               // (in a VGPR: the 16 row offsets of a block are VALU adds here, not 16 SGPRs)
+        rsrc_t rsM = rsC;
+        int voM = 0, rowM = 0;
+        if (q->mask) {
+            rsM = uniform_rsrc(q->mask + i0_done * q->ldm + j0, (rows_done - 1) * q->ldm + ncols);
+            voM = (int)(((int64_t)(32 * w + 4 * half_e) * q->ldm + li_e) * 4);
+            rowM = fresh_v((int)(q->ldm * 4));
+        }
+#pragma unroll
+        for (int b = 0; b < NBB; ++b) {
+            const int col = 32 * b + li_e;
+            const bool in_c = col < ncols;                                       // (a column predicate: the descriptor bounds rows only)
+            const bool is_val = j0 + col < q->n_store;
+            const int vo = in_c ? voC + b * 128 : 0x7ffffff0;
+            const int vm = in_c ? voM + b * 128 : 0x7ffffff0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                float v = acc[b][r];
+                if (q->accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo + ro * rowB, 0, 0));
+                if (q->relu) v = relu1(v);
+                if (q->mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm + ro * rowM, 0, 0)) > 0.f ? v : 0.f;
+                v = is_val ? v : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(f2u(v), rsC, vo + ro * rowB, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // block by block: the scheduler would otherwise pull every accumulator out of the
+        }                                                // AGPR file first (16 NBB VGPRs live at once: spills in the wide tiles)
+        if (!more) break;
+        tile = next;
     }
 }
 
@@ -312,8 +360,15 @@ int launch_nt(const NtArgs& a, int tiles_n, hipStream_t stream) {
     if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<NBB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
         e != hipSuccess)
         return dmn_fail_hip(e, "gemm_nt: hipFuncSetAttribute");
+    // persistent grid: one workgroup per CU slot (nt_occupancy per CU), each walking the sample tiles with stride gridDim.x
+    int dev = 0, cus = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return dmn_fail_hip(e, "gemm_nt: hipGetDevice");
+    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess || cus < 1)
+        return dmn_fail_hip(e, "gemm_nt: hipDeviceGetAttribute");
     const int64_t ti = (a.M + 127) / 128;
-    hipLaunchKernelGGL(gemm_nt_kernel<NBB>, dim3((unsigned)ti, (unsigned)tiles_n), dim3(256), lds_bytes, stream, a);
+    const int64_t slots = (int64_t)cus * nt_occupancy(NBB) / tiles_n > 0 ? (int64_t)cus * nt_occupancy(NBB) / tiles_n : 1;
+    const int64_t gx = ti < slots ? ti : slots;
+    hipLaunchKernelGGL(gemm_nt_kernel<NBB>, dim3((unsigned)gx, (unsigned)tiles_n), dim3(256), lds_bytes, stream, a);
     return dmn_check_launch("gemm_nt");
 }
 
@@ -356,7 +411,6 @@ extern "C" int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats
     const int nbb = dmnerf_gemm_nt_blocks(n_store);
     const int tiles = ((n_store + 31) / 32 + nbb - 1) / nbb;
     if (b_floats < (int64_t)tiles * nbb * 32 * ldb) return dmn_fail(DMNERF_E_ARG, "gemm_nt: packed weights hold %lld floats, %lld needed", (long long)b_floats, (long long)tiles * nbb * 32 * ldb);
-    if ((M + 127) / 128 > 0x7fffffffLL) return dmn_fail(DMNERF_E_ARG, "gemm_nt: too many rows");
     NtArgs a{};
     a.A0 = d_A0; a.A1 = k1 > 0 ? d_A1 : nullptr; a.lda0 = lda0; a.lda1 = k1 > 0 ? lda1 : 0; a.a0_floats = a0_floats; a.a1_floats = a1_floats;
     a.nc0 = nc0; a.nc1 = nc1; a.B = d_B; a.b_floats = b_floats; a.ldb = ldb; a.bias = d_bias; a.C = d_C; a.ldc = ldc;
