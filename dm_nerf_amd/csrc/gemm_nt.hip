@@ -84,8 +84,7 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     const int j0 = blockIdx.y * (NBB * 32);         // first output (row of the packed weights) of this workgroup
     const int nchunk = a.nc0 + a.nc1;
     // PERSISTENT: the grid is (at most) one workgroup per CU slot and a workgroup walks the sample tiles blockIdx.x, + gridDim.x, ...
-    // A tile's fixed cost (workgroup launch, the first chunks' DMA latency, the stores draining: ~10 us measured against 5 .. 40 us of
-    // MFMA work) shrinks to what cannot overlap: the next tile's first chunks are requested BEFORE this tile's epilogue issues its stores.
+    // (a tile's fixed cost -- workgroup launch, the first chunks' DMA latency, the stores draining -- was ~10 us against 5 .. 40 us of MFMA work)
     const int64_t ntiles = (a.M + 127) / 128;
     int64_t tile = blockIdx.x;
 
@@ -126,15 +125,6 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, (i - 4) * fresh_s(blkB) + cc * 128, 0, 0);
         }
     };
-    auto issue_first_chunks = [&]() __attribute__((always_inline)) {                   // the current tile's first D chunks (those that exist) into slots 0 .. D - 1
-#pragma unroll
-        for (int sl = 0; sl < D; ++sl)
-            if (sl < nchunk) {
-#pragma unroll
-                for (int i = 0; i < NL; ++i) dma_chunk_piece(sl, sl * BUF, i);
-            }
-    };
-
     // ---- read geometry: lane (li, half) reads row 32 blk + li, unit (2 t + half) ^ ((li >> 1) & 7) in round t
     unsigned offA[4], offB[4];
 #pragma unroll
@@ -160,18 +150,45 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
         else lds_read16_async<(g - 1) * 4096>(bv[buf][g - 1], addrB);
     };
 
-    set_tile(tile);
-    issue_first_chunks();
+    // ---- ONE chunk stream across the tiles.  The ring does not drain at a tile boundary: the chunk fetched D chunks ahead simply
+    // belongs to the next tile once the current one's K range is exhausted (its own A descriptors, the weights again from k = 0), so a
+    // tile's first chunks have long landed when its first MFMA issues, and the memory latency is paid once per workgroup, not per tile.
+    // Fetch state: the tile / chunk the NEXT request is for (rsA0 / rsA1 are the FETCH tile's descriptors); compute state: tile, i0.
+    int fc = 0;                                         // chunk (inside the fetch tile) of the next request
+    int ahead = 0;                                      // chunks requested beyond the one being consumed
+    int64_t ftile = tile;
+    bool fvalid = true;
+    set_tile(ftile);
+    const int64_t i0_first = i0;
+    auto advance_fetch = [&]() __attribute__((always_inline)) {           // after the NL pieces of (ftile, fc) have been issued
+        if (++fc == nchunk) {
+            fc = 0;
+            ftile += gridDim.x;
+            fvalid = ftile < ntiles;
+            if (fvalid) set_tile(ftile);
+        }
+    };
+    // prologue: the first D chunks of the stream (they may span tiles when K is short), chunk 0 landed, its round-0 operands on their way
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl)
+        if (fvalid) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) dma_chunk_piece(fc, sl * BUF, i);
+            advance_fetch();
+            ++ahead;
+        }
+    --ahead;                                            // (chunk 0 is the one being consumed)
+    if (ahead == D - 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));     // vmcnt((D-1) NL) only
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                           // a short stream: everything
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
+
     f32x16 acc[NBB];
+    unsigned sb = 0;                                    // byte offset of the ring slot of the chunk being consumed (uniform)
+    int64_t i0c = i0_first;                             // the tile being COMPUTED
 #pragma nounroll
     for (;;) {
-        // ---- the tile's first chunks have landed (everything older too: the bias, the previous tile's stores), round-0 operands on
-        // their way.  (vmcnt(0): behind the first chunk's pieces sit the other D - 1 chunks AND, from the second tile on, up to 16 NBB
-        // stores -- more than the counter can express; they were all issued within a microsecond of each other.)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        static_for<NR>([&](auto gc) { read_ops_one(gc, 0, offA[0], offB[0]); });
 #pragma unroll
         for (int b = 0; b < NBB; ++b) {                 // accumulators start from the bias
             float bb = bias_v[b];
@@ -180,24 +197,23 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
             if constexpr (NBB > 6) asm volatile("" : "+a"(acc[b]));    // one workgroup per CU: the accumulators live in the AGPR half of the file
         }
 
-        unsigned sb = 0;                                // byte offset of the ring slot of chunk c (uniform)
 #pragma nounroll
         for (int c = 0; c < nchunk; ++c) {
             const unsigned nb = sb + BUF == (unsigned)(D * BUF) ? 0u : sb + BUF;
             unsigned cA[4], cB[4];
 #pragma unroll
             for (int t = 1; t < 4; ++t) { cA[t] = offA[t] + sb; cB[t] = offB[t] + sb; }
-            cA[0] = offA[0] + nb; cB[0] = offB[0] + nb; // round 0 of the NEXT chunk (read in this chunk's round 3)
+            cA[0] = offA[0] + nb; cB[0] = offB[0] + nb; // round 0 of the NEXT chunk of the stream (read in this chunk's round 3)
             static_for<4>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 lds_wait<0>(av[r & 1]);
 #pragma unroll
                 for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
                 if constexpr (r == 3) {
-                    // ring hand-over: chunk c + 1 has landed in every wave's view, and this chunk's slot is released.  In flight
-                    // behind chunk c + 1 are the D - 2 chunks after it -- or fewer at the end of the K range (no refill is issued for
-                    // chunks that do not exist), where waiting for everything is exact enough
-                    if (c + D - 1 < nchunk) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
+                    // ring hand-over: the next chunk of the stream has landed in every wave's view, and this chunk's slot is released.
+                    // In flight behind the next chunk are the D - 2 chunks after it (plus, after a tile boundary, the epilogue's stores:
+                    // younger, so the count only errs towards waiting) -- or fewer at the end of the stream, where everything is waited for
+                    if (ahead == D - 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 2) * NL) & 15) | ((((D - 2) * NL) >> 4) << 14));
                     else __builtin_amdgcn_s_waitcnt(0x0F70);
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
@@ -207,14 +223,14 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
                     constexpr int g = decltype(gc)::value;
                     constexpr int u = g / NBB, ib = g % NBB;
                     if constexpr (g < NR) read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
-                    if constexpr (r == 3) {                             // refill the released slot with chunk c + D (if there is one)
+                    if constexpr (r == 3) {                             // refill the released slot with the stream's next chunk (if any)
                         constexpr int G0 = NR < NGAP ? NR : NGAP - 1;
                         constexpr int PD = (NGAP - G0) / NL > 0 ? (NGAP - G0) / NL : 1;
                         static_for<NL>([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
                             constexpr int at = G0 + i * PD < NGAP ? G0 + i * PD : NGAP - 1;
                             if constexpr (at == g) {
-                                if (c + D < nchunk) dma_chunk_piece(c + D, sb, i);
+                                if (fvalid) dma_chunk_piece(fc, sb, i);
                             }
                         });
                     }
@@ -222,25 +238,22 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
+            // this chunk is consumed (ahead - 1); its slot took the stream's next chunk, if there was one (ahead + 1)
+            if (fvalid) advance_fetch();
+            else --ahead;
             sb = nb;
         }
-        // the read-ahead of the chunk after the last one lands in registers nobody uses, but it must have landed before the ring is
-        // refilled (the ties keep its registers allocated); the barrier: EVERY wave is done reading this tile's chunks
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("" : "+" DMN_TILE_RC(av[0][0]));
+        // the round-0 operands of the stream's next chunk (the NEXT tile's first) were requested in the last round: landed before the
+        // epilogue's own memory operations start (the ties hand the registers back to the compiler)
+        lds_wait<0>(av[0]);
 #pragma unroll
         for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
 
-        // ---- the NEXT tile's first chunks go out now, under this tile's epilogue
-        const int64_t i0_done = i0, rows_done = rows_valid;
+        const int64_t i0_done = i0c;
+        const int64_t rows_done = args()->M - i0_done < 128 ? args()->M - i0_done : 128;
         const int64_t next = tile + gridDim.x;
         const bool more = next < ntiles;
-        if (more) {
-            set_tile(next);
-            issue_first_chunks();
-        }
+        i0c = next * 128;
 
         // ---- epilogue: lane holds column n = j0 + 32 b + li, rows 32 w + (r & 3) + 8 (r >> 2) + 4 half
         // (`fresh` hides a value's origin: what is derived from it is computed HERE, in every trip, instead of being hoisted out of the
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
         if (!more) break;
         tile = next;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
     (void)a;
 #endif
