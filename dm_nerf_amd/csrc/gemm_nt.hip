@@ -118,6 +118,12 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     auto fresh_s = [](int x) -> int { asm volatile("" : "+s"(x)); return x; };
     auto dma_chunk_piece = [&](int cc, unsigned slot_byte, int i) __attribute__((always_inline)) {      // piece i of NL of chunk cc (< nchunk) into a ring slot
         float* dst = lds + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;       // (likewise: the LDS addresses of the first chunks' pieces)
+#if defined(DMN_NT_NO_A)   /* diagnostic builds only (scripts/diag_gemm_nt.sh): the loop without the activation / weight requests */
+        if (i < 4) return;
+#endif
+#if defined(DMN_NT_NO_B)
+        if (i >= 4) return;
+#endif
         if (i < 4) {
             if (cc < a.nc0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (DMN_LAS void*)dst, 16, voA0, i * fresh_s(blkA0) + cc * 128, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (DMN_LAS void*)dst, 16, voA1, i * fresh_s(blkA1) + (cc - a.nc0) * 128, 0, 0);
@@ -289,6 +295,9 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
                 if (q->relu) v = relu1(v);
                 if (q->mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm + ro * rowM, 0, 0)) > 0.f ? v : 0.f;
                 v = is_val ? v : 0.f;
+#if defined(DMN_NT_NO_STORE)   /* diagnostic: only the first block's stores (keeps the epilogue's arithmetic alive) */
+                if (b > 0) { asm volatile("" :: "v"(v)); continue; }
+#endif
                 __builtin_amdgcn_raw_buffer_store_b32(f2u(v), rsC, vo + ro * rowB, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);           // block by block: the scheduler would otherwise pull every accumulator out of the

@@ -2,7 +2,9 @@ import sys, time, types, warnings, torch
 warnings.filterwarnings('ignore')
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dm_nerf_amd import config as Cfg
+from dm_nerf_amd import _lib, config as Cfg
+if os.environ.get('DMNERF_DIAG_LIB'):          # a diagnostic build of the library (timing experiments; results may be wrong on purpose)
+    _lib.LIB_PATH = os.path.abspath(os.environ['DMNERF_DIAG_LIB'])
 from dm_nerf_amd.networks import helpers as H, render as R
 RENDER_ONLY = '--render-only' in sys.argv
 SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:] if not a.startswith('--')] or [(8, 256), (8, 192), (6, 128), (10, 320)]
