@@ -19,7 +19,7 @@ def mean(sub, counter):
 
 f, nf = mean("pmc_fetch", "FETCH_SIZE")
 w, nw = mean("pmc_write", "WRITE_SIZE")
-d = {"round": 2, "kernel": "mlp_fwd_kernel<1,false,false,false> fine launch (4096x192 samples)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+d = {"round": 6, "kernel": "mlp_fwd_kernel<1,false,false,false> fine launch (4096x192 samples)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
      "dispatches": [nf, nw], "fetch_correction": 2.0, "traffic_bytes_per_launch": int(round((2.0 * f + w) * 1024)), "source": note}
 json.dump(d, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(d)
