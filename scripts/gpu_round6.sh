@@ -29,6 +29,7 @@ for w in $WHAT; do
     prof)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}/trace -o bench -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --full-record $OUT/prof_${TAG}_bench_full.json > $OUT/prof_${TAG}_trace.log 2>&1)
       python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary.txt 2>&1
+      find $OUT/prof_${TAG} -name "*kernel_trace.csv" -delete     # (tens of MiB; gpurun_out/ merges back only below 64 MiB)
       head -n 60 $OUT/prof_${TAG}/summary.txt ;;
     pmc)
       BENCH="python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --full-record /tmp/bench_full_pmc.json"
@@ -36,7 +37,10 @@ for w in $WHAT; do
        timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_${TAG}/pmc_mfma -o bench -- $BENCH > $OUT/prof_${TAG}_pmc_mfma.log 2>&1
        timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}/pmc_fetch -o bench -- $BENCH > $OUT/prof_${TAG}_pmc_fetch.log 2>&1
        timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}/pmc_write -o bench -- $BENCH > $OUT/prof_${TAG}_pmc_write.log 2>&1)
-      python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary.txt 2>&1
-      head -n 80 $OUT/prof_${TAG}/summary.txt ;;
+      python scripts/summarize_prof.py $OUT/prof_${TAG} > $OUT/prof_${TAG}/summary_pmc.txt 2>&1
+      python scripts/make_pmc_traffic.py $OUT/prof_${TAG} "scripts/gpu_round6.sh ${TAG} pmc (round-6 tree; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of \`bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline\`): profiles/r06/rocprofv3_pmc_r06.txt" > $OUT/prof_${TAG}/make_pmc_traffic.log 2>&1
+      cp profiles/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
+      find $OUT/prof_${TAG} -name "*kernel_trace.csv" -delete -o -name "*counter_collection.csv" -delete
+      head -n 80 $OUT/prof_${TAG}/summary_pmc.txt ;;
   esac
 done
