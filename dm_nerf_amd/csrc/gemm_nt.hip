@@ -8,7 +8,7 @@
 // * the cats of dm_nerf.py:87,90 ([h, pts], [rgb_feature, dirs]) are a K-OFFSET, not a copy: the A operand has up to two K ranges
 //   with their own source pointer and row stride (h | pts), matched by the column order of the packed weights.
 //
-// Tile: one workgroup = 128 samples x ALL (up to 384) outputs of the layer: wave w owns the 32 samples of A block w and every
+// Tile: one workgroup = 128 samples x ALL (up to 320) outputs of the layer: wave w owns the 32 samples of A block w and every
 // B block, NBB accumulator blocks of v_mfma_f32_32x32x2_f32 (the weights are the shared operand: one copy per workgroup through
 // LDS; each activation row is read from HBM exactly once per layer).  Per 32-k chunk the tile is (4 + NBB) blocks of 32 rows x
 // 128 bytes; a block lands in LDS by four LDS-DMA wave-instructions (buffer_load ... lds, 16 B per lane: 8 rows of 128 B each) with the 16-byte units of a
@@ -32,16 +32,15 @@ using namespace dmn;
 
 namespace {
 
-constexpr int NT_RING_BYTES = 147456;     // ring budget of the CU's 160 KiB when ONE workgroup owns the CU
-constexpr int NT_RING_BYTES_2 = 81920;    // ... and when TWO share it (narrow layers: see nt_occupancy)
+constexpr int NT_STAGE_BYTES = 16384;     // the epilogue's transposition area: 4 KiB per wave (one 32 x 32 block)
+constexpr int NT_RING_BYTES = 147456 - NT_STAGE_BYTES;      // ring budget of the CU's 160 KiB when ONE workgroup owns the CU
+constexpr int NT_RING_BYTES_2 = 81920 - NT_STAGE_BYTES;     // ... and when TWO share it (narrow layers: see nt_occupancy)
 constexpr int NT_MAX_DEPTH = 4;
-constexpr int NT_MAX_NBB = 12;            // 384 outputs per workgroup: 192 accumulator registers
+constexpr int NT_MAX_NBB = 10;            // 320 outputs per workgroup: 160 accumulator registers (12 blocks no longer fit the file next to the epilogue's staging)
 
-// Workgroups per CU.  A tile's fixed cost -- launch, the first chunk's DMA latency, the epilogue's stores draining -- is ~10 us
-// (measured: a 63 -> 192 layer, 2 chunks, took 15 us per tile for 5 us of MFMA work); with one workgroup per CU nothing runs under
-// it.  Up to 6 out-blocks a wave needs < 256 registers and the ring fits 80 KiB at depth 2, so two workgroups share a CU and one's
-// prologue / epilogue hides under the other's MFMA stream; wider tiles (longer K loops, relatively smaller fixed cost) keep the CU.
-constexpr int nt_occupancy(int nbb) { return nbb <= 6 ? 2 : 1; }
+// Workgroups per CU.  Up to 4 out-blocks a wave needs < 256 registers and ring + staging fit 80 KiB at depth 2: two workgroups share
+// a CU and one's epilogue hides under the other's MFMA stream; wider tiles keep the CU (and a deeper ring).
+constexpr int nt_occupancy(int nbb) { return nbb <= 4 ? 2 : 1; }
 
 struct NtArgs {
     const float* A0; const float* A1;     // the two K ranges of the A operand (A1 null: one range)
@@ -56,7 +55,16 @@ struct NtArgs {
     const float* mask; int64_t ldm;       // data gradient: C = mask[m * ldm + n] > 0 ? v : 0, or null
     int64_t M;
     int relu, accumulate;
+    int x4;                               // epilogue form: 1 = 16-byte stores through the LDS transposition (n_zero a multiple of 4)
+#ifdef DMN_NT_TRACE
+    long long* trace;                     // diagnostic builds only (scripts/diag_gemm_nt.py): per workgroup and tile, shader-clock stamps
+#endif
 };
+#ifdef DMN_NT_TRACE
+#define DMN_NT_STAMP(k) do { if (a.trace && threadIdx.x == 0 && tile_seq < 32) a.trace[((int64_t)blockIdx.x * 32 + tile_seq) * 4 + (k)] = (long long)clock64(); } while (0)
+#else
+#define DMN_NT_STAMP(k) do {} while (0)
+#endif
 
 template <int NBB>
 struct NtRing {
@@ -193,8 +201,12 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     f32x16 acc[NBB];
     unsigned sb = 0;                                    // byte offset of the ring slot of the chunk being consumed (uniform)
     int64_t i0c = i0_first;                             // the tile being COMPUTED
+#ifdef DMN_NT_TRACE
+    int tile_seq = 0;
+#endif
 #pragma nounroll
     for (;;) {
+        DMN_NT_STAMP(0);
 #pragma unroll
         for (int b = 0; b < NBB; ++b) {                 // accumulators start from the bias
             float bb = bias_v[b];
@@ -251,6 +263,7 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
         }
         // the round-0 operands of the stream's next chunk (the NEXT tile's first) were requested in the last round: landed before the
         // epilogue's own memory operations start (the ties hand the registers back to the compiler)
+        DMN_NT_STAMP(1);
         lds_wait<0>(av[0]);
 #pragma unroll
         for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[0][k]));
@@ -280,28 +293,76 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
             voM = (int)(((int64_t)(32 * w + 4 * half_e) * q->ldm + li_e) * 4);
             rowM = fresh_v((int)(q->ldm * 4));
         }
+        if (q->x4) {
+            // ---- 16-byte stores.  A burst of 16 NBB dword stores per lane ran into the wave's limit of outstanding memory operations:
+            // 15 000 cycles per tile at 10 out-blocks, 36 000 with two workgroups per CU (stamps: scripts/diag_gemm_nt.py) -- a sixth to a
+            // third of the tile.  Each 32 x 32 block goes through this wave's 4 KiB of LDS instead (lane (li, half) writes column li of
+            // its 16 rows; lane l reads 4 consecutive columns of row 8 j + (l >> 3)) and leaves as FOUR 1-KiB stores: 8 rows x 128 bytes.
+            float* const st = lds + (D * BUF) / 4 + w * 1024;
+            const int row_l = lane_e >> 3, col_l = 4 * (lane_e & 7);
+            const int voC4 = (int)(((int64_t)(32 * w + row_l) * q->ldc + col_l) * 4);
+            const int voM4 = q->mask ? (int)(((int64_t)(32 * w + row_l) * q->ldm + col_l) * 4) : 0;
+            const int rowB8 = 8 * rowB, rowM8 = 8 * rowM;
 #pragma unroll
-        for (int b = 0; b < NBB; ++b) {
-            const int col = 32 * b + li_e;
-            const bool in_c = col < ncols;                                       // (a column predicate: the descriptor bounds rows only)
-            const bool is_val = j0 + col < q->n_store;
-            const int vo = in_c ? voC + b * 128 : 0x7ffffff0;
-            const int vm = in_c ? voM + b * 128 : 0x7ffffff0;
+            for (int b = 0; b < NBB; ++b) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ro = (r & 3) + 8 * (r >> 2);
-                float v = acc[b][r];
-                if (q->accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo + ro * rowB, 0, 0));
-                if (q->relu) v = relu1(v);
-                if (q->mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm + ro * rowM, 0, 0)) > 0.f ? v : 0.f;
-                v = is_val ? v : 0.f;
-#if defined(DMN_NT_NO_STORE)   /* diagnostic: only the first block's stores (keeps the epilogue's arithmetic alive) */
-                if (b > 0) { asm volatile("" :: "v"(v)); continue; }
-#endif
-                __builtin_amdgcn_raw_buffer_store_b32(f2u(v), rsC, vo + ro * rowB, 0, 0);
+                for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * half_e) * 32 + li_e] = acc[b][r];
+                const int col0 = 32 * b + col_l;
+                const bool in_c = col0 < ncols;                                  // (ncols is a multiple of 4 here)
+                const int vo = in_c ? voC4 + b * 128 : 0x7ffffff0;
+                const int vm = in_c ? voM4 + b * 128 : 0x7ffffff0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(st + (8 * j + row_l) * 32 + col_l);
+                    if (q->accumulate) {
+                        const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rsC, vo + j * rowB8, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(o[e]);
+                    }
+                    if (q->relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = relu1(v[e]);
+                    }
+                    if (q->mask) {
+                        const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, vm + j * rowM8, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(mk[e]) > 0.f ? v[e] : 0.f;
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = j0 + col0 + e < q->n_store ? f2u(v[e]) : 0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsC, vo + j * rowB8, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);           // block by block: the scheduler would otherwise pull every accumulator out of the
-        }                                                // AGPR file first (16 NBB VGPRs live at once: spills in the wide tiles)
+        } else {
+    #pragma unroll
+            for (int b = 0; b < NBB; ++b) {
+                const int col = 32 * b + li_e;
+                const bool in_c = col < ncols;                                       // (a column predicate: the descriptor bounds rows only)
+                const bool is_val = j0 + col < q->n_store;
+                const int vo = in_c ? voC + b * 128 : 0x7ffffff0;
+                const int vm = in_c ? voM + b * 128 : 0x7ffffff0;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    float v = acc[b][r];
+                    if (q->accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo + ro * rowB, 0, 0));
+                    if (q->relu) v = relu1(v);
+                    if (q->mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, vm + ro * rowM, 0, 0)) > 0.f ? v : 0.f;
+                    v = is_val ? v : 0.f;
+    #if defined(DMN_NT_NO_STORE)   /* diagnostic: only the first block's stores (keeps the epilogue's arithmetic alive) */
+                    if (b > 0) { asm volatile("" :: "v"(v)); continue; }
+    #endif
+                    __builtin_amdgcn_raw_buffer_store_b32(f2u(v), rsC, vo + ro * rowB, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);           // block by block: the scheduler would otherwise pull every accumulator out of the
+            }                                                // AGPR file first (16 NBB VGPRs live at once: spills in the wide tiles)
+        }
+        DMN_NT_STAMP(2);
+#ifdef DMN_NT_TRACE
+        ++tile_seq;
+#endif
         if (!more) break;
         tile = next;
     }
@@ -383,7 +444,7 @@ __global__ void copy_cols_pad_kernel(const float* __restrict__ src, int64_t lds_
 
 template <int NBB>
 int launch_nt(const NtArgs& a, int tiles_n, hipStream_t stream) {
-    constexpr int lds_bytes = NtRing<NBB>::D * NtRing<NBB>::BUF;
+    constexpr int lds_bytes = NtRing<NBB>::D * NtRing<NBB>::BUF + NT_STAGE_BYTES;
     static DmnOncePerDevice once;
     if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<NBB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
         e != hipSuccess)
@@ -401,6 +462,11 @@ int launch_nt(const NtArgs& a, int tiles_n, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef DMN_NT_TRACE
+static long long* g_dmn_nt_trace = nullptr;
+extern "C" int dmnerf_gemm_nt_set_trace(int64_t* d_ticks) { g_dmn_nt_trace = (long long*)d_ticks; return 0; }
+#endif
 
 extern "C" int dmnerf_gemm_nt_blocks(int n_out) {
     // out-blocks (32 outputs) per workgroup for a layer of n_out outputs: all of them up to NT_MAX_NBB, else even tiles
@@ -443,6 +509,11 @@ extern "C" int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats
     a.A0 = d_A0; a.A1 = k1 > 0 ? d_A1 : nullptr; a.lda0 = lda0; a.lda1 = k1 > 0 ? lda1 : 0; a.a0_floats = a0_floats; a.a1_floats = a1_floats;
     a.nc0 = nc0; a.nc1 = nc1; a.B = d_B; a.b_floats = b_floats; a.ldb = ldb; a.bias = d_bias; a.C = d_C; a.ldc = ldc;
     a.n_store = n_store; a.n_zero = n_zero; a.mask = d_mask; a.ldm = ldm; a.M = M; a.relu = relu; a.accumulate = accumulate;
+    // 16-byte epilogue accesses only where every row of C (and of the mask) keeps them 16-byte aligned
+    a.x4 = (n_zero % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)d_C & 15) == 0 && (!d_mask || (ldm % 4 == 0 && ((uintptr_t)d_mask & 15) == 0))) ? 1 : 0;
+#ifdef DMN_NT_TRACE
+    a.trace = g_dmn_nt_trace;
+#endif
     hipStream_t s = (hipStream_t)stream;
     switch (nbb) {
         case 1: return launch_nt<1>(a, tiles, s);
@@ -455,8 +526,6 @@ extern "C" int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats
         case 8: return launch_nt<8>(a, tiles, s);
         case 9: return launch_nt<9>(a, tiles, s);
         case 10: return launch_nt<10>(a, tiles, s);
-        case 11: return launch_nt<11>(a, tiles, s);
-        case 12: return launch_nt<12>(a, tiles, s);
         default: return dmn_fail(DMNERF_E_ARG, "gemm_nt: unsupported block count %d", nbb);
     }
 }

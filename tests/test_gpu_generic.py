@@ -60,11 +60,12 @@ def test_strided_gemm_three_forms(A):
 
 
 @pytest.mark.parametrize("M_,K0,K1,N", [(1000, 167, 0, 130), (257, 63, 0, 128), (4097, 320, 63, 320), (300, 192, 27, 96), (129, 96, 0, 18),
-                                         (1000, 1, 0, 320), (513, 384, 0, 400)])
+                                         (1000, 1, 0, 320), (513, 384, 0, 400), (700, 64, 0, 3), (300, 160, 27, 352)])
 def test_gemm_nt_forward_and_data_gradient_forms(A, M_, K0, K1, N):
     """csrc/gemm_nt.hip (the LDS-DMA / ds_read_b128 GEMM of the generic path) against float64: forward relu(X W^T + b) with a cat
     input as two K ranges, output into a column slice of a wider buffer with its pad columns zeroed; the data-gradient form
-    (W^T packed transposed, ReLU-derivative mask, accumulate); ragged M, K not a multiple of 32, N of 1 .. 13 out-blocks (two tiles)."""
+    (W^T packed transposed, ReLU-derivative mask, accumulate); ragged M, K not a multiple of 32, N of 1 .. 13 out-blocks (two tiles), both epilogue forms (16-byte stores when the row's
+    pad allows, dword stores into a 4 + C wide output)."""
     G = A.G
     g = torch.Generator().manual_seed(M_ + N)
     x0 = G._Act.empty(M_, K0, "cuda"); x0.buf.copy_(torch.randn(M_, x0.ld, generator=g)); x0.buf[:, K0:] = 0
