@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
             const int voC4 = (int)(((int64_t)(32 * w + row_l) * q->ldc + col_l) * 4);
             const int voM4 = q->mask ? (int)(((int64_t)(32 * w + row_l) * q->ldm + col_l) * 4) : 0;
             const int rowB8 = 8 * rowB, rowM8 = 8 * rowM;
+            const bool all_valid = j0 + NBB * 32 <= q->n_store;
 #pragma unroll
             for (int b = 0; b < NBB; ++b) {
 #pragma unroll
@@ -329,8 +330,13 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
                         for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(mk[e]) > 0.f ? v[e] : 0.f;
                     }
                     u32x4 o;
+                    if (all_valid) {                                            // (uniform: no pad column inside this workgroup's columns)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = j0 + col0 + e < q->n_store ? f2u(v[e]) : 0u;
+                        for (int e = 0; e < 4; ++e) o[e] = f2u(v[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = j0 + col0 + e < q->n_store ? f2u(v[e]) : 0u;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(o, rsC, vo + j * rowB8, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -420,14 +426,30 @@ __global__ void ray_embed_kernel(const float* __restrict__ ro, const float* __re
     float* ov = xv + m * ldv;
     op[c] = p;
     ov[c] = v;
-    const double tp = dmn::rev_of(p), tv = dmn::rev_of(v);
-    for (int k = 0; k < Lp; ++k) {
-        op[3 + 6 * k + c] = dmn::sin_rev(tp, k, 0);
-        op[3 + 6 * k + 3 + c] = dmn::sin_rev(tp, k, 1);
+    // one sin / cos pair per coordinate (frequency 1, shared range reduction in double), the higher octaves by the double-angle
+    // recurrence in double precision -- exactly what the fused kernels' encode() does (mlp_common.h): 5 instead of ~19 f64 instructions
+    // per output, absolute error <= 2^k 1e-16
+    {
+        const double t = dmn::rev_of(p);
+        double sn = dmn::sin_rev_d(t, 0, 0), cs = dmn::sin_rev_d(t, 0, 1);
+        for (int k = 0; k < Lp; ++k) {
+            op[3 + 6 * k + c] = (float)sn;
+            op[3 + 6 * k + 3 + c] = (float)cs;
+            const double s_old = sn, t2 = s_old + s_old;
+            sn = t2 * cs;
+            cs = __builtin_fma(-t2, s_old, 1.0);
+        }
     }
-    for (int k = 0; k < Lv; ++k) {
-        ov[3 + 6 * k + c] = dmn::sin_rev(tv, k, 0);
-        ov[3 + 6 * k + 3 + c] = dmn::sin_rev(tv, k, 1);
+    {
+        const double t = dmn::rev_of(v);
+        double sn = dmn::sin_rev_d(t, 0, 0), cs = dmn::sin_rev_d(t, 0, 1);
+        for (int k = 0; k < Lv; ++k) {
+            ov[3 + 6 * k + c] = (float)sn;
+            ov[3 + 6 * k + 3 + c] = (float)cs;
+            const double s_old = sn, t2 = s_old + s_old;
+            sn = t2 * cs;
+            cs = __builtin_fma(-t2, s_old, 1.0);
+        }
     }
     for (int q = 3 + 6 * Lp + c; q < ldp; q += 3) op[q] = 0.f;     // pad columns
     for (int q = 3 + 6 * Lv + c; q < ldv; q += 3) ov[q] = 0.f;
