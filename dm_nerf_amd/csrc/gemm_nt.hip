@@ -33,14 +33,16 @@ using namespace dmn;
 namespace {
 
 constexpr int NT_STAGE_BYTES = 16384;     // the epilogue's transposition area: 4 KiB per wave (one 32 x 32 block)
-constexpr int NT_RING_BYTES = 147456 - NT_STAGE_BYTES;      // ring budget of the CU's 160 KiB when ONE workgroup owns the CU
-constexpr int NT_RING_BYTES_2 = 81920 - NT_STAGE_BYTES;     // ... and when TWO share it (narrow layers: see nt_occupancy)
+// (ring budget: 147 456 bytes of the CU's 160 KiB when ONE workgroup owns the CU, 81 920 when TWO share it, minus the staging area)
 constexpr int NT_MAX_DEPTH = 4;
 constexpr int NT_MAX_NBB = 10;            // 320 outputs per workgroup: 160 accumulator registers (12 blocks no longer fit the file next to the epilogue's staging)
 
-// Workgroups per CU.  Up to 4 out-blocks a wave needs < 256 registers and ring + staging fit 80 KiB at depth 2: two workgroups share
-// a CU and one's epilogue hides under the other's MFMA stream; wider tiles keep the CU (and a deeper ring).
-constexpr int nt_occupancy(int nbb) { return nbb <= 4 ? 2 : 1; }
+// Workgroups per CU.  Up to 6 out-blocks a wave needs < 256 registers and the ring fits 80 KiB at depth 2: two workgroups share a CU
+// and one's epilogue hides under the other's MFMA stream (W = 192: 0.66 of the roof against 0.64 alone on the CU with the 16-byte
+// epilogue, measured); wider tiles keep the CU.  The epilogue's staging area fits next to the ring except at 5 and 6 out-blocks with
+// two workgroups (2 x 40 KiB + 16 > 80): those keep the dword epilogue.
+constexpr int nt_occupancy(int nbb) { return nbb <= 6 ? 2 : 1; }
+constexpr bool nt_staged(int nbb) { return nbb <= 4 || nbb > 6; }
 
 struct NtArgs {
     const float* A0; const float* A1;     // the two K ranges of the A operand (A1 null: one range)
@@ -70,7 +72,8 @@ template <int NBB>
 struct NtRing {
     static constexpr int NL = 4 + NBB;                                   // DMA pieces per wave per chunk (1 KiB each)
     static constexpr int BUF = NL * 4096;                                // bytes per chunk
-    static constexpr int BUDGET = nt_occupancy(NBB) == 2 ? NT_RING_BYTES_2 : NT_RING_BYTES;
+    static constexpr int STAGE = nt_staged(NBB) ? NT_STAGE_BYTES : 0;
+    static constexpr int BUDGET = (nt_occupancy(NBB) == 2 ? 81920 : 147456) - STAGE;
     static constexpr int D = BUDGET / BUF < NT_MAX_DEPTH ? BUDGET / BUF : NT_MAX_DEPTH;
     static_assert(D >= 2, "ring needs two slots");
     static_assert((D - 1) * NL <= 63, "vmcnt range");
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
             voM = (int)(((int64_t)(32 * w + 4 * half_e) * q->ldm + li_e) * 4);
             rowM = fresh_v((int)(q->ldm * 4));
         }
-        if (q->x4) {
+        if (nt_staged(NBB) && q->x4) {
             // ---- 16-byte stores.  A burst of 16 NBB dword stores per lane ran into the wave's limit of outstanding memory operations:
             // 15 000 cycles per tile at 10 out-blocks, 36 000 with two workgroups per CU (stamps: scripts/diag_gemm_nt.py) -- a sixth to a
             // third of the tile.  Each 32 x 32 block goes through this wave's 4 KiB of LDS instead (lane (li, half) writes column li of
@@ -466,7 +469,7 @@ __global__ void copy_cols_pad_kernel(const float* __restrict__ src, int64_t lds_
 
 template <int NBB>
 int launch_nt(const NtArgs& a, int tiles_n, hipStream_t stream) {
-    constexpr int lds_bytes = NtRing<NBB>::D * NtRing<NBB>::BUF + NT_STAGE_BYTES;
+    constexpr int lds_bytes = NtRing<NBB>::D * NtRing<NBB>::BUF + NtRing<NBB>::STAGE;
     static DmnOncePerDevice once;
     if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)gemm_nt_kernel<NBB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
         e != hipSuccess)
