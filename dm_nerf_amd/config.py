@@ -19,7 +19,7 @@ def create_nerf(args):
         warnings.warn(f"dm_nerf_amd.create_nerf: netdepth={D} netwidth={W} multires={getattr(args, 'multires', 10)}/"
                       f"{getattr(args, 'multires_views', 4)} is not the shape the fused kernels are specialised for (8 x 256, skips [4], "
                       "multires 10 / 4: every shipped config); it runs layer by layer on the generic GEMM path (dm_nerf_amd/generic.py) at "
-                      "0.5 - 0.7x of the f32-MFMA roof in inference (measured: W = 128 0.49, 192 0.64, 320 0.73; scripts/generic_time.py) "
+                      "0.5 - 0.7x of the f32-MFMA roof in inference (measured: W = 128 0.52, 192 0.66, 320 0.77; scripts/generic_time.py) "
                       "instead of 0.93, training about half of that",
                       RuntimeWarning, stacklevel=2)
     return position_embedder, view_embedder, model_coarse, model_fine, args
