@@ -204,11 +204,15 @@ def _long_run(budget):
     return _long_runs[budget]
 
 
-def plan_budgets():
-    """Weight-gradient plans: the default (one workgroup per CU) and four other splits of the sample axis -- 7/8, 3/4, 5/8 and 1/2
-    of the CU count (224, 192, 160, 128 workgroups on the 256 CUs of an MI355X)."""
+def plan_budgets(n=5):
+    """Weight-gradient plans: the default (one workgroup per CU) and ``n - 1`` other splits of the sample axis -- 7/8, 3/4, 5/8 and 1/2
+    of the CU count (224, 192, 160, 128 workgroups on the 256 CUs of an MI355X); n = 8 adds 15/16, 13/16 and 11/16 (240, 208, 176)."""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    return (None,) + tuple(int(cus * f) for f in (0.875, 0.75, 0.625, 0.5))
+    fracs = (0.875, 0.75, 0.625, 0.5, 0.9375, 0.8125, 0.6875)[:n - 1]
+    return (None,) + tuple(int(cus * f) for f in fracs)
+
+
+N_PLANS_DEFAULT_MODE = 8           # HIP runs of the default mode (shared by the 300-step and the plateau test: _long_run)
 
 
 def _oracle_runs(golden, steps_needed):
@@ -251,8 +255,9 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     """300 steps x 512 rays on the batches and jitter of the oracle's run.  A training trajectory amplifies rounding differences
     (ReLU boundaries, Adam's sign-like first steps), so the losses are compared step by step where that is tight and in windows
     afterwards, and the PSNR after the 300 steps -- still climbing ~0.03 dB per step there -- as a TWO-SAMPLE comparison (VERDICT
-    r04 item 3): five HIP runs that differ only in the order of the weight-gradient partial sums (plan_budgets()) against the
-    oracle's four runs that differ only in the order the batch rows are visited (tests/golden/train_traj*.npz).  The means must
+    r04 item 3): eight HIP runs (five in the opt-in modes) that differ only in the order of the weight-gradient partial sums
+    (plan_budgets()) against the oracle's runs -- four, six once train_traj_v4 / v5 are committed -- that differ only in the order the
+    batch rows are visited (tests/golden/train_traj*.npz).  The means must
     agree within twice the standard error of their difference AND within 0.5 dB whatever the spreads.  Loss bounds (r03
     measurements: 1.7e-4 over the first 20 steps, 4e-4 .. 5e-3 over the first 100, 1.2 .. 1.6 % on 20-step windows) are ~2.5-3x
     those figures."""
@@ -263,7 +268,7 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     oracle_runs, n_or = _oracle_runs(golden, (T.STEPS,))
     assert n_or >= 4, "the oracle's summation-order variants (tests/golden/train_traj_v*.npz) are missing"
     if mode is None:                                                    # (shared with the plateau test: _long_run)
-        runs = {b: (_long_run(b)[0][:T.STEPS], _long_run(b)[1]) for b in plan_budgets()}
+        runs = {b: (_long_run(b)[0][:T.STEPS], _long_run(b)[1]) for b in plan_budgets(N_PLANS_DEFAULT_MODE)}
     else:
         runs = {b: _run_trajectory(mode, T.STEPS, (T.STEPS,), max_wgs=b) for b in plan_budgets()}
     got, evals = runs[None]
@@ -296,8 +301,8 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
 def test_trained_psnr_matches_the_oracle_at_the_plateau(golden, capsys):
     """The same run continued to 2000 steps (the oracle's: ~1-3 h of CPU each in the build container, make_train_traj.py): from
     ~1000 steps on the held-out PSNR has no steady slope left and wanders by a dB between checkpoints, so single checkpoints say
-    little.  Statistic per run: the MEAN PSNR over steps 1000 / 1500 / 2000.  Two samples: five HIP runs (weight-gradient sums in
-    five orders) against the oracle's four (batch rows in four orders): |difference of the sample means| <= 2 standard errors AND
+    little.  Statistic per run: the MEAN PSNR over steps 1000 / 1500 / 2000.  Two samples: eight HIP runs (weight-gradient sums in
+    eight orders) against the oracle's four to six (batch rows in as many orders): |difference of the sample means| <= 2 standard errors AND
     <= 0.75 dB whatever the spreads."""
     g = golden("train_traj")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
@@ -309,7 +314,7 @@ def test_trained_psnr_matches_the_oracle_at_the_plateau(golden, capsys):
     assert sorted(oracle_runs) == list(T.EVAL_AT) and T.EVAL_AT[-1] == T.LONG_STEPS
     late = [s for s in T.EVAL_AT if s >= 1000]
     oracle_means = [float(np.mean([oracle_runs[s][k] for s in late])) for k in range(n_or)]
-    runs = {b: _long_run(b)[1] for b in plan_budgets()}
+    runs = {b: _long_run(b)[1] for b in plan_budgets(N_PLANS_DEFAULT_MODE)}
     means = {b: float(np.mean([ev[s][0] for s in late])) for b, ev in runs.items()}
     gap, bound, ok = _two_sample(list(means.values()), oracle_means, cap=0.75)
     with capsys.disabled():
