@@ -91,6 +91,13 @@ def test_gemm_nt_forward_and_data_gradient_forms(A, M_, K0, K1, N):
     want = (dY.buf[:, :N].double() @ Wt.double()[:, :K0] + 0.5) * (H[:, :K0] > 0)
     assert float((dX.buf[:, :K0].double() - want).abs().max()) <= 2e-6 * max(10.0, float(want.abs().max()))     # (sums of N terms: up to ~25)
     assert bool((dX.buf[:, K0:] == 0).all())
+    # the dword epilogue (an output whose rows cannot take 16-byte stores: the heads' column slices of the [M, 4 + C] raw tensor):
+    # exactly N columns written into a buffer of odd row length, everything around them untouched
+    Z = torch.full((M_, N + 5), 7.0, device="cuda")
+    G._linear_nt(x0, pk, G._col(Z, 3), N + 5, N, N, M_, a1=x1, relu=False)
+    want = X @ Wt.double().t() + b.double()
+    assert float((Z[:, 3:3 + N].double() - want).abs().max()) <= 2e-6 * max(10.0, float(want.abs().max()))
+    assert bool((Z[:, :3] == 7.0).all()) and bool((Z[:, 3 + N:] == 7.0).all())
 
 
 @pytest.mark.parametrize("cfg", SHAPES)
