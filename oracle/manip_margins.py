@@ -9,7 +9,7 @@ displaced sample lands), not of the implementation -- and it can be measured wit
 * ``sens [n, 4]``: per pixel and output (final rgb, final object map, target rgb, target object map) the largest deviation from the
   reference's recorded run among several OTHER f32-class evaluations of the same chain on the same rays and draws
   (``variant_nets``: the oracle as this host's BLAS rounds it, the network evaluated in float64 on the same f32 inputs, the
-  K dimension of every layer summed in 2, 3, 4 or 5 pieces, forwards or backwards).  A tolerance that follows it --
+  K dimension of every layer summed in 2, 3 or 4 pieces, forwards or backwards).  A tolerance that follows it --
   ``floor + gain * sens`` -- is tight (the floor) wherever the chain is well-conditioned and loosens only where the reference's own
   formula amplifies rounding, by as much as it is seen to.
 * ``critical [n]``: pixels with a draw on the DISCONTINUITY -- a resampling draw whose cdf slope is within 4 ulp of the cdf (4.8e-7)
@@ -68,7 +68,7 @@ def _split_k_net(parts, reverse):
 def variant_nets():
     """name -> ``net`` for ``ref_cpu.manipulator(net=)``: f32-class evaluations of the same network."""
     return {"oracle_this_host": None, "network_f64": _net_f64, "k_split_2": _split_k_net(2, False), "k_split_3_reversed": _split_k_net(3, True),
-            "k_split_4_reversed": _split_k_net(4, True), "k_split_5": _split_k_net(5, False)}
+            "k_split_4_reversed": _split_k_net(4, True)}
 
 
 def frame_inputs(g):

@@ -122,10 +122,12 @@ def test_object_branch_learns_on_the_analytic_scene(mode, capsys):
     # peaked weights, saturated sigmoids, confident labels -- instead of scaled random weights.
     hip_rgb, hip_ins = _evaluate.last['rgb_fine'].cpu(), _evaluate.last['ins_fine'].cpu()
     gt = ims[-1].reshape(-1, 3)
-    # (the oracle renders a subset of the image rows -- 9600 of the 19 200 pixels in the default mode, 4800 in the opt-in one: ~25 / 12 s
-    # of host time instead of 50; the full view was compared in rounds 3-5: 0 / 19 200 flips, profiles/r05)
-    stride = 2 if mode is None else 4
-    rows = torch.arange(0, H, stride)[:, None] * W + torch.arange(W)[None, :]
+    # (the oracle renders a subset of the image rows -- every third, 6400 of the 19 200 pixels: ~15 s of host time instead of 50; the
+    # full view was compared in rounds 3-5: 0 / 19 200 flips, profiles/r05.  The opt-in mode's trained networks are not re-rendered
+    # by the oracle any more: its inference parity has its own tests, test_gpu_parity.py / test_gpu_configs.py.)
+    if mode is not None:
+        return
+    rows = torch.arange(0, H, 3)[:, None] * W + torch.arange(W)[None, :]
     sel = rows.reshape(-1)
     or_rgb, or_ins = _oracle_render(mc, mf, test_rays[:, sel.to(test_rays.device)], ze[:sel.numel()])
     hip_rgb, hip_ins, gt = hip_rgb[sel], hip_ins[sel], gt[sel]

@@ -170,12 +170,12 @@ def test_against_the_reference_manipulator_eval_run(golden, capsys):
 
     The chain is ill-conditioned on a minority of rays (three inverse-CDF resamplings with slopes down to 1e-5 and a hard threshold
     there, discrete label decisions), so each pixel is held to the reference's run AS TIGHTLY AS ITS OWN CONDITIONING ALLOWS
-    (oracle/manip_margins.py): tolerance = 1e-4 + 4 x the largest deviation SIX other f32-class evaluations
-    of the same chain show at that pixel (the oracle on this host, the network in float64, K summed in 2 / 3 / 4 / 5 pieces) --
+    (oracle/manip_margins.py): tolerance = 1e-4 + 4 x the largest deviation FIVE other f32-class evaluations
+    of the same chain show at that pixel (the oracle on this host, the network in float64, K summed in 2 / 3 / 4 pieces) --
     1e-4 .. 2e-4 on more than 80 % of the pixels.  At most 1 % of the pixels may exceed it, only pixels with a draw ON the slope
     threshold (about 10 % of the rays have one of their 384 draws there) by more than fifty times, and the label equals the
     reference's wherever the reference's top-2 margin exceeds twice the tolerance.  The rule's soundness (it accepts each of the
-    six evaluations when the tolerance is measured without it) and power (it rejects a frame with 20 % or 2 % of its pixels
+    five evaluations when the tolerance is measured without it) and power (it rejects a frame with 20 % or 2 % of its pixels
     mis-routed) are shown on the CPU: tests/test_manip_conditioning.py."""
     from dm_nerf_amd import distributed as D
     from dm_nerf_amd.networks import dm_nerf as M
@@ -215,7 +215,7 @@ def test_against_the_reference_manipulator_eval_run(golden, capsys):
             fr.step(c)
         frame = [t.cpu() for t in fr.gather()]
     n = H_ * W_
-    sens, critical, _ = MM.frame_conditioning(g)                          # six oracle evaluations of the frame on the host cores
+    sens, critical, _ = MM.frame_conditioning(g)                          # five oracle evaluations of the frame on the host cores
     rep = MM.check_frame([t.reshape(n, -1) for t in frame], g, sens, critical)
     with capsys.disabled():
         print(f"\n[manipulation frame vs the reference's manipulator_eval, {n} pixels] tolerance 1e-4 + 4 sens: <= 2e-4 on "

@@ -22,7 +22,7 @@ def _sens(g, outs, names):
 
 
 def test_the_rule_accepts_every_variant_left_out_of_its_own_tolerance(frame):
-    """Leave-one-out: each f32-class evaluation (network in float64; K summed in 2 .. 5 pieces) judged against a tolerance measured
+    """Leave-one-out: each f32-class evaluation (network in float64; K summed in 2 .. 4 pieces) judged against a tolerance measured
     WITHOUT it must pass -- it stands in for the HIP path, which the tolerance is never measured with."""
     g, outs, critical = frame
     names = list(outs)
