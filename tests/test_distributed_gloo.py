@@ -256,10 +256,12 @@ def _train_two_steps(penalize=True):
     if dist.is_initialized():
         dist.all_gather = lambda *a, **k: (calls.__setitem__("gather", calls["gather"] + 1), real_gather(*a, **k))[1]
         dist.all_reduce = lambda *a, **k: (calls.__setitem__("reduce", calls["reduce"] + 1), real_reduce(*a, **k))[1]
+    D.collective_tally(reset=True)
     try:
         losses = _two_steps(rays, z, target, labels, mc, mf, args, opt, render, penalizer)
     finally:
         dist.all_gather, dist.all_reduce = real_gather, real_reduce
+    calls["tally"] = D.collective_tally(reset=True)          # the module's own count (what bench.py reports per step at N > 1)
     flat = torch.cat([p.detach().reshape(-1) for p in mc.parameters() + mf.parameters()])
     draws = [torch.cat([a, b], 1).numpy() for a, b in seen]  # per step: [n_local, S + N_importance]
     return losses, flat.numpy(), _two_steps.nbytes, calls, draws
@@ -316,7 +318,11 @@ def test_two_rank_sharded_training_equals_single_process(penalize):
         assert nbytes == 4 * n_param                        # ONE flat bucket with both models' gradients
         if not penalize:                                    # (the injected penalizer of this test gathers on its own)
             # per step: ONE packed all-gather (rgb | ins of both levels) and ONE gradient all-reduce
+            tally = calls.pop("tally")
             assert calls == {"gather": 2, "reduce": 2}, calls
+            # ... and the module's own tally (bench.py's `collectives_per_step` / `allreduce_bytes_per_step`) says the same
+            assert tally["count"] == 4 and tally["kinds"] == {"all_gather": 2, "all_reduce_grads": 2}, tally
+            assert tally["bytes"] >= 2 * 4 * n_param
         assert np.allclose(losses, want_losses, rtol=1e-5), (losses, want_losses)
         assert np.abs(flat - want).max() <= 1e-6, np.abs(flat - want).max()
         assert np.abs(flat - start).max() >= 1e-3           # ... of steps that did move the weights
@@ -370,6 +376,7 @@ def test_wide_worlds_frame_and_training_equal_single_process(world):
             assert all(np.array_equal(a, b) for a, b in zip(frames[h], res[0][1][h])), (rank, h)
         assert np.array_equal(lab[1], lab1[1]) and lab[1].dtype == np.int64
         assert all(np.allclose(a, b, rtol=0, atol=2.5e-7) for a, b in zip(lab, lab1))
+        assert calls.pop("tally")["kinds"] == {"all_gather": 2, "all_reduce_grads": 2}
         assert calls == {"gather": 2, "reduce": 2}, calls
         assert np.allclose(losses, want_losses, rtol=1e-5), (losses, want_losses)
         assert np.abs(flat - want).max() <= 2e-6, np.abs(flat - want).max()
