@@ -37,6 +37,11 @@ class RepackModel(ctypes.Structure):
                 ("d_idx_t", c_vp), ("d_blob_t", c_vp), ("d_f_pos", c_vp)]
 
 
+class ChainLayer(ctypes.Structure):
+    """``dmnerf_chain_layer`` (include/dmnerf_hip.h)."""
+    _fields_ = [("d_B", c_vp), ("d_bias", c_vp), ("ldb", c_int), ("from_act", c_int), ("from_x", c_int), ("relu", c_int)]
+
+
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); exactly the symbols include/dmnerf_hip.h declares
@@ -104,6 +109,8 @@ SIGNATURES = {
     "dmnerf_pack_nt": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "dmnerf_gemm_nt": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_int,
                                c_i64, c_int, c_vp, c_i64, c_int, c_vp]),
+    "dmnerf_mlp_chain_supported": (c_int, [c_int, c_int]),
+    "dmnerf_mlp_chain": (c_int, [c_vp, c_i64, c_i64, c_int, ctypes.POINTER(ChainLayer), c_int, c_int, c_vp, c_i64, c_i64, c_vp]),
     "dmnerf_copy_cols_pad": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
     "dmnerf_ray_embed": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "dmnerf_wgrad_set_trace": (c_int, [c_vp]),

@@ -12,6 +12,8 @@ on the strided kernel of ``csrc/generic.hip``.  One pass over HBM per layer (the
 ``DM_NeRF._fused_ok()`` is false; the shipped shape never comes here.  No torch compute ops: tensors are allocated with torch, every FLOP runs in
 ``libdmnerf_hip.so``.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -202,7 +204,19 @@ def forward_layers(net, x_pos, x_dir, save):
     pk = net.packed_forward()
     h = None
     hs = []                                                  # the ReLU output of every trunk layer
-    for i in range(net.D):
+    lib = _lib.load()
+    chained = save is None and bool(lib.dmnerf_mlp_chain_supported(W, net.inp)) and net.D <= 16 \
+        and os.environ.get("DMNERF_GENERIC_CHAIN", "1") != "0"
+    if chained:
+        # inference on a narrow network: the whole trunk as ONE launch, activations LDS-resident from layer to layer (csrc/gemm_chain.hip)
+        arr = (_lib.ChainLayer * net.D)()
+        for i in range(net.D):
+            p_ = pk[f"mlps.{i}"]
+            arr[i] = _lib.ChainLayer(p_.w.data_ptr(), p_.b.data_ptr(), p_.ldb, int(i > 0), int(i == 0 or net.after_skip(i)), 1)
+        h = _Act.empty(M, W, dev)
+        _lib.check(lib.dmnerf_mlp_chain(_lib.ptr(x_pos.buf), x_pos.ld, _floats_from(x_pos.buf), net.inp, arr, net.D, W, _lib.ptr(h.buf), h.ld, M,
+                                        _lib.stream()), "dmnerf_mlp_chain")
+    for i in range(net.D if not chained else 0):
         out = _Act.empty(M, W, dev)
         if i == 0:
             _linear_nt(x_pos, pk["mlps.0"], out.buf, out.ld, W, out.ld, M, relu=True)

@@ -489,6 +489,21 @@ int dmnerf_pack_nt(const float* d_W, int64_t ldw, int n_rows, int c0, int k0, in
 int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats, int k0, const float* d_A1, int64_t lda1, int64_t a1_floats, int k1,
                    const float* d_B, int64_t b_floats, int ldb, const float* d_bias, float* d_C, int64_t ldc, int n_store, int n_zero,
                    int64_t M, int relu, const float* d_mask, int64_t ldm, int accumulate, void* stream);
+/* The TRUNK of a narrow network (width 32 .. 160, a multiple of 32) as ONE launch in inference (csrc/gemm_chain.hip): the activations
+ * of a 128-sample tile stay in LDS from layer to layer, the weights of all layers stream through an LDS ring.  Layer l: h_l = relu?(
+ * [h_{l-1} if from_act | x if from_x] W_l^T + b_l) with d_B packed by dmnerf_pack_nt (range 0 = the `width` columns of h, range 1 = the
+ * x_cols columns of the encoding; layer 0: from_x only), d_bias [width]; d_x = the row-padded encoding [M][ldx] of dmnerf_ray_embed,
+ * d_out = the last layer's output [M][ldo].  dmnerf_mlp_chain_supported: whether (width, x_cols) fits the CU's LDS.                    */
+#define DMNERF_CHAIN_MAX_LAYERS 16
+typedef struct dmnerf_chain_layer {
+    const float* d_B;
+    const float* d_bias;
+    int ldb;          /* 32 x (width / 32 if from_act) + 32 x ceil(x_cols / 32) if from_x) */
+    int from_act, from_x, relu;
+} dmnerf_chain_layer;
+int dmnerf_mlp_chain_supported(int width, int x_cols);
+int dmnerf_mlp_chain(const float* d_x, int64_t ldx, int64_t x_floats, int x_cols, const dmnerf_chain_layer* layers, int n_layers,
+                     int width, float* d_out, int64_t ldo, int64_t M, void* stream);
 int dmnerf_copy_cols_pad(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t M, int n, int n_pad, void* stream);
 int dmnerf_ray_embed(const float* d_rays_o, const float* d_rays_d, const float* d_z, int64_t N, int S, int Lp, int Lv,
                      float* d_x_pos, int ldp, float* d_x_dir, int ldv, void* stream);
