@@ -191,7 +191,7 @@ def test_create_nerf_is_silent_for_the_shipped_shape(A):
         A.Cfg.create_nerf(args)
 
 
-@pytest.mark.parametrize("D,W,multires,M_", [(6, 128, 6, 1000), (8, 160, 10, 4097), (5, 64, 4, 129), (8, 128, 10, 70000)])
+@pytest.mark.parametrize("D,W,multires,M_", [(6, 128, 6, 1000), (8, 160, 10, 4097), (6, 64, 4, 129), (8, 128, 10, 70000)])
 def test_chained_trunk_equals_the_layer_by_layer_trunk_bit_for_bit(A, D, W, multires, M_, monkeypatch):
     """csrc/gemm_chain.hip (inference, widths up to 160: the trunk as ONE launch, activations LDS-resident) against the same network
     layer by layer on gemm_nt: the chunk order, the k order inside a chunk and the bias-first accumulation are the same, so the raw
@@ -199,7 +199,7 @@ def test_chained_trunk_equals_the_layer_by_layer_trunk_bit_for_bit(A, D, W, mult
     ins_num, mv = 9, 4
     inp, inv = 3 + 6 * multires, 3 + 6 * mv
     sd = O.make_weights(40 + D, ins_num, W=W, gain=1.5, D=D, input_ch_pts=inp, input_ch_views=inv)
-    m = A.M.DM_NeRF(D, W, inp, inv, [4] if D > 5 else [2], ins_num)
+    m = A.M.DM_NeRF(D, W, inp, inv, [4], ins_num)
     m.load_state_dict(sd)
     m = m.cuda().eval()
     assert not m._fused_ok() and bool(A.lib.load().dmnerf_mlp_chain_supported(W, inp))
@@ -216,5 +216,5 @@ def test_chained_trunk_equals_the_layer_by_layer_trunk_bit_for_bit(A, D, W, mult
     assert got.shape == want.shape == (M_, 4 + ins_num + 1)
     assert torch.equal(got, want), float((got - want).abs().max())
     if M_ <= 1000:                                                       # ... and both agree with the oracle
-        ref = O.mlp_forward(sd, x.cpu(), input_ch_pts=inp, input_ch_views=inv, D=D, skips=(4,) if D > 5 else (2,))
+        ref = O.mlp_forward(sd, x.cpu(), input_ch_pts=inp, input_ch_views=inv, D=D)
         assert maxrel(got.cpu(), ref) <= 1e-5
