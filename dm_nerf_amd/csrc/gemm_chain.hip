@@ -105,28 +105,37 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     int fl = 0, fc = 0, ahead = 0;
     int64_t ftile = tile;
     bool fvalid = true;
-    auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {  // the NL pieces of (fl, fc) -- one call per refill
+    // The FETCH layer's operands live in registers and change once per layer: reading them from the kernarg segment per chunk put four
+    // to six scalar-load round trips (each an s_waitcnt the one wave per SIMD sits out) into every 4096-cycle chunk.
+    rsrc_t rsB;
+    int voB = 0, blkB = 0, fn = 0;                       // descriptor, lane offset, bytes per 32-row block, chunks of the fetch layer
+    auto load_fetch_layer = [&]() __attribute__((always_inline)) {
         KArgs* q = args();
-        const rsrc_t rsB = uniform_rsrc(q->L[fl].B, (int64_t)NBB * 32 * q->L[fl].ldb);
-        const int voB = drow * q->L[fl].ldb * 4 + dunit;
-        const int blkB = 32 * q->L[fl].ldb * 4;
+        const int ldb = q->L[fl].ldb;
+        rsB = uniform_rsrc(q->L[fl].B, (int64_t)NBB * 32 * ldb);
+        voB = drow * ldb * 4 + dunit;
+        blkB = 32 * ldb * 4;
+        fn = q->L[fl].kA + q->L[fl].kX;
+    };
+    auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {  // the NL pieces of (fl, fc) -- one call per refill
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             float* dst = ring + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, i * blkB + fc * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, i * fresh_s(blkB) + fc * 128, 0, 0);
         }
     };
     auto advance_fetch = [&]() __attribute__((always_inline)) {
-        KArgs* q = args();
-        if (++fc == q->L[fl].kA + q->L[fl].kX) {
+        if (++fc == fn) {
             fc = 0;
-            if (++fl == q->n_layers) {
+            if (++fl == args()->n_layers) {
                 fl = 0;
                 ftile += gridDim.x;
                 fvalid = ftile < ntiles;
             }
+            load_fetch_layer();
         }
     };
+    load_fetch_layer();
 
     // ---- read geometry: lane (li, half) reads row li of its block, unit (2 t + half) ^ ((li >> 1) & 7) in round t
     unsigned offA[4], offB[4];
