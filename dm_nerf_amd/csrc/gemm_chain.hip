@@ -107,17 +107,19 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     bool fvalid = true;
     // The FETCH layer's operands live in registers and change once per layer: reading them from the kernarg segment per chunk put four
     // to six scalar-load round trips (each an s_waitcnt the one wave per SIMD sits out) into every 4096-cycle chunk.
-    rsrc_t rsB;
-    int voB = 0, blkB = 0, fn = 0;                       // descriptor, lane offset, bytes per 32-row block, chunks of the fetch layer
+    // (the descriptor itself is rebuilt per request from the pointer: four scalar moves; as loop-carried state it does not compile)
+    const float* fB = nullptr;
+    int fldb = 0, voB = 0, fn = 0;                       // weights, their row stride, lane offset, chunks of the fetch layer
     auto load_fetch_layer = [&]() __attribute__((always_inline)) {
         KArgs* q = args();
-        const int ldb = q->L[fl].ldb;
-        rsB = uniform_rsrc(q->L[fl].B, (int64_t)NBB * 32 * ldb);
-        voB = drow * ldb * 4 + dunit;
-        blkB = 32 * ldb * 4;
+        fB = q->L[fl].B;
+        fldb = q->L[fl].ldb;
+        voB = drow * fldb * 4 + dunit;
         fn = q->L[fl].kA + q->L[fl].kX;
     };
     auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {  // the NL pieces of (fl, fc) -- one call per refill
+        const rsrc_t rsB = uniform_rsrc(fB, (int64_t)NBB * 32 * fldb);
+        const int blkB = __builtin_amdgcn_readfirstlane(32 * fldb * 4);
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             float* dst = ring + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;
