@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     const int ring_bytes = CH_LDS_BUDGET - CH_BIAS_BYTES - (NBB + nx) * 16384;
     const int D = ring_bytes / BUF < 4 ? ring_bytes / BUF : 4;                    // (host checked: >= 2)
     const unsigned ring0 = lds_addr(ring), act0 = lds_addr(act), aux0 = lds_addr(aux);
-    const int64_t ntiles = (a.M + 127) / 128;
-    int64_t tile = blockIdx.x;
+    const int ntiles = (int)((a.M + 127) / 128);   // (32-bit: see gemm_nt.hip -- a 64-bit `<` is a vector compare and drags the fetch state into VGPRs)
+    int tile = blockIdx.x;
 
     // ---- weight-ring DMA geometry (gemm_nt): wave w owns piece w of every 32-row block; lane l lands at row 8 w + (l >> 3), unit l & 7
     const int drow = 8 * w + (lane >> 3);
@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     const int xunit_odd = ((lane & 7) ^ (((xrow >> 1) + 4) & 7)) << 4;             // j odd:  + 4
     const int voX_even = (int)(xrow * a.ldx * 4) + xunit_even, voX_odd = (int)(xrow * a.ldx * 4) + xunit_odd;
     auto bound = [](int64_t want, int64_t have) { const int64_t b = want < have ? want : have; return b < 0x1fffffff ? b : (int64_t)0x1fffffff; };
-    auto issue_aux = [&](int64_t t) __attribute__((always_inline)) {               // the encoding rows of tile t (this wave's 32) into AUX
+    auto issue_aux = [&](int t) __attribute__((always_inline)) {               // the encoding rows of tile t (this wave's 32) into AUX
         KArgs* q = args();
-        const int64_t r0 = t * 128 + 32 * w;
+        const int64_t r0 = (int64_t)t * 128 + 32 * w;
         const int64_t rows = q->M - r0 < 32 ? (q->M - r0 > 0 ? q->M - r0 : 0) : 32;          // rows beyond M read as 0
         const rsrc_t rsX = uniform_rsrc(q->X + (r0 < q->M ? r0 : 0) * q->ldx, rows > 0 ? bound(rows * q->ldx, q->x_floats - r0 * q->ldx) : 0);
         const int ld8 = (int)(8 * q->ldx * 4);
@@ -103,23 +103,21 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 
     // ---- the weight stream: (layer fl, chunk fc) is the next request
     int fl = 0, fc = 0, ahead = 0;
-    int64_t ftile = tile;
+    int ftile = tile;
     bool fvalid = true;
     // The FETCH layer's operands live in registers and change once per layer: reading them from the kernarg segment per chunk put four
     // to six scalar-load round trips (each an s_waitcnt the one wave per SIMD sits out) into every 4096-cycle chunk.
-    // (the descriptor itself is rebuilt per request from the pointer: four scalar moves; as loop-carried state it does not compile)
-    const float* fB = nullptr;
-    int fldb = 0, voB = 0, fn = 0;                       // weights, their row stride, lane offset, chunks of the fetch layer
+    rsrc_t rsB;
+    int voB = 0, blkB = 0, fn = 0;                       // descriptor, lane offset, bytes per 32-row block, chunks of the fetch layer
     auto load_fetch_layer = [&]() __attribute__((always_inline)) {
         KArgs* q = args();
-        fB = q->L[fl].B;
-        fldb = q->L[fl].ldb;
-        voB = drow * fldb * 4 + dunit;
+        const int ldb = q->L[fl].ldb;
+        rsB = uniform_rsrc(q->L[fl].B, (int64_t)NBB * 32 * ldb);
+        voB = drow * ldb * 4 + dunit;
+        blkB = 32 * ldb * 4;
         fn = q->L[fl].kA + q->L[fl].kX;
     };
     auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {  // the NL pieces of (fl, fc) -- one call per refill
-        const rsrc_t rsB = uniform_rsrc(fB, (int64_t)NBB * 32 * fldb);
-        const int blkB = __builtin_amdgcn_readfirstlane(32 * fldb * 4);
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             float* dst = ring + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             fc = 0;
             if (++fl == args()->n_layers) {
                 fl = 0;
-                ftile += gridDim.x;
+                ftile += (int)gridDim.x;
                 fvalid = ftile < ntiles;
             }
             load_fetch_layer();
@@ -265,7 +263,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the encoding is free once the last layer that reads it has run: request the NEXT tile's rows now
-                if (l == q->last_aux_layer && tile + gridDim.x < ntiles) issue_aux(tile + gridDim.x);
+                if (l == q->last_aux_layer && tile + (int)gridDim.x < ntiles) issue_aux(tile + (int)gridDim.x);
             }
             // the A operand of the stream's next chunk (round 0) now that ACT holds the new activations (at the tile boundary: below)
             if (l + 1 < n_layers) {
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
         // (l & 7) ^ ((row >> 1) & 7) of the row)
         {
             KArgs* q = args();
-            const int64_t r0 = tile * 128 + 32 * w;
+            const int64_t r0 = (int64_t)tile * 128 + 32 * w;
             const int64_t rows = q->M - r0 < 32 ? q->M - r0 : 32;
             if (rows > 0) {
                 const rsrc_t rsC = uniform_rsrc(q->out + r0 * q->ldo, (rows - 1) * q->ldo + NBB * 32);
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 }
             }
         }
-        const int64_t next = tile + gridDim.x;
+        const int next = tile + (int)gridDim.x;
         if (next >= ntiles) break;
         tile = next;
         // the next tile's encoding has landed (requested behind the last layer that read this tile's; when that IS the last layer its

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     const int nchunk = a.nc0 + a.nc1;
     // PERSISTENT: the grid is (at most) one workgroup per CU slot and a workgroup walks the sample tiles blockIdx.x, + gridDim.x, ...
     // (a tile's fixed cost -- workgroup launch, the first chunks' DMA latency, the stores draining -- was ~10 us against 5 .. 40 us of MFMA work)
-    const int64_t ntiles = (a.M + 127) / 128;
-    int64_t tile = blockIdx.x;
+    // (32-bit tile counters: a 64-bit `<` has no scalar form -- it compiled to a vector compare, the fetch state moved to VGPRs with it and
+    // every DMA request sat in a waterfall loop; the host bounds M)
+    const int ntiles = (int)((a.M + 127) / 128);
+    int tile = blockIdx.x;
 
     // ---- DMA geometry (wgrad.hip): wave w owns the 1-KiB piece w of every 32-row block (rows 8 w .. 8 w + 7); lane l lands at LDS
     // row 8 w + (l >> 3), unit l & 7, so it must FETCH unit (l & 7) ^ ((row >> 1) & 7) of that row
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     // per-tile state: rows beyond M are beyond the A descriptors' ranges (they read as 0 and feed rows the epilogue never stores)
     int64_t i0 = 0, rows_valid = 0;
     rsrc_t rsA0, rsA1;
-    auto set_tile = [&](int64_t t) __attribute__((always_inline)) {
+    auto set_tile = [&](int t) __attribute__((always_inline)) {
         KArgs* q = args();
-        i0 = t * 128;
+        i0 = (int64_t)t * 128;
         rows_valid = q->M - i0 < 128 ? q->M - i0 : 128;
         rsA0 = uniform_rsrc(q->A0 + i0 * q->lda0, bound(rows_valid * q->lda0, q->a0_floats - i0 * q->lda0));
         rsA1 = q->A1 ? uniform_rsrc(q->A1 + i0 * q->lda1, bound(rows_valid * q->lda1, q->a1_floats - i0 * q->lda1)) : rsA0;
@@ -173,14 +175,14 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
     // Fetch state: the tile / chunk the NEXT request is for (rsA0 / rsA1 are the FETCH tile's descriptors); compute state: tile, i0.
     int fc = 0;                                         // chunk (inside the fetch tile) of the next request
     int ahead = 0;                                      // chunks requested beyond the one being consumed
-    int64_t ftile = tile;
+    int ftile = tile;
     bool fvalid = true;
     set_tile(ftile);
     const int64_t i0_first = i0;
     auto advance_fetch = [&]() __attribute__((always_inline)) {           // after the NL pieces of (ftile, fc) have been issued
         if (++fc == nchunk) {
             fc = 0;
-            ftile += gridDim.x;
+            ftile += (int)gridDim.x;
             fvalid = ftile < ntiles;
             if (fvalid) set_tile(ftile);
         }
@@ -273,9 +275,9 @@ __global__ __launch_bounds__(256, nt_occupancy(NBB)) void gemm_nt_kernel(const N
 
         const int64_t i0_done = i0c;
         const int64_t rows_done = args()->M - i0_done < 128 ? args()->M - i0_done : 128;
-        const int64_t next = tile + gridDim.x;
+        const int next = tile + (int)gridDim.x;
         const bool more = next < ntiles;
-        i0c = next * 128;
+        i0c = (int64_t)next * 128;
 
         // ---- epilogue: lane holds column n = j0 + 32 b + li, rows 32 w + (r & 3) + 8 (r >> 2) + 4 half
         // (`fresh` hides a value's origin: what is derived from it is computed HERE, in every trip, instead of being hoisted out of the
