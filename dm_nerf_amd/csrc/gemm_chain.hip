@@ -49,7 +49,14 @@ struct ChainArgs {
     int n_layers, last_aux_layer;         // last_aux_layer: the last layer with kX > 0 (the next tile's AUX is requested behind it)
     int total_chunks;                     // sum of kA + kX over the layers
     ChainLayerDev L[CH_MAX_LAYERS];
+    long long* trace;                     // diagnostic builds only (scripts/diag_chain.py): shader-clock stamps of wave 0, tile `CH_TRACE_TILE`
 };
+#if defined(DMN_CH_TRACE)
+#define CH_TRACE_TILE 3
+#define DMN_CH_STAMP(k) do { if (args()->trace && threadIdx.x == 0 && tile_seq == CH_TRACE_TILE) args()->trace[(int64_t)blockIdx.x * 64 + (k)] = (long long)clock64(); } while (0)
+#else
+#define DMN_CH_STAMP(k) do { } while (0)
+#endif
 
 template <int NBB>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
@@ -118,6 +125,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
         fn = q->L[fl].kA + q->L[fl].kX;
     };
     auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {  // the NL pieces of (fl, fc) -- one call per refill
+#if defined(DMN_CH_NO_W)      /* diagnostic builds only (scripts/diag_chain.sh): timing without the weight requests; results are wrong */
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             float* dst = ring + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;
@@ -175,9 +185,13 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 
     f32x16 acc[NBB];
     unsigned sb = 0;
+#if defined(DMN_CH_TRACE)
+    int tile_seq = 0;
+#endif
 #pragma nounroll
     for (;;) {                                           // tiles
         const int n_layers = args()->n_layers;
+        DMN_CH_STAMP(0);
 #pragma nounroll
         for (int l = 0; l < n_layers; ++l) {
             const int kA = args()->L[l].kA;
@@ -213,7 +227,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                         } else {
                             __builtin_amdgcn_s_waitcnt(0x0F70);
                         }
+#if !defined(DMN_CH_NO_BAR)
                         __builtin_amdgcn_s_barrier();
+#endif
                         asm volatile("" ::: "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -244,12 +260,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             // ---- layer epilogue: relu(acc) -> ACT (this wave's rows).  Every ds_read of this layer's A operand has returned (the last
             // round's operands were consumed by its MFMAs), so the rows may be rewritten.
             lds_wait<0>(bv[0]);                                    // (the B read-ahead of the next chunk: registers handed back)
+            DMN_CH_STAMP(1 + 2 * l);
             {
                 KArgs* q = args();
                 const int relu = q->L[l].relu;
                 const int lane_e = fresh_v(lane);
                 const int half_e = lane_e >> 5, li_e = lane_e & 31;
                 float* const aw = act + w * 1024;                  // + block * 4096 floats
+#if defined(DMN_CH_NO_EPI)
+                if (relu == 77)
+#endif
 #pragma unroll
                 for (int b = 0; b < NBB; ++b) {
 #pragma unroll
@@ -263,13 +283,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the encoding is free once the last layer that reads it has run: request the NEXT tile's rows now
+                #if !defined(DMN_CH_NO_AUX)
                 if (l == q->last_aux_layer && tile + (int)gridDim.x < ntiles) issue_aux(tile + (int)gridDim.x);
+#endif
             }
             // the A operand of the stream's next chunk (round 0) now that ACT holds the new activations (at the tile boundary: below)
             if (l + 1 < n_layers) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes have landed
                 lds_read16_async<0>(av[0][0], a_base(kA_next, 0) + offA[0]);
             }
+            DMN_CH_STAMP(2 + 2 * l);
         }
         // ---- the trunk's output: ACT rows -> HBM as 1-KiB stores (lane l: row 8 j + (l >> 3), the 16 bytes at position l & 7 = unit
         // (l & 7) ^ ((row >> 1) & 7) of the row)
@@ -277,7 +300,12 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             KArgs* q = args();
             const int64_t r0 = (int64_t)tile * 128 + 32 * w;
             const int64_t rows = q->M - r0 < 32 ? q->M - r0 : 32;
-            if (rows > 0) {
+#if defined(DMN_CH_NO_OUT)
+            if (rows > 77)
+#else
+            if (rows > 0)
+#endif
+            {
                 const rsrc_t rsC = uniform_rsrc(q->out + r0 * q->ldo, (rows - 1) * q->ldo + NBB * 32);
                 const int lane_e = fresh_v(lane);
                 const int rowl = lane_e >> 3, pos = lane_e & 7;
@@ -298,6 +326,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 }
             }
         }
+        DMN_CH_STAMP(40);
         const int next = tile + (int)gridDim.x;
         if (next >= ntiles) break;
         tile = next;
@@ -305,6 +334,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
         // latency is exposed here, once per tile) -- and with it everything older; then layer 0's first A operand
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         lds_read16_async<0>(av[0][0], a_base(args()->L[0].kA, 0) + offA[0]);
+        DMN_CH_STAMP(41);
+#if defined(DMN_CH_TRACE)
+        ++tile_seq;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
@@ -330,6 +363,11 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+#if defined(DMN_CH_TRACE)
+static long long* g_dmn_ch_trace = nullptr;
+extern "C" int dmnerf_mlp_chain_set_trace(int64_t* d_ticks) { g_dmn_ch_trace = (long long*)d_ticks; return 0; }
+#endif
+
 extern "C" int dmnerf_mlp_chain_supported(int width, int x_cols) {
     if (width < 32 || width % 32 || width / 32 > CH_MAX_NBB || x_cols < 1) return 0;
     const int nbb = width / 32, nx = (x_cols + 31) / 32;
@@ -349,6 +387,9 @@ extern "C" int dmnerf_mlp_chain(const float* d_x, int64_t ldx, int64_t x_floats,
     ChainArgs a{};
     a.X = d_x; a.ldx = ldx; a.x_floats = x_floats; a.nx = nx; a.out = d_out; a.ldo = ldo; a.M = M; a.n_layers = n_layers;
     a.last_aux_layer = -1; a.total_chunks = 0;
+#if defined(DMN_CH_TRACE)
+    a.trace = g_dmn_ch_trace;
+#endif
     for (int l = 0; l < n_layers; ++l) {
         const dmnerf_chain_layer& s = layers[l];
         const int kA = s.from_act ? nbb : 0, kX = s.from_x ? nx : 0;
