@@ -58,7 +58,9 @@ struct ChainArgs {
 #define DMN_CH_STAMP(k) do { } while (0)
 #endif
 
-template <int NBB>
+// D: slots of the weight ring (2 .. 4; the host derives it from the width and the encoding's size -- a template parameter because the
+// hand-over's s_waitcnt takes its count as an immediate, and as a run-time value every chunk walked a ladder of branches for it)
+template <int NBB, int D>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)       // (host pass: launch stub only -- see gemm_nt.hip)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,8 +80,6 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     float* const act = lds + CH_BIAS_BYTES / 4;
     float* const aux = act + NBB * 4096;
     float* const ring = aux + nx * 4096;
-    const int ring_bytes = CH_LDS_BUDGET - CH_BIAS_BYTES - (NBB + nx) * 16384;
-    const int D = ring_bytes / BUF < 4 ? ring_bytes / BUF : 4;                    // (host checked: >= 2)
     const unsigned ring0 = lds_addr(ring), act0 = lds_addr(act), aux0 = lds_addr(aux);
     const int ntiles = (int)((a.M + 127) / 128);   // (32-bit: see gemm_nt.hip -- a 64-bit `<` is a vector compare and drags the fetch state into VGPRs)
     int tile = blockIdx.x;
@@ -124,15 +124,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
         blkB = 32 * ldb * 4;
         fn = q->L[fl].kA + q->L[fl].kX;
     };
-    auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {  // the NL pieces of (fl, fc) -- one call per refill
+    auto issue_weight_piece = [&](unsigned slot_byte, int i) __attribute__((always_inline)) {  // piece i of NL of (fl, fc)
 #if defined(DMN_CH_NO_W)      /* diagnostic builds only (scripts/diag_chain.sh): timing without the weight requests; results are wrong */
         return;
 #endif
+        float* dst = ring + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, i * fresh_s(blkB) + fc * 128, 0, 0);
+    };
+    auto issue_weights = [&](unsigned slot_byte) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            float* dst = ring + (slot_byte + i * 4096 + fresh_s(w) * 1024) / 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)dst, 16, voB, i * fresh_s(blkB) + fc * 128, 0, 0);
-        }
+        for (int i = 0; i < NL; ++i) issue_weight_piece(slot_byte, i);
     };
     auto advance_fetch = [&]() __attribute__((always_inline)) {
         if (++fc == fn) {
@@ -199,9 +200,17 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             const int ln = l + 1 < n_layers ? l + 1 : 0;
             const int kA_next = args()->L[ln].kA;
             {
-                const float* bt = btab + l * NBB * 32 + fresh_v(li);
+                // accumulator register 4 q + e of block b: feature 32 b + 8 q + 4 half + e (of sample li)
+                const float* bt = btab + l * NBB * 32 + fresh_v(4 * half);
 #pragma unroll
-                for (int b = 0; b < NBB; ++b) acc[b] = (f32x16)(bt[32 * b]);
+                for (int b = 0; b < NBB; ++b) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(bt + 32 * b + 8 * q4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[b][4 * q4 + e] = v[e];
+                    }
+                }
             }
 #pragma nounroll
             for (int c = 0; c < nchunk; ++c) {
@@ -216,14 +225,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 cA[0] = an_next + offA[0]; cB[0] = offB[0] + nb;
                 static_for<4>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
+#if defined(DMN_CH_TRACE)
+                    if (l == 2 && c == 1) DMN_CH_STAMP(48 + r);
+#endif
                     lds_wait<0>(av[r & 1]);
 #pragma unroll
                     for (int k = 0; k < NBB; ++k) asm volatile("" : "+" DMN_TILE_RC(bv[r & 1][k]));
                     if constexpr (r == 3) {
-                        if (ahead == D - 1) {
-                            if (D == 2) __builtin_amdgcn_s_waitcnt(0x0F70);
-                            else if (D == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((NL)&15) | (((NL) >> 4) << 14));
-                            else __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * NL) & 15) | (((2 * NL) >> 4) << 14));
+                        if (ahead == D - 1) {                      // the stream's next chunk has landed: all but the (D - 2) NL youngest requests
+                            constexpr int keep = (D - 2) * NL;
+                            __builtin_amdgcn_s_waitcnt(0x0F70 | (keep & 15) | ((keep >> 4) << 14));
                         } else {
                             __builtin_amdgcn_s_waitcnt(0x0F70);
                         }
@@ -246,16 +257,24 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                                 read_ops_one(gc, (r + 1) & 1, cA[(r + 1) & 3], cB[(r + 1) & 3]);
                             }
                         }
-                        if constexpr (r == 3 && g == (NR < NGAP ? NR : NGAP - 1)) {
-                            if (fvalid) issue_weights(sb);                 // refill the released slot with the stream's next chunk
+                        if constexpr (r == 3 && g >= NR && g < NR + NL) {    // (NR + NL = 1 + 2 NBB <= NGAP - 1)
+                            if (fvalid) issue_weight_piece(sb, g - NR);   // refill the released slot with the stream's next chunk, a request per gap
                         }
-                        acc[ib] = mfma32(av[r & 1][0][u], bv[r & 1][ib][u], acc[ib]);
+                        if constexpr (r == 3 && g == NR + NL) {           // ... and the stream's bookkeeping under an MFMA as well
+                            if (fvalid) advance_fetch();
+                            else --ahead;
+                        }
+                        acc[ib] = mfma32(bv[r & 1][ib][u], av[r & 1][0][u], acc[ib]);   // (weights as the ROW operand: see the epilogue)
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
-                if (fvalid) advance_fetch();
-                else --ahead;
+#if defined(DMN_CH_TRACE)
+                if (l == 2 && c == 1) DMN_CH_STAMP(52);
+#endif
                 sb = nb;
+#if defined(DMN_CH_TRACE)
+                if (l == 2 && c == 1) DMN_CH_STAMP(53);
+#endif
             }
             // ---- layer epilogue: relu(acc) -> ACT (this wave's rows).  Every ds_read of this layer's A operand has returned (the last
             // round's operands were consumed by its MFMAs), so the rows may be rewritten.
@@ -264,21 +283,25 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             {
                 KArgs* q = args();
                 const int relu = q->L[l].relu;
+                const int lo = fresh_s(relu ? 0 : (int)0x80000000);  // (opaque: one v_max_i32 per value instead of a max and a select) relu1 (mlp_common.h) is an integer max with 0; without relu: with INT_MIN
                 const int lane_e = fresh_v(lane);
                 const int half_e = lane_e >> 5, li_e = lane_e & 31;
-                float* const aw = act + w * 1024;                  // + block * 4096 floats
+                float* const aw = act + w * 1024 + li_e * 32;      // this sample's row (+ block * 4096 floats)
+                const int sw = (li_e >> 1) & 7;
 #if defined(DMN_CH_NO_EPI)
                 if (relu == 77)
 #endif
 #pragma unroll
                 for (int b = 0; b < NBB; ++b) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int s = (r & 3) + 8 * (r >> 2) + 4 * half_e;                       // row of this wave's 32
-                        const int unit = (li_e >> 2) ^ ((s >> 1) & 7);
-                        float v = acc[b][r];
-                        if (relu) v = relu1(v);
-                        aw[b * 4096 + s * 32 + unit * 4 + (li_e & 3)] = v;
+                    for (int q4 = 0; q4 < 4; ++q4) {               // features 32 b + 8 q4 + 4 half .. + 3: unit 2 q4 + half of the row
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int xi = (int)f2u(acc[b][4 * q4 + e]);
+                            v[e] = __uint_as_float((unsigned)(xi > lo ? xi : lo));
+                        }
+                        *reinterpret_cast<f32x4*>(aw + b * 4096 + (((2 * q4 + half_e) ^ sw) << 2)) = v;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -345,11 +368,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 #endif
 }
 
-template <int NBB>
+template <int NBB, int D>
 int launch_chain(const ChainArgs& a, hipStream_t stream) {
     const int lds_bytes = CH_LDS_BUDGET;
     static DmnOncePerDevice once;
-    if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)chain_kernel<NBB>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BUDGET); });
+    if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)chain_kernel<NBB, D>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BUDGET); });
         e != hipSuccess)
         return dmn_fail_hip(e, "mlp_chain: hipFuncSetAttribute");
     int dev = 0, cus = 0;
@@ -357,7 +380,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess || cus < 1)
         return dmn_fail_hip(e, "mlp_chain: hipDeviceGetAttribute");
     const int64_t ti = (a.M + 127) / 128;
-    hipLaunchKernelGGL(chain_kernel<NBB>, dim3((unsigned)(ti < cus ? ti : cus)), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((chain_kernel<NBB, D>), dim3((unsigned)(ti < cus ? ti : cus)), dim3(256), lds_bytes, stream, a);
     return dmn_check_launch("mlp_chain");
 }
 
@@ -401,12 +424,17 @@ extern "C" int dmnerf_mlp_chain(const float* d_x, int64_t ldx, int64_t x_floats,
         a.total_chunks += kA + kX;
     }
     hipStream_t st = (hipStream_t)stream;
+    const int slots = (CH_LDS_BUDGET - CH_BIAS_BYTES - (nbb + nx) * 16384) / (nbb * 4096);        // >= 2 (dmnerf_mlp_chain_supported)
+    const int depth = slots < 4 ? slots : 4;
+#define DMN_CH_CASE(N)                                                                                           \
+    case N: return depth == 2 ? launch_chain<N, 2>(a, st) : depth == 3 ? launch_chain<N, 3>(a, st) : launch_chain<N, 4>(a, st);
     switch (nbb) {
-        case 1: return launch_chain<1>(a, st);
-        case 2: return launch_chain<2>(a, st);
-        case 3: return launch_chain<3>(a, st);
-        case 4: return launch_chain<4>(a, st);
-        case 5: return launch_chain<5>(a, st);
+        DMN_CH_CASE(1)
+        DMN_CH_CASE(2)
+        DMN_CH_CASE(3)
+        DMN_CH_CASE(4)
+        DMN_CH_CASE(5)
         default: return dmn_fail(DMNERF_E_ARG, "mlp_chain: unsupported width %d", width);
     }
+#undef DMN_CH_CASE
 }

@@ -30,8 +30,8 @@ with torch.no_grad():
 t = ticks.cpu().numpy().reshape(cus, 64).astype(np.float64)
 nbb = W // 32
 skips = [4]
-print(f"D={D} W={W}: shader-clock ticks of wave 0, tile 3 of each workgroup's fine pass, mean over {cus} workgroups (100 MHz ticks x 24 = 2.4 GHz cycles)")
-scale = 24.0                                                                              # s_memtime counts at 100 MHz on this part
+print(f"D={D} W={W}: shader-clock ticks of wave 0, tile 3 of each workgroup's fine pass, mean over {cus} workgroups ")
+scale = 1.0                                                                               # (s_memtime ticks are shader cycles)
 tot = 0.0
 for l in range(D):
     kin = 2 if l == 0 else (nbb + 2 if (l - 1) in skips else nbb)
@@ -44,3 +44,5 @@ out = (t[:, 40] - t[:, 2 * D]).mean() * scale
 gap = (t[:, 41] - t[:, 40]).mean() * scale
 whole = (t[:, 41] - t[:, 0]).mean() * scale
 print(f"  output stores {out:7.0f}; wait for the next tile's encoding {gap:7.0f}; whole tile {whole:9.0f}")
+r = [(t[:, 49 + i] - t[:, 48 + i]).mean() for i in range(5)]
+print(f"  layer 2 chunk 1: rounds 0..3 {r[0]:6.0f} {r[1]:6.0f} {r[2]:6.0f} {r[3]:6.0f} (1024 of MFMA work each; round 3 holds the ring hand-over and the refill); fetch bookkeeping {r[4]:5.0f}")
