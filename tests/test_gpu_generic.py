@@ -218,3 +218,36 @@ def test_chained_trunk_equals_the_layer_by_layer_trunk_bit_for_bit(A, D, W, mult
     if M_ <= 1000:                                                       # ... and both agree with the oracle
         ref = O.mlp_forward(sd, x.cpu(), input_ch_pts=inp, input_ch_views=inv, D=D)
         assert maxrel(got.cpu(), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("N,S,Lp,Lv,ldp,ldv", [(7, 9, 10, 4, 64, 32),        # 63 samples: one ragged workgroup
+                                                (33, 64, 10, 4, 64, 32),      # 2112 samples = 33 tiles of 64
+                                                (5, 13, 6, 2, 39, 15),        # rows that are not 16-byte multiples: the dword copy
+                                                (3, 50, 4, 0, 32, 4)])
+def test_ray_embed_rows_against_the_reference_formulas(A, N, S, Lp, Lv, ldp, ldv):
+    """dmnerf_ray_embed (csrc/gemm_nt.hip): pts = o + d z (render.py:49), viewdirs = d / |d| (render.py:37), both encodings
+    (dm_nerf.py:22-38) as row-padded operands: [x, sin(2^k x), cos(2^k x) ...] per row, pad columns zero, nothing beyond row M - 1."""
+    import ctypes
+    lib = A.lib.load()
+    g = torch.Generator().manual_seed(N * 100 + S)
+    ro = (torch.rand(N, 3, generator=g) * 2 - 1) * 3.0
+    rd = torch.randn(N, 3, generator=g)
+    z = torch.rand(N, S, generator=g) * 6 + 0.5
+    M_ = N * S
+    xp = torch.full((M_ + 3, ldp), 7.0, device="cuda")                   # (three guard rows behind the last sample)
+    xv = torch.full((M_ + 3, ldv), 7.0, device="cuda")
+    A.lib.check(lib.dmnerf_ray_embed(A.lib.ptr(ro.cuda()), A.lib.ptr(rd.cuda()), A.lib.ptr(z.cuda().contiguous()), N, S, Lp, Lv, A.lib.ptr(xp), ldp,
+                                     A.lib.ptr(xv), ldv, A.lib.stream()), "dmnerf_ray_embed")
+    xp, xv = cpu(xp), cpu(xv)
+    pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(M_, 3)
+    vd = (rd / rd.norm(dim=-1, keepdim=True))[:, None, :].expand(N, S, 3).reshape(M_, 3)
+    assert torch.equal(xp[:M_, :3], pts)                                 # (one multiply, one add: bit-equal)
+    assert float((xv[:M_, :3] - vd).abs().max()) <= 2e-7
+    # the encodings against float64 sin / cos of the (float32) coordinate the kernel itself produced
+    for x, L, ld in ((xp, Lp, ldp), (xv, Lv, ldv)):
+        base = x[:M_, :3].double()
+        for k in range(L):
+            assert float((x[:M_, 3 + 6 * k:6 + 6 * k].double() - torch.sin(base * 2.0 ** k)).abs().max()) <= 1.2e-7
+            assert float((x[:M_, 6 + 6 * k:9 + 6 * k].double() - torch.cos(base * 2.0 ** k)).abs().max()) <= 1.2e-7
+        assert float(x[:M_, 3 + 6 * L:].abs().max() if ld > 3 + 6 * L else 0.0) == 0.0
+        assert torch.all(x[M_:] == 7.0)
