@@ -236,7 +236,8 @@ def test_ray_embed_rows_against_the_reference_formulas(A, N, S, Lp, Lv, ldp, ldv
     M_ = N * S
     xp = torch.full((M_ + 3, ldp), 7.0, device="cuda")                   # (three guard rows behind the last sample)
     xv = torch.full((M_ + 3, ldv), 7.0, device="cuda")
-    A.lib.check(lib.dmnerf_ray_embed(A.lib.ptr(ro.cuda()), A.lib.ptr(rd.cuda()), A.lib.ptr(z.cuda().contiguous()), N, S, Lp, Lv, A.lib.ptr(xp), ldp,
+    d_ro, d_rd, d_z = ro.cuda(), rd.cuda(), z.cuda().contiguous()
+    A.lib.check(lib.dmnerf_ray_embed(A.lib.ptr(d_ro), A.lib.ptr(d_rd), A.lib.ptr(d_z), N, S, Lp, Lv, A.lib.ptr(xp), ldp,
                                      A.lib.ptr(xv), ldv, A.lib.stream()), "dmnerf_ray_embed")
     xp, xv = cpu(xp), cpu(xv)
     pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(M_, 3)
