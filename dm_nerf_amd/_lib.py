@@ -109,6 +109,8 @@ SIGNATURES = {
     "dmnerf_pack_nt": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "dmnerf_gemm_nt": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_int,
                                c_i64, c_int, c_vp, c_i64, c_int, c_vp]),
+    "dmnerf_gemm_tn_ws_floats": (c_i64, [c_int, c_int, c_i64]),
+    "dmnerf_gemm_tn": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dmnerf_mlp_chain_supported": (c_int, [c_int, c_int]),
     "dmnerf_mlp_chain": (c_int, [c_vp, c_i64, c_i64, c_int, ctypes.POINTER(ChainLayer), c_int, c_int, c_vp, c_i64, c_i64, c_vp]),
     "dmnerf_copy_cols_pad": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp]),
@@ -159,7 +161,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.dmnerf_abi_version() != 7:
+    if lib.dmnerf_abi_version() != 8:
         raise RuntimeError("libdmnerf_hip.so ABI version mismatch")
     _lib = lib
     return lib

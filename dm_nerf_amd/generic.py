@@ -85,13 +85,35 @@ def _linear_nt(a0, pk, out, ldc, n_store, n_zero, M, a1=None, relu=False, mask=N
                                           _lib.ptr(mask), ldm, int(accumulate), _lib.stream()), "dmnerf_gemm_nt")
 
 
+def _tn_ok(t):
+    """Whether an operand's rows are what gemm_tn's LDS-DMA needs (16-byte aligned: every ``_Act`` is)."""
+    return t.ld % 4 == 0 and t.buf.data_ptr() % 16 == 0
+
+
+def _wgrad_tn(dy, n_out, x, n_in, M, dW, ldw, want_bias):
+    """dW = dy^T x (+ db = column sums of dy) on csrc/gemm_tn.hip: one product launch + one reduction."""
+    lib = _lib.load()
+    dev = x.buf.device
+    db = torch.empty(n_out, dtype=torch.float32, device=dev) if want_bias else None
+    n_ws = int(lib.dmnerf_gemm_tn_ws_floats(n_out, n_in, M))
+    if n_ws < 0:
+        raise RuntimeError("dmnerf_gemm_tn_ws_floats: " + _lib.last_error())
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
+    _lib.check(lib.dmnerf_gemm_tn(_lib.ptr(dy.buf), dy.ld, _floats_from(dy.buf), n_out, _lib.ptr(x.buf), x.ld, _floats_from(x.buf), n_in, M,
+                                  _lib.ptr(dW), ldw, _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.stream()), "dmnerf_gemm_tn")
+    return db
+
+
 def _wgrad_w(dy, n_out, x, n_in, M, dW=None, ldw=None):
     """dW [n_out, n_in] = dy[:, :n_out]^T x[:, :n_in] over the M samples (``dy`` / ``x``: ``_Act``); into ``dW`` with row stride ``ldw``
     when given (one column range of a cat input's weight)."""
     if dW is None:
         dW = torch.empty(n_out, n_in, dtype=torch.float32, device=x.buf.device)
         ldw = n_in
-    _gemm(dy.buf, 1, dy.ld, x.buf, x.ld, 1, dW, ldw, n_out, n_in, M, splits=_splits(n_out, n_in, M))
+    if M > 0 and _tn_ok(dy) and _tn_ok(x):
+        _wgrad_tn(dy, n_out, x, n_in, M, dW, ldw, False)
+    else:                                                    # rows that are not 16-byte aligned: the strided kernel
+        _gemm(dy.buf, 1, dy.ld, x.buf, x.ld, 1, dW, ldw, n_out, n_in, M, splits=_splits(n_out, n_in, M))
     return dW
 
 
@@ -105,6 +127,10 @@ def _colsum(dy, n_out, M):
 
 
 def _wgrad_act(dy, n_out, x, n_in, M):
+    """-> (dW, db) of a layer: one gemm_tn launch (the bias gradient rides on the dy operand's registers)."""
+    if M > 0 and _tn_ok(dy) and _tn_ok(x):
+        dW = torch.empty(n_out, n_in, dtype=torch.float32, device=x.buf.device)
+        return dW, _wgrad_tn(dy, n_out, x, n_in, M, dW, n_in, True)
     return _wgrad_w(dy, n_out, x, n_in, M), _colsum(dy, n_out, M)
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DMNERF_ABI_VERSION 7
+#define DMNERF_ABI_VERSION 8
 
 #define DMNERF_OK 0
 #define DMNERF_E_ARG (-1)     /* bad size / null pointer / unsupported shape */
@@ -489,6 +489,15 @@ int dmnerf_pack_nt(const float* d_W, int64_t ldw, int n_rows, int c0, int k0, in
 int dmnerf_gemm_nt(const float* d_A0, int64_t lda0, int64_t a0_floats, int k0, const float* d_A1, int64_t lda1, int64_t a1_floats, int k1,
                    const float* d_B, int64_t b_floats, int ldb, const float* d_bias, float* d_C, int64_t ldc, int n_store, int n_zero,
                    int64_t M, int relu, const float* d_mask, int64_t ldm, int accumulate, void* stream);
+/* The same path's WEIGHT gradient (csrc/gemm_tn.hip, ABI 8): dW[i*ldw + j] = sum_m dy[m*ldy + i] x[m*ldx + j] for i < n_out, j < n_in
+ * and (d_db non-null) db[i] = sum_m dy[m*ldy + i] -- both operands sample-major rows as gemm_nt reads and writes them (ldy / ldx multiples
+ * of 4, base pointers 16-byte aligned, *_floats = floats from the pointer to the end of its allocation), 32-sample chunks through an
+ * LDS-DMA ring, split over the samples with a workspace of dmnerf_gemm_tn_ws_floats(n_out, n_in, M) floats whose partials are added in
+ * slice order (deterministic).  Replaces dmnerf_gemm's splits > 1 form + dmnerf_colsum on this path (those remain for operands whose
+ * rows are not 16-byte aligned).  torch.autograd of nn.Linear in the reference: dm_nerf.py:66-83 layers under train_dmsr.py:62-64.   */
+int64_t dmnerf_gemm_tn_ws_floats(int n_out, int n_in, int64_t M);
+int dmnerf_gemm_tn(const float* d_dy, int64_t ldy, int64_t dy_floats, int n_out, const float* d_x, int64_t ldx, int64_t x_floats, int n_in,
+                   int64_t M, float* d_dW, int64_t ldw, float* d_db, float* d_ws, int64_t ws_floats, void* stream);
 /* The TRUNK of a narrow network (width 32 .. 160, a multiple of 32) as ONE launch in inference (csrc/gemm_chain.hip): the activations
  * of a 128-sample tile stay in LDS from layer to layer, the weights of all layers stream through an LDS ring.  Layer l: h_l = relu?(
  * [h_{l-1} if from_act | x if from_x] W_l^T + b_l) with d_B packed by dmnerf_pack_nt (range 0 = the `width` columns of h, range 1 = the

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol_and_binding_matches():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dmnerf_hip.h but not exported"
     assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
-    assert lib.dmnerf_abi_version() == 7
+    assert lib.dmnerf_abi_version() == 8
     assert isinstance(lib.dmnerf_device_count(), int)   # 0 on a CPU-only host, never an error
 
 

@@ -252,3 +252,31 @@ def test_ray_embed_rows_against_the_reference_formulas(A, N, S, Lp, Lv, ldp, ldv
             assert float((x[:M_, 6 + 6 * k:9 + 6 * k].double() - torch.cos(base * 2.0 ** k)).abs().max()) <= 1.2e-7
         assert float(x[:M_, 3 + 6 * L:].abs().max() if ld > 3 + 6 * L else 0.0) == 0.0
         assert torch.all(x[M_:] == 7.0)
+
+
+@pytest.mark.parametrize("M_,n_out,n_in", [(1000, 128, 128), (4097, 64, 160), (257, 3, 64), (70001, 13, 64), (300, 128, 27), (31, 1, 128),
+                                           (5000, 320, 63), (2048, 192, 192), (1, 5, 7), (9000, 40, 288)])
+def test_gemm_tn_weight_and_bias_gradient(A, M_, n_out, n_in):
+    """dmnerf_gemm_tn (csrc/gemm_tn.hip): dW = dy^T x and db = column sums of dy over M sample-major rows -- every tile shape class
+    (1 x 4, 1 x 8, 4 x 1, 8 x 1, 2 x 2 .. 4 x 4 blocks, several output tiles), ragged last chunk, fewer chunks than slices, a column range of
+    a wider dW (the cat inputs' halves), pad columns holding other data; against float64, and bit-reproducible from run to run."""
+    G = A.G
+    g = torch.Generator().manual_seed(M_ + n_out)
+    dy, x = G._Act.empty(M_, n_out, "cuda"), G._Act.empty(M_, n_in, "cuda")
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g))               # (pad columns too: they must not reach dW / db)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g))
+    ldw = n_in + 5
+    dW = torch.full((n_out, ldw), 7.0, device="cuda")
+    db = G._wgrad_tn(dy, n_out, x, n_in, M_, dW, ldw, True)
+    dW2 = torch.full((n_out, ldw), 7.0, device="cuda")
+    db2 = G._wgrad_tn(dy, n_out, x, n_in, M_, dW2, ldw, True)
+    dW3 = torch.empty(n_out, n_in, device="cuda")
+    assert G._wgrad_tn(dy, n_out, x, n_in, M_, dW3, n_in, False) is None
+    a64, b64 = cpu(dy.buf)[:, :n_out].double(), cpu(x.buf)[:, :n_in].double()
+    want_W, want_b = a64.T @ b64, a64.sum(0)
+    got_W, got_b = cpu(dW), cpu(db)
+    assert torch.all(got_W[:, n_in:] == 7.0)
+    tol = 4e-6 * max(1.0, M_ ** 0.5)
+    assert float((got_W[:, :n_in].double() - want_W).abs().max()) <= tol
+    assert float((got_b.double() - want_b).abs().max()) <= tol
+    assert torch.equal(got_W, cpu(dW2)) and torch.equal(got_b, cpu(db2)) and torch.equal(cpu(dW3), got_W[:, :n_in])
