@@ -30,7 +30,7 @@ using namespace dmn;
 
 namespace {
 
-constexpr int TN_LDS_BUDGET = 131072;
+constexpr int TN_LDS_BUDGET = 163840;
 
 struct TnArgs {
     const float* A; int64_t lda, a_floats;      // dy [M][lda] (floats from the pointer to the end of its allocation)
@@ -189,41 +189,67 @@ struct TnReduceArgs {
     float* db;                                  // nullable
 };
 
-// dW[i][j] = sum over the slices (in slice order, eight independent running sums folded in a fixed order) of the tile partials;
-// db[i] likewise over slices and the two lane halves
-__global__ void reduce_tn_kernel(const TnReduceArgs a) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dW[i][j] = sum over the slices of the tile partials, db[i] likewise over slices and the two lane halves -- in a fixed order: a
+// workgroup owns 32 consecutive outputs; thread (j, g) adds the terms g, g + 8, g + 16, ... of output j (8 loads in flight per
+// thread: a 128-byte row per slice and wave quarter), then the eight partial sums meet in LDS and are added g = 0 .. 7.
+// (One thread per output walked all 256 slices alone: 57 us for a 128 x 128 gradient -- a third of its product's time.)
+__global__ __launch_bounds__(256) void reduce_tn_kernel(const TnReduceArgs a) {
+    __shared__ float sh[8][33];
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + j;
     const int64_t total = (int64_t)a.n_out * a.n_in;
+    const float* p = nullptr;
+    int64_t stride = 0;
+    int terms = 0;
     if (e < total) {
-        const int i = (int)(e / a.n_in), j = (int)(e % a.n_in);
-        const int tile = (i / a.ta32) * a.tiles_b + j / a.tb32;
-        const int64_t tsz = (int64_t)a.ta32 * a.tb32;
-        const float* p = a.part + (int64_t)tile * a.slices * tsz + (int64_t)(i % a.ta32) * a.tb32 + j % a.tb32;
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 8 <= a.slices; k += 8)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += p[(int64_t)(k + u) * tsz];
-        for (int u = 0; k < a.slices; ++k, ++u) s[u] += p[(int64_t)k * tsz];
-        a.dW[(int64_t)i * a.ldw + j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        const int i = (int)(e / a.n_in), jj = (int)(e % a.n_in);
+        const int tile = (i / a.ta32) * a.tiles_b + jj / a.tb32;
+        stride = (int64_t)a.ta32 * a.tb32;
+        p = a.part + (int64_t)tile * a.slices * stride + (int64_t)(i % a.ta32) * a.tb32 + jj % a.tb32;
+        terms = a.slices;
     } else if (a.db && e < total + a.n_out) {
         const int i = (int)(e - total);
-        const float* p = a.asum + (int64_t)(i / a.ta32) * a.slices * 2 * a.ta32 + i % a.ta32;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < a.slices; ++k) {
-            s[(2 * k) & 3] += p[(int64_t)(2 * k) * a.ta32];
-            s[(2 * k + 1) & 3] += p[(int64_t)(2 * k + 1) * a.ta32];
-        }
-        a.db[i] = (s[0] + s[1]) + (s[2] + s[3]);
+        stride = a.ta32;                                                   // term 2 slice + half
+        p = a.asum + (int64_t)(i / a.ta32) * a.slices * 2 * a.ta32 + i % a.ta32;
+        terms = 2 * a.slices;
+    }
+    float s = 0.f;
+    int k = g;
+    for (; k + 56 < terms; k += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + 8 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < terms; k += 8) s += p[(int64_t)k * stride];
+    sh[g][j] = s;
+    __syncthreads();
+    if (g == 0 && terms > 0) {
+        float t = sh[0][j];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += sh[u][j];
+        if (e < total) a.dW[(e / a.n_in) * a.ldw + e % a.n_in] = t;
+        else a.db[e - total] = t;
     }
 }
 
 struct TnShape { int sa, sb, wa, wb; };
+// blocks per wave along one dimension of the 2 x 2 wave grid for nblk 32-column blocks: the tile (2, 4 or 6 blocks) that needs the fewest
+// tiles (every extra tile re-reads the OTHER operand), among those the one that pads least
+int tn_per_wave(int nblk) {
+    int best = 1, best_tiles = 1 << 30, best_pad = 1 << 30;
+    for (int s = 3; s >= 1; --s) {
+        const int t = 2 * s, tiles = (nblk + t - 1) / t, pad = tiles * t;
+        if (tiles < best_tiles || (tiles == best_tiles && pad < best_pad)) { best = s; best_tiles = tiles; best_pad = pad; }
+    }
+    return best;
+}
 TnShape tn_shape(int n_out, int n_in) {
     const int na = (n_out + 31) / 32, nb = (n_in + 31) / 32;
     if (na == 1) return {1, nb <= 4 ? 1 : 2, 1, 4};
     if (nb == 1) return {na <= 4 ? 1 : 2, 1, 4, 1};
-    return {na <= 2 ? 1 : 2, nb <= 2 ? 1 : 2, 2, 2};
+    return {tn_per_wave(na), tn_per_wave(nb), 2, 2};
 }
 
 struct TnPlan { TnShape sh; int ta, tb, tiles_a, tiles_b, slices; int64_t chunks, part_floats, asum_floats; };
@@ -295,16 +321,24 @@ extern "C" int dmnerf_gemm_tn(const float* d_dy, int64_t ldy, int64_t dy_floats,
     a.part = d_ws; a.asum = d_ws + p.part_floats;
     const int blocks = p.tiles_a * p.tiles_b * p.slices;
     const TnShape& s = p.sh;
-    int rc;
+    int rc = DMNERF_OK;
     if (s.wa == 1) rc = s.sb == 1 ? launch_tn<1, 1, 1, 4>(a, blocks, st) : launch_tn<1, 2, 1, 4>(a, blocks, st);
     else if (s.wb == 1) rc = s.sa == 1 ? launch_tn<1, 1, 4, 1>(a, blocks, st) : launch_tn<2, 1, 4, 1>(a, blocks, st);
-    else if (s.sa == 1) rc = s.sb == 1 ? launch_tn<1, 1, 2, 2>(a, blocks, st) : launch_tn<1, 2, 2, 2>(a, blocks, st);
-    else rc = s.sb == 1 ? launch_tn<2, 1, 2, 2>(a, blocks, st) : launch_tn<2, 2, 2, 2>(a, blocks, st);
+    else {
+#define DMN_TN_CASE(SA_, SB_) case SA_ * 4 + SB_: rc = launch_tn<SA_, SB_, 2, 2>(a, blocks, st); break;
+        switch (s.sa * 4 + s.sb) {
+            DMN_TN_CASE(1, 1) DMN_TN_CASE(1, 2) DMN_TN_CASE(1, 3)
+            DMN_TN_CASE(2, 1) DMN_TN_CASE(2, 2) DMN_TN_CASE(2, 3)
+            DMN_TN_CASE(3, 1) DMN_TN_CASE(3, 2) DMN_TN_CASE(3, 3)
+            default: return dmn_fail(DMNERF_E_ARG, "gemm_tn: no kernel for %d x %d blocks per wave", s.sa, s.sb);
+        }
+#undef DMN_TN_CASE
+    }
     if (rc != DMNERF_OK) return rc;
     TnReduceArgs r{};
     r.part = a.part; r.asum = a.asum; r.slices = p.slices; r.tiles_b = p.tiles_b; r.ta32 = p.ta * 32; r.tb32 = p.tb * 32;
     r.n_out = n_out; r.n_in = n_in; r.dW = d_dW; r.ldw = ldw; r.db = d_db;
     const int64_t total = (int64_t)n_out * n_in + (d_db ? n_out : 0);
-    hipLaunchKernelGGL(reduce_tn_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(reduce_tn_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, r);
     return dmn_check_launch("gemm_tn reduce");
 }

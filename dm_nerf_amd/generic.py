@@ -104,17 +104,18 @@ def _wgrad_tn(dy, n_out, x, n_in, M, dW, ldw, want_bias):
     return db
 
 
-def _wgrad_w(dy, n_out, x, n_in, M, dW=None, ldw=None):
+def _wgrad_w(dy, n_out, x, n_in, M, dW=None, ldw=None, want_bias=False):
     """dW [n_out, n_in] = dy[:, :n_out]^T x[:, :n_in] over the M samples (``dy`` / ``x``: ``_Act``); into ``dW`` with row stride ``ldw``
-    when given (one column range of a cat input's weight)."""
+    when given (one column range of a cat input's weight).  ``want_bias``: -> (dW, db) with db = column sums of dy."""
     if dW is None:
         dW = torch.empty(n_out, n_in, dtype=torch.float32, device=x.buf.device)
         ldw = n_in
     if M > 0 and _tn_ok(dy) and _tn_ok(x):
-        _wgrad_tn(dy, n_out, x, n_in, M, dW, ldw, False)
+        db = _wgrad_tn(dy, n_out, x, n_in, M, dW, ldw, want_bias)
     else:                                                    # rows that are not 16-byte aligned: the strided kernel
         _gemm(dy.buf, 1, dy.ld, x.buf, x.ld, 1, dW, ldw, n_out, n_in, M, splits=_splits(n_out, n_in, M))
-    return dW
+        db = _colsum(dy, n_out, M) if want_bias else None
+    return (dW, db) if want_bias else dW
 
 
 def _colsum(dy, n_out, M):
@@ -128,10 +129,7 @@ def _colsum(dy, n_out, M):
 
 def _wgrad_act(dy, n_out, x, n_in, M):
     """-> (dW, db) of a layer: one gemm_tn launch (the bias gradient rides on the dy operand's registers)."""
-    if M > 0 and _tn_ok(dy) and _tn_ok(x):
-        dW = torch.empty(n_out, n_in, dtype=torch.float32, device=x.buf.device)
-        return dW, _wgrad_tn(dy, n_out, x, n_in, M, dW, n_in, True)
-    return _wgrad_w(dy, n_out, x, n_in, M), _colsum(dy, n_out, M)
+    return _wgrad_w(dy, n_out, x, n_in, M, want_bias=True)
 
 
 # ---- the three products of a linear layer on the STRIDED kernel (csrc/generic.hip::gemm_kernel), plain row-major operands with
@@ -152,7 +150,7 @@ def _wgrad(dy, ldy, n_out, x, ldx, n_in, M):
     """-> dW [n_out, n_in] = dy[:, :n_out]^T x[:, :n_in] over the M samples, db [n_out] = column sums of dy."""
     a, b = _Act(dy, n_out), _Act(x, n_in)
     a.ld, b.ld = ldy, ldx
-    return _wgrad_w(a, n_out, b, n_in, M), _colsum(a, n_out, M)
+    return _wgrad_w(a, n_out, b, n_in, M, want_bias=True)
 
 
 def _slice_act(src, ld_src, col, n, M):
@@ -298,9 +296,9 @@ def backward_layers(net, save, g_out):
     dxr = _Act.empty(M, W, dev)                              # gradient w.r.t. rgb_feature (the dirs columns of the cat need none)
     _linear_nt(dg1, pt["rh"], dxr.buf, dxr.ld, W, dxr.ld, M)
     dWrh = torch.empty(HW, W + inv, dtype=torch.float32, device=dev)     # cat[rgb_feature, dirs]: two column ranges, two sources
-    _wgrad_w(dg1, HW, xr, W, M, dW=dWrh, ldw=W + inv)
+    _, db_rh = _wgrad_w(dg1, HW, xr, W, M, dW=dWrh, ldw=W + inv, want_bias=True)
     _wgrad_w(dg1, HW, x_dir, inv, M, dW=_col(dWrh, W), ldw=W + inv)
-    grads["rgb_feature_linears.0"] = (dWrh, _colsum(dg1, HW, M))
+    grads["rgb_feature_linears.0"] = (dWrh, db_rh)
     grads["rgb_feature_linear"] = _wgrad_act(dxr, W, h, W, M)
     grads["density_linear"] = _wgrad_act(g_den, 1, h, W, M)
     # d h_D = df W_rf + g_sigma w_d, masked by relu'(h_D)
@@ -313,9 +311,9 @@ def backward_layers(net, save, g_out):
         n_in = Wi.shape[1]
         if net.after_skip(i):                                # cat[h, pts]: the two column ranges of dW from their own sources
             dW = torch.empty(W, n_in, dtype=torch.float32, device=dev)
-            _wgrad_w(dy, W, x, W, M, dW=dW, ldw=n_in)
+            _, db = _wgrad_w(dy, W, x, W, M, dW=dW, ldw=n_in, want_bias=True)
             _wgrad_w(dy, W, x_pos, inp, M, dW=_col(dW, W), ldw=n_in)
-            grads[f"mlps.{i}"] = (dW, _colsum(dy, W, M))
+            grads[f"mlps.{i}"] = (dW, db)
         else:
             grads[f"mlps.{i}"] = _wgrad_act(dy, W, x, n_in, M)
         if i > 0:                                            # gradient w.r.t. the relu output of the previous layer

@@ -255,10 +255,10 @@ def test_ray_embed_rows_against_the_reference_formulas(A, N, S, Lp, Lv, ldp, ldv
 
 
 @pytest.mark.parametrize("M_,n_out,n_in", [(1000, 128, 128), (4097, 64, 160), (257, 3, 64), (70001, 13, 64), (300, 128, 27), (31, 1, 128),
-                                           (5000, 320, 63), (2048, 192, 192), (1, 5, 7), (9000, 40, 288)])
+                                           (5000, 320, 63), (2048, 192, 192), (1, 5, 7), (9000, 40, 288), (3000, 160, 128), (777, 96, 192)])
 def test_gemm_tn_weight_and_bias_gradient(A, M_, n_out, n_in):
     """dmnerf_gemm_tn (csrc/gemm_tn.hip): dW = dy^T x and db = column sums of dy over M sample-major rows -- every tile shape class
-    (1 x 4, 1 x 8, 4 x 1, 8 x 1, 2 x 2 .. 4 x 4 blocks, several output tiles), ragged last chunk, fewer chunks than slices, a column range of
+    (1 x 4, 1 x 8, 4 x 1, 8 x 1, 2 x 2 .. 6 x 6 blocks, several output tiles), ragged last chunk, fewer chunks than slices, a column range of
     a wider dW (the cat inputs' halves), pad columns holding other data; against float64, and bit-reproducible from run to run."""
     G = A.G
     g = torch.Generator().manual_seed(M_ + n_out)
