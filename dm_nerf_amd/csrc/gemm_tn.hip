@@ -47,13 +47,15 @@ __device__ __forceinline__ void lds_read4_async(float& v, unsigned addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 
-template <int SA, int SB, int WA, int WB>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs a) {
+// OCC: workgroups per CU the kernel is built for (2: half the LDS ring each, <= 256 registers -- the small tiles, whose barrier and
+// hand-over gaps a second workgroup fills)
+template <int SA, int SB, int WA, int WB, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_kernel(const TnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)       // (host pass: launch stub only -- see gemm_nt.hip)
     static_assert(WA * WB == 4, "four waves");
     constexpr int TA = SA * WA, TB = SB * WB, NL = TA + TB;
     constexpr int BUF = NL * 4096;
-    constexpr int D = TN_LDS_BUDGET / BUF < 4 ? TN_LDS_BUDGET / BUF : 4;
+    constexpr int D = TN_LDS_BUDGET / OCC / BUF < 4 ? TN_LDS_BUDGET / OCC / BUF : 4;
     static_assert(D >= 2 && (D - 1) * NL <= 63, "ring depth / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -65,25 +67,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs a) {
     const int64_t per = (a.chunks + a.slices - 1) / a.slices;
     const int64_t c0 = (int64_t)slice * per;
     const int n = (int)(a.chunks - c0 < per ? (a.chunks - c0 > 0 ? a.chunks - c0 : 0) : per);      // chunks of this slice
-    const float* const A = a.A + (int64_t)ta * TA * 32;
-    const float* const B = a.B + (int64_t)tb * TB * 32;
-    const int64_t a_left = a.a_floats - (int64_t)ta * TA * 32, b_left = a.b_floats - (int64_t)tb * TB * 32;
 
     // ---- DMA: piece (block j, samples 8 w .. 8 w + 7): lane l fetches the 16 bytes at unit l & 7 of sample 8 w + (l >> 3), landing at
-    // the piece's byte 16 l = row (l >> 3), unit l & 7: the tile is row-major [block][32 samples][128 B]
+    // the piece's byte 16 l = row (l >> 3), unit l & 7: the tile is row-major [block][32 samples][128 B].
+    // The chunks of a slice are requested strictly in order: running pointers, the floats left in each allocation, the samples left.
     const int drow = 8 * w + (lane >> 3);
     const int voA = (int)(drow * a.lda * 4) + ((lane & 7) << 4), voB = (int)(drow * a.ldb * 4) + ((lane & 7) << 4);
+    const float* pa = a.A + (int64_t)ta * TA * 32 + c0 * 32 * a.lda;
+    const float* pb = a.B + (int64_t)tb * TB * 32 + c0 * 32 * a.ldb;
+    int64_t a_left = a.a_floats - ((int64_t)ta * TA * 32 + c0 * 32 * a.lda), b_left = a.b_floats - ((int64_t)tb * TB * 32 + c0 * 32 * a.ldb);
+    int64_t rows_left = a.M - c0 * 32;
     auto bound = [](int64_t want, int64_t have) { const int64_t b = want < have ? want : have; return b < 0 ? (int64_t)0 : (b < 0x1fffffff ? b : (int64_t)0x1fffffff); };
-    auto issue_chunk = [&](int c, unsigned slot_byte) __attribute__((always_inline)) {        // chunk c of this slice into a ring slot
-        const int64_t r0 = (c0 + c) * 32;
-        const int64_t rows = a.M - r0 < 32 ? a.M - r0 : 32;                                   // samples beyond M read as 0
-        const rsrc_t rsA = uniform_rsrc(A + r0 * a.lda, bound(rows * a.lda, a_left - r0 * a.lda));
-        const rsrc_t rsB = uniform_rsrc(B + r0 * a.ldb, bound(rows * a.ldb, b_left - r0 * a.ldb));
+    auto issue_chunk = [&](unsigned slot_byte) __attribute__((always_inline)) {               // the slice's next chunk into a ring slot
+        const int64_t rows = rows_left < 32 ? rows_left : 32;                                 // samples beyond M read as 0
+        const rsrc_t rsA = uniform_rsrc(pa, bound(rows * a.lda, a_left));
+        const rsrc_t rsB = uniform_rsrc(pb, bound(rows * a.ldb, b_left));
         float* const dst = lds + (slot_byte + w * 1024) / 4;
 #pragma unroll
         for (int j = 0; j < TA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (DMN_LAS void*)(dst + j * 1024), 16, voA, j * 128, 0, 0);
 #pragma unroll
         for (int j = 0; j < TB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (DMN_LAS void*)(dst + (TA + j) * 1024), 16, voB, j * 128, 0, 0);
+        pa += 32 * a.lda; pb += 32 * a.ldb;
+        a_left -= 32 * a.lda; b_left -= 32 * a.ldb;
+        rows_left -= 32;
     };
 
     // ---- operand reads: block's byte 128 (2 s + half) + 4 li of k-step s
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs a) {
 
     if (n > 0) {
         // prologue: the first D chunks on their way, chunk 0 landed, its operands requested
-        for (int c = 0; c < D && c < n; ++c) issue_chunk(c, c * BUF);
+        for (int c = 0; c < D && c < n; ++c) issue_chunk(c * BUF);
         if (n >= D) __builtin_amdgcn_s_waitcnt(0x0F70 | (((D - 1) * NL) & 15) | ((((D - 1) * NL) >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs a) {
             for (int i = 0; i < SB; ++i)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(rb[p][i][s]));
-            if (c + D < n) issue_chunk(c + D, sb);
+            if (c + D < n) issue_chunk(sb);
             static_for<16>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
 #pragma unroll
@@ -252,7 +258,16 @@ TnShape tn_shape(int n_out, int n_in) {
     return {tn_per_wave(na), tn_per_wave(nb), 2, 2};
 }
 
-struct TnPlan { TnShape sh; int ta, tb, tiles_a, tiles_b, slices; int64_t chunks, part_floats, asum_floats; };
+// two workgroups per CU where both fit: <= 4 accumulator blocks per wave and a chunk of <= 10 blocks (a 2-deep ring in 80 KiB)
+int tn_occupancy(const TnShape& s) {
+#if defined(DMN_TN_OCC1)
+    return 1;
+#else
+    return s.sa * s.sb <= 4 && s.sa * s.wa + s.sb * s.wb <= 10 ? 2 : 1;
+#endif
+}
+
+struct TnPlan { TnShape sh; int occ, ta, tb, tiles_a, tiles_b, slices; int64_t chunks, part_floats, asum_floats; };
 int tn_plan(int n_out, int n_in, int64_t M, TnPlan* p) {
     int dev = 0, cus = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return dmn_fail_hip(e, "gemm_tn: hipGetDevice");
@@ -264,7 +279,8 @@ int tn_plan(int n_out, int n_in, int64_t M, TnPlan* p) {
     p->tiles_a = ((n_out + 31) / 32 + p->ta - 1) / p->ta;
     p->tiles_b = ((n_in + 31) / 32 + p->tb - 1) / p->tb;
     p->chunks = (M + 31) / 32;
-    int64_t s = cus / (p->tiles_a * p->tiles_b);
+    p->occ = tn_occupancy(p->sh);
+    int64_t s = (int64_t)cus * p->occ / (p->tiles_a * p->tiles_b);
     if (s < 1) s = 1;
     if (s > p->chunks) s = p->chunks;
     p->slices = (int)s;
@@ -273,17 +289,24 @@ int tn_plan(int n_out, int n_in, int64_t M, TnPlan* p) {
     return DMNERF_OK;
 }
 
-template <int SA, int SB, int WA, int WB>
-int launch_tn(const TnArgs& a, int blocks, hipStream_t stream) {
+template <int SA, int SB, int WA, int WB, int OCC>
+int launch_tn_occ(const TnArgs& a, int blocks, hipStream_t stream) {
     constexpr int NL = SA * WA + SB * WB;
-    constexpr int D = TN_LDS_BUDGET / (NL * 4096) < 4 ? TN_LDS_BUDGET / (NL * 4096) : 4;
+    constexpr int D = TN_LDS_BUDGET / OCC / (NL * 4096) < 4 ? TN_LDS_BUDGET / OCC / (NL * 4096) : 4;
     constexpr int lds_bytes = D * NL * 4096;
     static DmnOncePerDevice once;
-    if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)gemm_tn_kernel<SA, SB, WA, WB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    if (hipError_t e = once.run([] { return hipFuncSetAttribute((const void*)gemm_tn_kernel<SA, SB, WA, WB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
         e != hipSuccess)
         return dmn_fail_hip(e, "gemm_tn: hipFuncSetAttribute");
-    hipLaunchKernelGGL((gemm_tn_kernel<SA, SB, WA, WB>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((gemm_tn_kernel<SA, SB, WA, WB, OCC>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
     return dmn_check_launch("gemm_tn");
+}
+template <int SA, int SB, int WA, int WB>
+int launch_tn(const TnArgs& a, int blocks, int occ, hipStream_t stream) {
+    if constexpr (SA * SB <= 4 && SA * WA + SB * WB <= 10) {
+        if (occ == 2) return launch_tn_occ<SA, SB, WA, WB, 2>(a, blocks, stream);
+    }
+    return launch_tn_occ<SA, SB, WA, WB, 1>(a, blocks, stream);
 }
 
 }  // namespace
@@ -322,10 +345,10 @@ extern "C" int dmnerf_gemm_tn(const float* d_dy, int64_t ldy, int64_t dy_floats,
     const int blocks = p.tiles_a * p.tiles_b * p.slices;
     const TnShape& s = p.sh;
     int rc = DMNERF_OK;
-    if (s.wa == 1) rc = s.sb == 1 ? launch_tn<1, 1, 1, 4>(a, blocks, st) : launch_tn<1, 2, 1, 4>(a, blocks, st);
-    else if (s.wb == 1) rc = s.sa == 1 ? launch_tn<1, 1, 4, 1>(a, blocks, st) : launch_tn<2, 1, 4, 1>(a, blocks, st);
+    if (s.wa == 1) rc = s.sb == 1 ? launch_tn<1, 1, 1, 4>(a, blocks, p.occ, st) : launch_tn<1, 2, 1, 4>(a, blocks, p.occ, st);
+    else if (s.wb == 1) rc = s.sa == 1 ? launch_tn<1, 1, 4, 1>(a, blocks, p.occ, st) : launch_tn<2, 1, 4, 1>(a, blocks, p.occ, st);
     else {
-#define DMN_TN_CASE(SA_, SB_) case SA_ * 4 + SB_: rc = launch_tn<SA_, SB_, 2, 2>(a, blocks, st); break;
+#define DMN_TN_CASE(SA_, SB_) case SA_ * 4 + SB_: rc = launch_tn<SA_, SB_, 2, 2>(a, blocks, p.occ, st); break;
         switch (s.sa * 4 + s.sb) {
             DMN_TN_CASE(1, 1) DMN_TN_CASE(1, 2) DMN_TN_CASE(1, 3)
             DMN_TN_CASE(2, 1) DMN_TN_CASE(2, 2) DMN_TN_CASE(2, 3)

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../dm_nerf_amd/csrc"
 make -s > /dev/null
 mkdir -p ../../diag_build build/var_chain
-OBJS=$(ls build/*.o | grep -v gemm_chain.o)
+OBJS=$(ls build/*.o | grep -v -- "-hip-\|-host-\|build/gemm_chain.o")
 for v in "$@"; do
   flags=""; for f in ${v//+/ }; do flags="$flags -DDMN_CH_$f"; done
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $flags -c gemm_chain.hip -o build/var_chain/gemm_chain_$v.o
