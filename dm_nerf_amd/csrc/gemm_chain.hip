@@ -5,9 +5,10 @@
 // 0.16 ms of MFMA work -- and a 128 -> 128 layer ran at 0.57 of the f32 roof however its loop was scheduled
 // (profiles/r06/gemm_nt_ablation_r06.txt).  Here:
 //   * ACT [chunk b][wave w][32 rows][128 B]: the current layer's input, wave-private (wave w owns samples 32 w .. 32 w + 31 of the tile
-//     for the whole trunk), in exactly the row-swizzled block form gemm_nt's DMA produces -- so the K loop reads its A operand with the
-//     same ds_read_b128, only from ACT instead of a ring slot; after the loop the wave writes relu(acc) back into ACT (the accumulator
-//     layout holds column li of 16 rows: 16 ds_write_b32 per block) -- no barrier, no HBM;
+//     for the whole trunk), in exactly the row-swizzled block form gemm_nt's DMA produces -- so the K loop reads its activation operand
+//     with the same ds_read_b128, only from ACT instead of a ring slot.  The WEIGHTS are the MFMA's row operand here: a lane's
+//     accumulator registers are then 4 consecutive features of ONE sample (its li), and after the loop the wave writes relu(acc) back
+//     into ACT as 16-byte units (4 ds_write_b128 per block and lane, one v_max_i32 per value) -- no barrier, no HBM;
 //   * AUX: the tile's positional encoding (dm_nerf.py:85-87: layer 0 reads it, the layer after a skip reads [h, pts]), fetched once
 //     per tile by LDS-DMA, each wave its own 32 rows; the NEXT tile's rows are requested as soon as the last layer that reads them is done;
 //   * the weights of all layers are ONE stream of 32-k chunks (NBB blocks of 32 rows x 128 B each) through a D-deep ring shared by the

@@ -45,4 +45,4 @@ gap = (t[:, 41] - t[:, 40]).mean() * scale
 whole = (t[:, 41] - t[:, 0]).mean() * scale
 print(f"  output stores {out:7.0f}; wait for the next tile's encoding {gap:7.0f}; whole tile {whole:9.0f}")
 r = [(t[:, 49 + i] - t[:, 48 + i]).mean() for i in range(5)]
-print(f"  layer 2 chunk 1: rounds 0..3 {r[0]:6.0f} {r[1]:6.0f} {r[2]:6.0f} {r[3]:6.0f} (1024 of MFMA work each; round 3 holds the ring hand-over and the refill); fetch bookkeeping {r[4]:5.0f}")
+print(f"  layer 2 chunk 1: rounds 0..3 {r[0]:6.0f} {r[1]:6.0f} {r[2]:6.0f} {r[3]:6.0f} ({4 * nbb * 64} of MFMA work each, + ~80 per stamp; round 3 holds the ring hand-over and the refill); fetch bookkeeping {r[4]:5.0f}")
