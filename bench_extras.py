@@ -186,3 +186,50 @@ def manipulator_frame_leg(mc, mf, K, dev, world=1):
     return out
 
 
+def generic_shapes_leg(ro, rd, z, dev, steps, shapes=((6, 128), (8, 192), (10, 320))):
+    """Not the headline: the same 4096-ray chunk on network shapes other than the shipped one (config.py:31-41 netdepth / netwidth ->
+    create_nerf :126-138) -- dm_nerf_amd/generic.py on csrc/gemm_nt.hip / gemm_tn.hip, the trunk of W <= 160 networks in inference
+    on csrc/gemm_chain.hip.  Per shape: render time and the WHOLE render's MACs against the f32 MFMA peak (encoding, heads, compositing
+    included in the time), and forward + backward of the same chunk (3 x the forward MACs)."""
+    import warnings
+    from dm_nerf_amd import config as Cfg
+    from dm_nerf_amd.networks import render as R
+    out = {"note": "opt-in shapes (no shipped config changes netdepth / netwidth); random-init weights; fractions are of the whole "
+                   "dm_nerf call, not of one kernel", "shapes": {}}
+    rays = torch.stack([ro[:C.N_RAYS], rd[:C.N_RAYS]])
+    for D, W in shapes:
+        C.quiesce()
+        a = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, netdepth=D, netwidth=W, ins_num=C.INS_NUM, device=dev)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pe, ve, mc, mf, _ = Cfg.create_nerf(a)
+        mac = sum(p.numel() for n, p in mc.named_parameters() if n.endswith("weight"))
+        ea = types.SimpleNamespace(perturb=False, N_importance=C.N_IMP, is_train=False, N_ins=None)
+        with torch.no_grad():
+            R.dm_nerf(rays, pe, ve, mc, mf, z, ea)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                R.dm_nerf(rays, pe, ve, mc, mf, z, ea)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        ta = types.SimpleNamespace(perturb=1.0, N_importance=C.N_IMP, is_train=True, N_ins=None)
+        mc.train(), mf.train()
+
+        def step():
+            o = R.dm_nerf(rays, pe, ve, mc, mf, z, ta)
+            (o['rgb_fine'].sum() + o['rgb_coarse'].sum() + o['ins_fine'].sum()).backward()
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(2, steps // 4)):
+            step()
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0) / max(2, steps // 4)
+        tf = 2.0 * mac * (C.S_COARSE + C.S_COARSE + C.N_IMP) * C.N_RAYS / dt / 1e12
+        out["shapes"][f"{D}x{W}"] = {"render_ms": dt * 1e3, "rays_per_s": C.N_RAYS / dt, "render_tflops": tf,
+                                     "render_frac_of_mfma_peak": tf / C.F32_MFMA_PEAK_TFLOPS, "fwd_bwd_ms": dtt * 1e3,
+                                     "fwd_bwd_frac_of_mfma_peak": 3.0 * tf * dt / dtt / C.F32_MFMA_PEAK_TFLOPS,
+                                     "mac_per_sample": mac, "chained_trunk": bool(W <= 160)}
+        del pe, ve, mc, mf
+    return out
