@@ -219,13 +219,15 @@ def generic_shapes_leg(ro, rd, z, dev, steps, shapes=((6, 128), (8, 192), (10, 3
         def step():
             o = R.dm_nerf(rays, pe, ve, mc, mf, z, ta)
             (o['rgb_fine'].sum() + o['rgb_coarse'].sum() + o['ins_fine'].sum()).backward()
-        step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(max(2, steps // 4)):
+        n_t = max(4, steps // 2)
+        for _ in range(2):                                  # (the first steps size the allocator's pools)
             step()
         torch.cuda.synchronize()
-        dtt = (time.perf_counter() - t0) / max(2, steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(n_t):
+            step()
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0) / n_t
         tf = 2.0 * mac * (C.S_COARSE + C.S_COARSE + C.N_IMP) * C.N_RAYS / dt / 1e12
         out["shapes"][f"{D}x{W}"] = {"render_ms": dt * 1e3, "rays_per_s": C.N_RAYS / dt, "render_tflops": tf,
                                      "render_frac_of_mfma_peak": tf / C.F32_MFMA_PEAK_TFLOPS, "fwd_bwd_ms": dtt * 1e3,
