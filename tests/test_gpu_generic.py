@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [dict(D=6, W=128, multires=6, multires_views=2, ins_num=5),          # narrower / shallower, fewer octaves
           dict(D=8, W=192, multires=10, multires_views=4, ins_num=13),        # a width that is not a multiple of 128
-          dict(D=10, W=320, multires=8, multires_views=4, ins_num=40)]        # deeper / wider, two logit blocks
+          dict(D=10, W=320, multires=8, multires_views=4, ins_num=40),        # deeper / wider, two logit blocks
+          dict(D=8, W=160, multires=10, multires_views=4, ins_num=13),        # five out-blocks: the chained trunk's widest, 6-block gradient tiles
+          dict(D=6, W=64, multires=4, multires_views=1, ins_num=3)]           # two out-blocks, a 9-column direction encoding
 
 
 @pytest.fixture(scope="module")
