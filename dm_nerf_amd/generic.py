@@ -1,5 +1,5 @@
 """DM_NeRF for network shapes other than the one the fused kernels are specialised for (D = 8, W = 256, skips = [4],
-multires 10 / 4): the layer-by-layer path on the kernels of ``csrc/generic.hip``.
+multires 10 / 4): the layer-by-layer path on ``csrc/gemm_nt.hip`` / ``gemm_tn.hip`` / ``gemm_chain.hip``.
 
 ``create_nerf`` (config.py:126-138) passes ``args.netdepth / netwidth / multires / multires_views`` through; no shipped config
 changes them, but a configuration that does must run, not raise.  This module chains one f32-MFMA GEMM per linear
@@ -7,8 +7,11 @@ layer exactly as ``DM_NeRF.forward`` does (networks/dm_nerf.py:80-106) -- skip c
 (:90) as a second K range of the layer that reads them, activation-free feature linears (:89,96), ``h.detach()`` on the ins
 branch (:95), output ``cat[rgb, density, ins]`` (:105) -- and, for training, as its autograd would (data gradient with the ReLU
 mask in the GEMM epilogue, split-K weight gradients, column-sum bias gradients).  Forward and data-gradient products run on
-``csrc/gemm_nt.hip`` (LDS-DMA operand ring, ``ds_read_b128``, one workgroup = 128 samples x all outputs); the weight gradients
-on the strided kernel of ``csrc/generic.hip``.  One pass over HBM per layer (the fused path has none) and used ONLY when
+``csrc/gemm_nt.hip`` (LDS-DMA operand ring, ``ds_read_b128``, one workgroup = 128 samples x all outputs); weight and bias gradients
+on ``csrc/gemm_tn.hip`` (both sample-major operands as 32-sample LDS-DMA chunks, bias sums on the dy registers, deterministic split
+over the samples); in inference the trunk of a network up to 160 wide is ONE launch of ``csrc/gemm_chain.hip`` (activations
+LDS-resident from layer to layer, bit-equal to the layer-by-layer trunk; ``DMNERF_GENERIC_CHAIN=0`` turns it off).  The strided
+kernel of ``csrc/generic.hip`` remains for operands whose rows are not 16-byte aligned.  Used ONLY when
 ``DM_NeRF._fused_ok()`` is false; the shipped shape never comes here.  No torch compute ops: tensors are allocated with torch, every FLOP runs in
 ``libdmnerf_hip.so``.
 """
@@ -268,8 +271,8 @@ def forward_layers(net, x_pos, x_dir, save):
 
 def backward_layers(net, save, g_out):
     """Parameter gradients (list in ``named_parameters`` order) for the upstream gradient g_out [M, 4 + C]: data gradients on gemm_nt
-    (W^T packed, the ReLU derivative as the epilogue's mask), weight gradients as split-K "TN" products on the strided kernel
-    (csrc/generic.hip), bias gradients as column sums."""
+    (W^T packed, the ReLU derivative as the epilogue's mask), weight and bias gradients of a layer as ONE split-K "TN" product on
+    gemm_tn (csrc/gemm_tn.hip; a cat input's two column ranges of dW from their own sources)."""
     g_out = _lib.f32(g_out)
     M = g_out.shape[0]
     dev = g_out.device
