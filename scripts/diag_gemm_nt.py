@@ -19,7 +19,7 @@ for K, N in ((320, 320), (192, 192), (128, 128), (63, 192)):
     b = torch.randn(N, device="cuda")
     pk = G._Packed(W, b, [(0, K)])
     y = G._Act.empty(M, N, "cuda")
-    nbb = int(lib.dmnerf_gemm_nt_blocks(N)); occ = 2 if nbb <= 4 else 1          # csrc/gemm_nt.hip::nt_occupancy
+    nbb = int(lib.dmnerf_gemm_nt_blocks(N)); occ = 2 if nbb <= 6 else 1          # csrc/gemm_nt.hip::nt_occupancy
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     grid = min((M + 127) // 128, cus * occ)
     ticks = torch.zeros(grid * 32 * 4, dtype=torch.int64, device="cuda")
