@@ -282,3 +282,55 @@ def test_gemm_tn_weight_and_bias_gradient(A, M_, n_out, n_in):
     assert float((got_W[:, :n_in].double() - want_W).abs().max()) <= tol
     assert float((got_b.double() - want_b).abs().max()) <= tol
     assert torch.equal(got_W, cpu(dW2)) and torch.equal(got_b, cpu(db2)) and torch.equal(cpu(dW3), got_W[:, :n_in])
+
+
+def test_generic_entry_points_reject_what_they_cannot_do(A):
+    """The C ABI's error behaviour on this path (include/dmnerf_hip.h): DMNERF_E_ARG with a message, nothing launched -- a workspace
+    that is too small, operand rows that are not 16-byte aligned, a width the chained trunk has no room for, a layer whose packed
+    weights do not match its inputs, layer 0 reading activations that do not exist yet; M = 0 is not an error (zero gradients)."""
+    import ctypes
+    lib, L = A.lib.load(), A.lib
+    dev = "cuda"
+    dy, x = torch.randn(64, 32, device=dev), torch.randn(64, 64, device=dev)
+    dW, db = torch.full((32, 64), 7.0, device=dev), torch.full((32,), 7.0, device=dev)
+    need = int(lib.dmnerf_gemm_tn_ws_floats(32, 64, 64))
+    assert need > 0 and int(lib.dmnerf_gemm_tn_ws_floats(0, 64, 64)) == 0
+    ws = torch.empty(need, device=dev)
+
+    def tn(dy_=dy, ldy=32, x_=x, ldx=64, M_=64, ws_floats=need, ldw=64):
+        return lib.dmnerf_gemm_tn(L.ptr(dy_), ldy, dy_.numel(), 32, L.ptr(x_), ldx, x_.numel(), 64, M_, L.ptr(dW), ldw, L.ptr(db), L.ptr(ws), ws_floats, L.stream())
+    assert tn(ws_floats=need - 1) == -1 and "workspace" in L.last_error()
+    assert tn(ldy=30) == -1 and "16-byte" in L.last_error()
+    assert tn(x_=x.reshape(-1)[1:]) == -1 and "16-byte" in L.last_error()
+    assert tn(ldw=63) == -1
+    torch.cuda.synchronize()
+    assert torch.all(dW == 7.0) and torch.all(db == 7.0)                   # nothing was launched
+    assert tn(M_=0) == 0
+    torch.cuda.synchronize()
+    assert torch.all(dW == 0.0) and torch.all(db == 0.0)
+    assert tn() == 0
+    torch.cuda.synchronize()
+    assert float((dW.double().cpu() - dy.double().cpu().T @ x.double().cpu()).abs().max()) <= 1e-4
+
+    # the chained trunk
+    assert lib.dmnerf_mlp_chain_supported(128, 63) == 1 and lib.dmnerf_mlp_chain_supported(160, 63) == 1
+    assert lib.dmnerf_mlp_chain_supported(192, 63) == 0 and lib.dmnerf_mlp_chain_supported(100, 63) == 0 and lib.dmnerf_mlp_chain_supported(128, 0) == 0
+    W_, inp = 128, 63
+    G = A.G
+    xp = G._Act.empty(256, inp, dev)
+    p0 = G._Packed(torch.randn(W_, inp, device=dev), torch.zeros(W_, device=dev), [(0, inp)])
+    p1 = G._Packed(torch.randn(W_, W_, device=dev), torch.zeros(W_, device=dev), [(0, W_)])
+    out = G._Act.empty(256, W_, dev)
+
+    def chain(layers, width=W_, ldo=None):
+        arr = (L.ChainLayer * len(layers))(*layers)
+        return lib.dmnerf_mlp_chain(L.ptr(xp.buf), xp.ld, xp.buf.numel(), inp, arr, len(layers), width, L.ptr(out.buf), out.ld if ldo is None else ldo, 256, L.stream())
+    l0 = L.ChainLayer(p0.w.data_ptr(), p0.b.data_ptr(), p0.ldb, 0, 1, 1)
+    l1 = L.ChainLayer(p1.w.data_ptr(), p1.b.data_ptr(), p1.ldb, 1, 0, 1)
+    assert chain([l0, l1]) == 0
+    assert chain([l1, l0]) == -1 and "layer 0" in L.last_error()
+    assert chain([l0, L.ChainLayer(p1.w.data_ptr(), p1.b.data_ptr(), p1.ldb, 1, 1, 1)]) == -1 and "bad operands" in L.last_error()
+    assert chain([l0, l1], width=192) == -1 and "not supported" in L.last_error()
+    assert chain([l0, l1], ldo=64) == -1
+    assert chain([l0] * 17) == -1
+    torch.cuda.synchronize()
