@@ -445,7 +445,7 @@ def single_gpu_render_legs(a, w, sc, h, res):
         if C.INS_NUM != 59:                               # BASELINE config 3: Replica office_0 width (59 objects), near / far of its config
             wide = C.build_models(w.dev, 59)
             res["render_ins59"] = X.render_leg(*wide, ro, rd, z, a.steps, ins_num=59)
-        res["generic_shapes"] = X.generic_shapes_leg(ro, rd, z, w.dev, max(a.steps // 2, 4))
+        res["generic_shapes"] = X.generic_shapes_leg(ro, rd, z, w.dev, max(a.steps, 8))
     return wide
 
 

@@ -206,8 +206,10 @@ def generic_shapes_leg(ro, rd, z, dev, steps, shapes=((6, 128), (8, 192), (10, 3
         mac = sum(p.numel() for n, p in mc.named_parameters() if n.endswith("weight"))
         ea = types.SimpleNamespace(perturb=False, N_importance=C.N_IMP, is_train=False, N_ins=None)
         with torch.no_grad():
-            R.dm_nerf(rays, pe, ve, mc, mf, z, ea)
-            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.2:            # (sustained rate: the clock settles over tens of ms of continuous work)
+                R.dm_nerf(rays, pe, ve, mc, mf, z, ea)
+                torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 R.dm_nerf(rays, pe, ve, mc, mf, z, ea)
@@ -220,7 +222,7 @@ def generic_shapes_leg(ro, rd, z, dev, steps, shapes=((6, 128), (8, 192), (10, 3
             o = R.dm_nerf(rays, pe, ve, mc, mf, z, ta)
             (o['rgb_fine'].sum() + o['rgb_coarse'].sum() + o['ins_fine'].sum()).backward()
         n_t = max(4, steps // 2)
-        for _ in range(2):                                  # (the first steps size the allocator's pools)
+        for _ in range(4):                                  # (the first steps size the allocator's pools; the clock settles)
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
