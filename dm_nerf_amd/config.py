@@ -19,7 +19,7 @@ def create_nerf(args):
         warnings.warn(f"dm_nerf_amd.create_nerf: netdepth={D} netwidth={W} multires={getattr(args, 'multires', 10)}/"
                       f"{getattr(args, 'multires_views', 4)} is not the shape the fused kernels are specialised for (8 x 256, skips [4], "
                       "multires 10 / 4: every shipped config); it runs on the generic GEMM path (dm_nerf_amd/generic.py) at "
-                      "0.55 - 0.8x of the f32-MFMA roof in inference (measured: W = 128 0.57, 192 0.67, 320 0.77; scripts/generic_time.py) "
+                      "0.6 - 0.8x of the f32-MFMA roof in sustained inference (measured: W = 128 0.63, 192 0.69, 320 0.78; scripts/generic_time.py) "
                       "instead of 0.94, forward + backward at 0.5 - 0.6x",
                       RuntimeWarning, stacklevel=2)
     return position_embedder, view_embedder, model_coarse, model_fine, args
