@@ -259,7 +259,7 @@ def test_training_trajectory_follows_the_oracle(mode, golden, capsys):
     (ReLU boundaries, Adam's sign-like first steps), so the losses are compared step by step where that is tight and in windows
     afterwards, and the PSNR after the 300 steps -- still climbing ~0.03 dB per step there -- as a TWO-SAMPLE comparison (VERDICT
     r04 item 3): twelve HIP runs (five in the opt-in modes) that differ only in the order of the weight-gradient partial sums
-    (plan_budgets()) against the oracle's runs -- four, six once train_traj_v4 / v5 are committed -- that differ only in the order the
+    (plan_budgets()) against the oracle's runs -- eight: train_traj.npz and train_traj_v1 .. v7 -- that differ only in the order the
     batch rows are visited (tests/golden/train_traj*.npz).  The means must
     agree within twice the standard error of their difference AND within 0.5 dB whatever the spreads.  Loss bounds (r03
     measurements: 1.7e-4 over the first 20 steps, 4e-4 .. 5e-3 over the first 100, 1.2 .. 1.6 % on 20-step windows) are ~2.5-3x
@@ -305,7 +305,7 @@ def test_trained_psnr_matches_the_oracle_at_the_plateau(golden, capsys):
     """The same run continued to 2000 steps (the oracle's: ~1-3 h of CPU each in the build container, make_train_traj.py): from
     ~1000 steps on the held-out PSNR has no steady slope left and wanders by a dB between checkpoints, so single checkpoints say
     little.  Statistic per run: the MEAN PSNR over steps 1000 / 1500 / 2000.  Two samples: twelve HIP runs (weight-gradient sums in
-    twelve orders) against the oracle's four to six (batch rows in as many orders): |difference of the sample means| <= 2 standard errors AND
+    twelve orders) against the oracle's six to eight (batch rows in as many orders): |difference of the sample means| <= 2 standard errors AND
     <= 0.75 dB whatever the spreads."""
     g = golden("train_traj")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
