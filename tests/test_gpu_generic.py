@@ -1,6 +1,8 @@
 """GPU tests (-m gpu) of network shapes other than the shipped one (config.py:126-138 passes args.netdepth / netwidth /
-multires / multires_views through): the layer-by-layer path of csrc/generic.hip + dm_nerf_amd/generic.py against the oracle --
-the strided GEMM itself in its three forms, DM_NeRF.forward, the whole dm_nerf dict, and the parameter gradients."""
+multires / multires_views through): dm_nerf_amd/generic.py on csrc/gemm_nt.hip / gemm_tn.hip / gemm_chain.hip / generic.hip against the
+oracle -- the strided GEMM in its three forms, gemm_nt's forward and data-gradient forms, gemm_tn's weight + bias gradient, the
+chained trunk (bit-equal to the layer-by-layer one), dmnerf_ray_embed's rows, the entry points' error behaviour, DM_NeRF.forward,
+the whole dm_nerf dict, and the parameter gradients."""
 import types
 
 import numpy as np
